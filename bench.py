@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py - per-group FP4 (E2M1) fake-quant throughput on MI355X.
+
+Metric (BASELINE.json): Gelements/s + achieved HBM GB/s, per-group FP4 quant of an
+fp16 [65536 x 1920] activation tensor, group 128.  One "step" = one pass of the
+fused kernel over that tensor (one call of fp_quant_e2_per_group_cuda's HIP
+replacement through the C ABI), input and output resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU.  The path is
+embarrassingly parallel over 128-element groups, so each rank quantizes its own
+[65536 x 1920] shard with no data-path collective ("scaling": "weak"); the only
+collectives are the timing barrier and the MAX over ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+ROWS, COLS, GROUP = 65536, 1920, 128
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_ELEM = 4              # fp16 read + fp16 write
+
+
+def cpu_baseline(sample_rows: int = 8192):
+    """The reference's pure-torch CPU path (tr/quant_utils.py:209-230,298-310:
+    abs -> max -> div -> |x - grid| -> argmin -> gather -> mul), restated in
+    oracle/fpq_oracle.py and validated against the reference's own output on the
+    golden vectors, timed on this box's host cores on a bounded sample."""
+    from oracle import fpq_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(sample_rows, COLS, generator=g)          # fp32, as the CPU path is used on weights
+    best = float("inf")
+    t_end = time.perf_counter() + 20.0
+    runs = 0
+    while runs < 6 and (runs < 2 or time.perf_counter() < t_end):
+        xi = x.clone()
+        t0 = time.perf_counter()
+        orc.per_group_argmin_sem(xi, "e2m1", GROUP, clamp3=False)
+        dt = time.perf_counter() - t0
+        if runs > 0:
+            best = min(best, dt)
+        runs += 1
+    return {"value": round(x.numel() / best / 1e9, 5), "unit": "Gelem/s", "cores": cores, "kind": "port",
+            "sample": f"fp32 [{sample_rows}x{COLS}] g={GROUP} E2M1, torch-op restatement of the reference CPU path "
+                      f"(argmin over a [N,15] distance tensor), min of {runs - 1} runs after 1 warm-up"}
+
+
+def unfused_gpu_sequence(x, steps=3):
+    """The reference's GPU op sequence (tr/quant_utils.py:313-330) as torch-ROCm ops
+    around the L0 scan kernel: the 'before' picture on the same GPU."""
+    from fpqvar_amd import ops
+    tab = torch.tensor([-6.0, -4.0, -3.0, -2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+    def once():
+        grid = tab.to(x.device)
+        xs = x.reshape(-1, GROUP)
+        scale = xs.abs().max(dim=-1, keepdim=True)[0] / grid.abs().max()
+        xn = (xs / scale).view(-1).to(torch.float32)
+        q = ops.quant_nearest(xn, grid.type_as(xn))
+        torch.zeros_like(xn)                       # the reference's never-used `idx` output
+        return (q.view(xs.shape) * scale).view(x.shape).to(x.dtype)
+
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(x.numel() / dt / 1e9, 3), "unit": "Gelem/s", "ms": round(dt * 1e3, 4)}
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (null if none)."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            with open(p) as f:
+                return json.load(f).get("traffic_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fpqvar_amd import _lib
+    lib = _lib.lib()
+
+    torch.manual_seed(rank)       # rank 0 = seed 0 = the SURVEY.md section 8d primary input
+    x = torch.randn(ROWS, COLS, device=dev).half()
+    out = torch.empty_like(x)
+    n_rows = x.numel() // GROUP
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
+    xp, op = x.data_ptr(), out.data_ptr()
+
+    def step():
+        st = lib.fpq_quant_rows(xp, op, n_rows, GROUP, _lib.TABLE_IDS["e2m1"], _lib.F16, _lib.F16, sp)
+        if st != 0:
+            _lib.check(st, "fpq_quant_rows")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)            # same stream the kernel is launched on
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps        # average launch duration, HIP events
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        elems = x.numel()
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * elems / (elapsed / args.steps) / 1e9
+        achieved = elems * BYTES_PER_ELEM / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "Gelements/s + achieved HBM GB/s, per-group FP4 quant [65536x1920,g=128]",
+            "value": round(value, 3),
+            "unit": "Gelem/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "fp16 [65536x1920] randn(seed=rank), per-group(128) FP4 E2M1 fake-quant, "
+                                   "fp16 out; one shard of this shape per GPU, no data-path collective",
+                       "rows": ROWS, "cols": COLS, "group": GROUP, "format": "fp_e2 (E2M1)",
+                       "parallelism": f"shard{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                         "kernel": "rows_subwave_kernel<f16,f16,16 lanes/group>",
+                         "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes": elems * BYTES_PER_ELEM},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["unfused_gpu"] = unfused_gpu_sequence(x)
+            except Exception as e:  # extra information only
+                res["unfused_gpu"] = {"error": str(e)[:200]}
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""ctypes binding of libfpq_hip.so (the C ABI declared in include/fpq.h).
+
+PyTorch is plumbing here: device memory (``tensor.data_ptr()``), the current HIP
+stream and the device guard.  There is NO fallback: if the shared library is
+missing or does not load, every op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfpq_hip.so")
+
+F16, F32, F64 = 0, 1, 2
+TABLE_IDS = {"e2m1": 0, "e1m2": 1, "e3m0": 2, "e2m3": 3, "e3m2": 4,
+             "e1m2_neg": 5, "e2m1_pos": 6, "int_neg": 7, "e2m3_pos": 8}
+_DTYPES = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
+
+_lib: Optional[ctypes.CDLL] = None
+
+_c = ctypes
+_SIGS = {
+    "fpq_version": (_c.c_int, []),
+    "fpq_strerror": (_c.c_char_p, [_c.c_int]),
+    "fpq_table_values": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_float)]),
+    "fpq_quant_nearest": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
+                                      _c.c_void_p]),
+    "fpq_quant_nearest_builtin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
+    "fpq_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                   _c.c_void_p]),
+    "fpq_quant_rows_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                        _c.c_int, _c.c_int, _c.c_void_p, _c.c_float, _c.c_void_p]),
+    "fpq_absmax": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "fpq_quant_rows_codes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                         _c.c_int, _c.c_int, _c.c_void_p]),
+    "fpq_dequant_rows_codes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                           _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the C-ABI library.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  fpqvar_amd has no CPU or eager fallback.")
+        l = ctypes.CDLL(LIB_PATH)   # torch is already imported: libamdhip64.so.7 resolves to torch's copy
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().fpq_strerror(status).decode()
+        raise RuntimeError(f"{what}: fpq error {status}: {msg}")
+
+
+def dtype_id(dt: torch.dtype) -> int:
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        raise RuntimeError(f"fpqvar_amd: unsupported dtype {dt}") from None
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: expected a tensor on the GPU, got device {t.device} "
+                           "(fpqvar_amd has no CPU path; the CPU restatement lives in oracle/ for tests only)")
+
+
+def table_values(name: str) -> torch.Tensor:
+    """Host copy of a built-in table as the reference spells it."""
+    l = lib()
+    tid = TABLE_IDS[name]
+    n = l.fpq_table_values(tid, None)
+    buf = (_c.c_float * n)()
+    l.fpq_table_values(tid, buf)
+    return torch.tensor(list(buf), dtype=torch.float32)

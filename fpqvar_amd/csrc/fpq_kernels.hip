@@ -1,0 +1,852 @@
+// fpq_kernels.hip - gfx950 (MI355X) fake-quantization kernels behind include/fpq.h.
+//
+// What the reference computes (PKU-SEC-Lab/FPQVAR, tr/ = models_fp_quant_transform_rotate/):
+//   quant/quant_kernel.cu:25-37        nearest entry of a value table, last index wins ties,
+//                                      best distance starts at 102400 -> NaN/Inf/far give 0.0
+//   tr/quant_utils.py:265-282 ...      ~11 torch ops around that kernel: absmax per row,
+//                                      scale = absmax / max|table|, x / scale, fp32 cast,
+//                                      kernel, q * scale, cast back
+// Here each of those Python bodies is ONE launch: 16-byte coalesced loads, the row
+// kept in registers between the absmax reduction and the rounding, cross-lane
+// reduction with shuffles (rows of <= 1 KiB live inside one wavefront) or through
+// LDS (long rows, one workgroup per row), and the table lookup replaced by a closed
+// form on the minifloat structure (no K-step scan).  HBM traffic is the
+// algorithmic minimum: every input byte read once, every output byte written once.
+//
+// Bit-exactness notes
+//   * all scale / normalise arithmetic is IEEE fp32 (`/` is correctly rounded:
+//     -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default; contraction is
+//     switched off at build time) with the same intermediate roundings to x's dtype
+//     that torch performs (fp16 ops = fp32 compute + one rounding);
+//   * absmax is taken on the integer bit patterns of |x| so that NaN (largest
+//     pattern) propagates exactly like torch's max;
+//   * closed form: for r = |xn|, levels of a sign-magnitude minifloat with
+//     subnormals have spacing 2^(max(e,emin)-M); a tie between two levels goes to
+//     the larger VALUE (the scan's `<=`), i.e. up in magnitude for xn > 0 and down
+//     for xn < 0.  tests/ prove it equal to the scan on every fp16 input and on fp32
+//     neighbourhoods of every midpoint; fpq_quant_nearest keeps the literal scan.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fpq.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;   // 4 wavefronts of 64
+constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident workgroups
+
+// ---------------------------------------------------------------------------------
+// Format descriptors (wave-uniform kernel arguments -> SGPRs)
+// ---------------------------------------------------------------------------------
+struct Fmt {
+  float kmin;       // smallest normal level 2^emin (levels below it are equally spaced)
+  float inv_step0;  // 1 / spacing below kmin
+  float step0;      // spacing below kmin = kmin / 2^M
+  float gmax;       // largest level
+  float limit;      // 102400 + gmax: beyond it the scan selects nothing
+  uint32_t half_add;   // 1 << (22 - M)
+  uint32_t keep_mask;  // ~((1 << (23 - M)) - 1)
+  int32_t zero_code;   // index of 0.0 in the sorted de-duplicated SYMMETRIC table
+  int32_t mshift;      // 23 - M
+  uint32_t kmin_code_base;  // (bits(kmin) >> mshift) - 2^M : level index = (bits>>mshift) - base
+};
+
+struct TableInfo {
+  const char* name;
+  int symmetric;  // usable with fpq_quant_rows
+  float kmin;
+  int mbits;
+  float gmax;
+  int n_pos;  // number of non-negative levels (incl. 0)
+};
+
+// E2M1: bias 1 -> subnormal step .5 below 1.0.  E1M2: bias 1 -> step .25 everywhere.
+// E3M0: bias 3 -> smallest normal .25.  E2M3: bias 1.  E3M2: bias 3.
+// INT_NEG: integers 0..32 = fixed point, expressed as kmin = 32, M = 5 (step 1).
+const TableInfo kTables[FPQ_NUM_TABLES] = {
+    {"e2m1", 1, 1.0f, 1, 6.0f, 8},      {"e1m2", 1, 1.0f, 2, 1.75f, 8},
+    {"e3m0", 1, 0.25f, 0, 16.0f, 8},    {"e2m3", 1, 1.0f, 3, 7.5f, 32},
+    {"e3m2", 1, 0.25f, 2, 28.0f, 32},   {"e1m2_neg", 0, 1.0f, 2, 1.75f, 8},
+    {"e2m1_pos", 0, 1.0f, 1, 6.0f, 8},  {"int_neg", 0, 32.0f, 5, 32.0f, 33},
+    {"e2m3_pos", 0, 1.0f, 3, 7.5f, 32},
+};
+
+inline uint32_t f2u(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+
+Fmt make_fmt(int id) {
+  const TableInfo& t = kTables[id];
+  Fmt f;
+  f.kmin = t.kmin;
+  f.step0 = t.kmin / (float)(1 << t.mbits);
+  f.inv_step0 = 1.0f / f.step0;
+  f.gmax = t.gmax;
+  f.limit = 102400.0f + t.gmax;
+  f.half_add = 1u << (22 - t.mbits);
+  f.keep_mask = ~((1u << (23 - t.mbits)) - 1u);
+  f.zero_code = t.n_pos - 1;
+  f.mshift = 23 - t.mbits;
+  f.kmin_code_base = (f2u(t.kmin) >> f.mshift) - (1u << t.mbits);
+  return f;
+}
+
+// positive levels of a table, ascending (host)
+int pos_levels(int id, float* out) {
+  const TableInfo& t = kTables[id];
+  int n = 0;
+  if (id == FPQ_INT_NEG) {
+    for (int v = 0; v <= 32; ++v) out[n++] = (float)v;
+    return n;
+  }
+  float step0 = t.kmin / (float)(1 << t.mbits);
+  for (int m = 0; m < (1 << t.mbits); ++m) out[n++] = m * step0;
+  for (float base = t.kmin; base <= t.gmax; base *= 2.0f)
+    for (int m = 0; m < (1 << t.mbits); ++m) {
+      float v = base * (1.0f + (float)m / (float)(1 << t.mbits));
+      if (v <= t.gmax) out[n++] = v;
+    }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------
+// Device helpers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
+
+__device__ __forceinline__ float h2f(uint32_t hbits) {
+  _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)hbits);
+  return (float)h;
+}
+__device__ __forceinline__ uint32_t f2h(float f) {
+  _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round to nearest even
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+
+// Magnitude of the nearest level for r = |xn| (r >= 0 or NaN); neg01 = 1 when xn < 0
+// (a tie then resolves to the smaller magnitude).  NaN, Inf and r > limit give 0.
+__device__ __forceinline__ float quant_mag(float r, uint32_t neg01, const Fmt& f) {
+  // binades at or above kmin: keep M mantissa bits, round half up (or half down)
+  uint32_t nb = (fbits(r) + f.half_add - neg01) & f.keep_mask;
+  float qn = u2f(nb);
+  // below kmin: equally spaced levels
+  float t = r * f.inv_step0;  // exact (power of two)
+  float fl = floorf(t);
+  float fr = t - fl;          // exact
+  bool up = neg01 ? (fr > 0.5f) : (fr >= 0.5f);
+  float qs = (fl + (up ? 1.0f : 0.0f)) * f.step0;
+  float q = (r >= f.kmin) ? qn : qs;
+  q = fminf(q, f.gmax);
+  return (r <= f.limit) ? q : 0.0f;
+}
+
+// index of a level magnitude q (exactly a level) among the non-negative levels
+__device__ __forceinline__ int level_index(float q, const Fmt& f) {
+  int hi = (int)((fbits(q) >> f.mshift) - f.kmin_code_base);
+  int lo = (int)(q * f.inv_step0);
+  return (q >= f.kmin) ? hi : lo;
+}
+
+// --- dtype traits: T = storage type of x, all arithmetic in fp32 with T's roundings ---
+template <typename T>
+struct DT;
+template <>
+struct DT<_Float16> {
+  static constexpr int kVec = 8;  // elements per 16-byte lane load
+  static __device__ __forceinline__ float get(const u32x4& v, int i) {
+    uint32_t w = v[i >> 1];
+    return h2f((i & 1) ? (w >> 16) : (w & 0xFFFFu));
+  }
+  static __device__ __forceinline__ void put(u32x4& v, int i, float p) {
+    uint32_t h = f2h(p);
+    uint32_t w = v[i >> 1];
+    v[i >> 1] = (i & 1) ? ((w & 0x0000FFFFu) | (h << 16)) : ((w & 0xFFFF0000u) | h);
+  }
+  static __device__ __forceinline__ uint32_t absbits(float xf) { return f2h(xf) & 0x7FFFu; }
+  static __device__ __forceinline__ float from_absbits(uint32_t b) { return h2f(b); }
+  static __device__ __forceinline__ float round(float v) { return h2f(f2h(v)); }
+  static __device__ __forceinline__ bool bits_nan(uint32_t b) { return b > 0x7C00u; }
+};
+template <>
+struct DT<float> {
+  static constexpr int kVec = 4;
+  static __device__ __forceinline__ float get(const u32x4& v, int i) { return u2f(v[i]); }
+  static __device__ __forceinline__ void put(u32x4& v, int i, float p) { v[i] = fbits(p); }
+  static __device__ __forceinline__ uint32_t absbits(float xf) { return fbits(xf) & 0x7FFFFFFFu; }
+  static __device__ __forceinline__ float from_absbits(uint32_t b) { return u2f(b); }
+  static __device__ __forceinline__ float round(float v) { return v; }
+  static __device__ __forceinline__ bool bits_nan(uint32_t b) { return b > 0x7F800000u; }
+};
+
+template <typename T>
+__device__ __forceinline__ float load_scalar(const T* p) {
+  return (float)(*p);
+}
+template <typename T>
+__device__ __forceinline__ void store_scalar(T* p, float v) {
+  *p = (T)v;
+}
+
+// scale = (T)(absmax / gmax), returned widened to fp32
+template <typename T>
+__device__ __forceinline__ float scale_of(uint32_t amax_bits, float gmax) {
+  return DT<T>::round(DT<T>::from_absbits(amax_bits) / gmax);
+}
+
+// One element of a symmetric-table row.  s = scale (already rounded to T).
+template <typename T>
+__device__ __forceinline__ float quant_sym(float xf, float s, const Fmt& f) {
+  float xn = DT<T>::round(xf / s);
+  uint32_t neg = (xn < 0.0f) ? 1u : 0u;
+  float qm = quant_mag(fabsf(xn), neg, f);
+  float q = (neg && qm != 0.0f) ? -qm : qm;  // the table's zero is +0.0
+  return q * s;                              // fp32 product; 0*inf and 0*nan poison the row
+}
+
+// One element of a dual-format row (neg table for x <= 0, pos table for x > 0).
+template <typename T>
+__device__ __forceinline__ float quant_dual(float xf, float sn, float sp, const Fmt& fn, const Fmt& fp) {
+  bool isn = xf <= 0.0f, isp = xf > 0.0f;  // NaN: neither
+  float qn = 0.0f, qp = 0.0f;
+  if (isn) {
+    float xn = DT<T>::round(xf / sn);
+    float qm = quant_mag(fabsf(xn), 1u, fn);
+    qn = (qm != 0.0f) ? -qm : 0.0f;
+  }
+  if (isp) {
+    float xn = DT<T>::round(xf / sp);
+    qp = quant_mag(xn, 0u, fp);
+  }
+  float a = qn * sn;
+  float b = qp * sp;
+  return a + b;
+}
+
+// clamp to +-clip with torch.clamp(Tensor bounds) NaN rules
+__device__ __forceinline__ float clamp_like_torch(float xf, float clip, bool clip_nan) {
+  if (clip_nan) return __builtin_nanf("");
+  if (xf != xf) return xf;
+  return fminf(fmaxf(xf, -clip), clip);
+}
+
+template <int LANES>
+__device__ __forceinline__ uint32_t lanes_max(uint32_t v) {
+#pragma unroll
+  for (int m = LANES / 2; m >= 1; m >>= 1) {
+    uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+    v = v > o ? v : o;
+  }
+  return v;
+}
+
+struct DualArgs {
+  Fmt fneg, fpos;
+  const void* clip_absmax;  // device scalar or nullptr
+  float clip_strength;
+};
+
+template <typename T>
+__device__ __forceinline__ float clip_value(const DualArgs& d, bool* is_nan) {
+  float am = load_scalar<T>((const T*)d.clip_absmax);
+  float c = DT<T>::round(d.clip_strength * am);
+  *is_nan = (c != c);
+  return c;
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 1: rows of <= 1 KiB - LPR lanes of one wavefront own a row, one 16-byte
+// load per lane, the row never leaves registers.  Grid-stride over wave tiles,
+// UNROLL independent loads in flight per lane.
+// ---------------------------------------------------------------------------------
+template <typename Tin, typename Tout, int LPR, bool DUAL, int UNROLL>
+__global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __restrict__ x,
+                                                             void* __restrict__ outv, int64_t n_vec,
+                                                             Fmt fs, DualArgs dual) {
+  constexpr int V = DT<Tin>::kVec;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  int64_t v0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  float clip = 0.0f;
+  bool clip_nan = false;
+  const bool has_clip = DUAL && dual.clip_absmax != nullptr;
+  if (has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+
+  // n_vec is a multiple of LPR (whole rows) and LPR divides 64, so a row never
+  // straddles the `live` boundary inside a wavefront.
+  for (; v0 < n_vec; v0 += stride * UNROLL) {
+    u32x4 raw[UNROLL];
+    bool live[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      int64_t v = v0 + u * stride;
+      live[u] = v < n_vec;
+      raw[u] = live[u] ? __builtin_nontemporal_load(x + v) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      float xf[V];
+      uint32_t mneg = 0, mpos = 0;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float e = DT<Tin>::get(raw[u], i);
+        if (has_clip) e = clamp_like_torch(e, clip, clip_nan);
+        xf[i] = e;
+        uint32_t ab = DT<Tin>::absbits(e);
+        if (DUAL) {
+          uint32_t bn = (e <= 0.0f) ? ab : 0u, bp = (e > 0.0f) ? ab : 0u;
+          mneg = mneg > bn ? mneg : bn;
+          mpos = mpos > bp ? mpos : bp;
+        } else {
+          mneg = mneg > ab ? mneg : ab;
+        }
+      }
+      mneg = lanes_max<LPR>(mneg);
+      if (DUAL) mpos = lanes_max<LPR>(mpos);
+      if (!live[u]) continue;
+      float p[V];
+      if (DUAL) {
+        float sn = scale_of<Tin>(mneg, dual.fneg.gmax), sp = scale_of<Tin>(mpos, dual.fpos.gmax);
+#pragma unroll
+        for (int i = 0; i < V; ++i) p[i] = quant_dual<Tin>(xf[i], sn, sp, dual.fneg, dual.fpos);
+      } else {
+        float s = scale_of<Tin>(mneg, fs.gmax);
+#pragma unroll
+        for (int i = 0; i < V; ++i) p[i] = quant_sym<Tin>(xf[i], s, fs);
+      }
+      int64_t v = v0 + u * stride;
+      if constexpr (sizeof(Tout) == sizeof(Tin)) {
+        u32x4 o = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < V; ++i) DT<Tout>::put(o, i, p[i]);
+        __builtin_nontemporal_store(o, (u32x4*)outv + v);
+      } else if constexpr (sizeof(Tout) < sizeof(Tin)) {  // f32 -> f16: 4 halves = 8 bytes
+        u32x2 o = {f2h(p[0]) | (f2h(p[1]) << 16), f2h(p[2]) | (f2h(p[3]) << 16)};
+        __builtin_nontemporal_store(o, (u32x2*)outv + v);
+      } else {  // f16 -> f32: 8 floats = 32 bytes
+        u32x4 o0 = {fbits(p[0]), fbits(p[1]), fbits(p[2]), fbits(p[3])};
+        u32x4 o1 = {fbits(p[4]), fbits(p[5]), fbits(p[6]), fbits(p[7])};
+        __builtin_nontemporal_store(o0, (u32x4*)outv + 2 * v);
+        __builtin_nontemporal_store(o1, (u32x4*)outv + 2 * v + 1);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 2: long rows (per-token 1920 / 7680 / 2304 / 9216 ...): one workgroup per
+// row, up to MAXC 16-byte vectors per lane kept in registers between the
+// reduction (shuffles + LDS) and the rounding; longer rows are re-read (L2).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t* sh) {
+  v = lanes_max<64>(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();  // protect sh from the previous use
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  uint32_t r = sh[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / 64; ++i) r = r > sh[i] ? r : sh[i];
+  return r;
+}
+
+template <typename Tin, typename Tout, bool DUAL, int MAXC>
+__global__ __launch_bounds__(kBlock) void rows_block_kernel(const Tin* __restrict__ x,
+                                                           Tout* __restrict__ out, int64_t rows,
+                                                           int64_t cols, Fmt fs, DualArgs dual) {
+  constexpr int V = DT<Tin>::kVec;
+  __shared__ uint32_t sh[kBlock / 64];
+  const int64_t vec_per_row = cols / V;  // cols % V == 0 guaranteed by the host
+  float clip = 0.0f;
+  bool clip_nan = false;
+  const bool has_clip = DUAL && dual.clip_absmax != nullptr;
+  if (has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const u32x4* xr = (const u32x4*)(x + row * cols);
+    u32x4 raw[MAXC];
+    uint32_t mneg = 0, mpos = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      int64_t v = (int64_t)c * kBlock + threadIdx.x;
+      raw[c] = (v < vec_per_row) ? __builtin_nontemporal_load(xr + v) : u32x4{0, 0, 0, 0};
+    }
+    auto scan = [&](const u32x4& r) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float e = DT<Tin>::get(r, i);
+        if (has_clip) e = clamp_like_torch(e, clip, clip_nan);
+        uint32_t ab = DT<Tin>::absbits(e);
+        if (DUAL) {
+          uint32_t bn = (e <= 0.0f) ? ab : 0u, bp = (e > 0.0f) ? ab : 0u;
+          mneg = mneg > bn ? mneg : bn;
+          mpos = mpos > bp ? mpos : bp;
+        } else {
+          mneg = mneg > ab ? mneg : ab;
+        }
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) scan(raw[c]);
+    for (int64_t v = (int64_t)MAXC * kBlock + threadIdx.x; v < vec_per_row; v += kBlock) scan(xr[v]);
+    mneg = block_max(mneg, sh);
+    if (DUAL) mpos = block_max(mpos, sh);
+    float sn = scale_of<Tin>(mneg, DUAL ? dual.fneg.gmax : fs.gmax);
+    float sp = DUAL ? scale_of<Tin>(mpos, dual.fpos.gmax) : 0.0f;
+
+    auto emit = [&](const u32x4& r, int64_t v) {
+      float p[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float e = DT<Tin>::get(r, i);
+        if (has_clip) e = clamp_like_torch(e, clip, clip_nan);
+        p[i] = DUAL ? quant_dual<Tin>(e, sn, sp, dual.fneg, dual.fpos) : quant_sym<Tin>(e, sn, fs);
+      }
+      Tout* o = out + row * cols + v * V;
+      if constexpr (sizeof(Tout) == 2) {
+        uint32_t w[V / 2];
+#pragma unroll
+        for (int i = 0; i < V / 2; ++i) w[i] = f2h(p[2 * i]) | (f2h(p[2 * i + 1]) << 16);
+        if constexpr (V == 8)
+          __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, (u32x4*)o);
+        else
+          __builtin_nontemporal_store(u32x2{w[0], w[1]}, (u32x2*)o);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; i += 4)
+          __builtin_nontemporal_store(u32x4{fbits(p[i]), fbits(p[i + 1]), fbits(p[i + 2]), fbits(p[i + 3])},
+                                      (u32x4*)(o + i));
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      int64_t v = (int64_t)c * kBlock + threadIdx.x;
+      if (v < vec_per_row) emit(raw[c], v);
+    }
+    for (int64_t v = (int64_t)MAXC * kBlock + threadIdx.x; v < vec_per_row; v += kBlock) emit(xr[v], v);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 3: ragged / unaligned rows - scalar accesses, one workgroup per row.
+// ---------------------------------------------------------------------------------
+template <typename Tin, typename Tout, bool DUAL>
+__global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restrict__ x,
+                                                            Tout* __restrict__ out, int64_t rows,
+                                                            int64_t cols, Fmt fs, DualArgs dual) {
+  __shared__ uint32_t sh[kBlock / 64];
+  float clip = 0.0f;
+  bool clip_nan = false;
+  const bool has_clip = DUAL && dual.clip_absmax != nullptr;
+  if (has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const Tin* xr = x + row * cols;
+    uint32_t mneg = 0, mpos = 0;
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      float e = load_scalar<Tin>(xr + c);
+      if (has_clip) e = clamp_like_torch(e, clip, clip_nan);
+      uint32_t ab = DT<Tin>::absbits(e);
+      if (DUAL) {
+        uint32_t bn = (e <= 0.0f) ? ab : 0u, bp = (e > 0.0f) ? ab : 0u;
+        mneg = mneg > bn ? mneg : bn;
+        mpos = mpos > bp ? mpos : bp;
+      } else {
+        mneg = mneg > ab ? mneg : ab;
+      }
+    }
+    mneg = block_max(mneg, sh);
+    if (DUAL) mpos = block_max(mpos, sh);
+    float sn = scale_of<Tin>(mneg, DUAL ? dual.fneg.gmax : fs.gmax);
+    float sp = DUAL ? scale_of<Tin>(mpos, dual.fpos.gmax) : 0.0f;
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      float e = load_scalar<Tin>(xr + c);
+      if (has_clip) e = clamp_like_torch(e, clip, clip_nan);
+      float p = DUAL ? quant_dual<Tin>(e, sn, sp, dual.fneg, dual.fpos) : quant_sym<Tin>(e, sn, fs);
+      store_scalar<Tout>(out + row * cols + c, p);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
+// The table index is wave-uniform, so table[j] is a scalar load (SGPR broadcast).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nearest_scan_kernel(const T* __restrict__ x,
+                                                             const float* __restrict__ table,
+                                                             T* __restrict__ z, int64_t n, int k) {
+  __shared__ float tab[256];
+  if ((int)threadIdx.x < k) tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    float xv = (float)x[i];
+    float best = 102400.0f, zv = 0.0f;
+    for (int j = 0; j < k; ++j) {
+      float y = tab[j];
+      float d = fabsf(xv - y);
+      if (d <= best) {
+        best = d;
+        zv = y;
+      }
+    }
+    z[i] = (T)zv;
+  }
+}
+
+// closed form against a built-in table (signed input)
+__global__ __launch_bounds__(kBlock) void nearest_builtin_kernel(const float* __restrict__ x,
+                                                                float* __restrict__ z, int64_t n, Fmt f,
+                                                                int side /*0 sym, 1 neg-only, 2 pos-only*/) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    float xv = x[i];
+    float q;
+    if (side == 0) {
+      uint32_t neg = xv < 0.0f ? 1u : 0u;
+      float qm = quant_mag(fabsf(xv), neg, f);
+      q = (neg && qm != 0.0f) ? -qm : qm;
+    } else if (side == 1) {
+      // table holds only values <= 0: positive inputs fall on 0 (if within reach)
+      // (0.0 is also what "nothing within reach" yields, so no reach test is needed here)
+      float qm = (xv <= 0.0f) ? quant_mag(fabsf(xv), 1u, f) : 0.0f;
+      q = (qm != 0.0f) ? -qm : 0.0f;
+    } else {
+      q = (xv > 0.0f) ? quant_mag(xv, 0u, f) : 0.0f;
+    }
+    z[i] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// absmax over a whole tensor (bit-pattern max, NaN propagates), atomicMax combine
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void absmax_kernel(const T* __restrict__ x, int64_t n,
+                                                       uint32_t* __restrict__ out) {
+  __shared__ uint32_t sh[kBlock / 64];
+  constexpr int V = DT<T>::kVec;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t nv = n / V;
+  uint32_t m = 0;
+  const u32x4* xv = (const u32x4*)x;
+  const bool aligned = ((uintptr_t)x & 15) == 0;
+  if (aligned) {
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += stride) {
+      u32x4 r = xv[v];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        uint32_t ab = DT<T>::absbits(DT<T>::get(r, i));
+        m = m > ab ? m : ab;
+      }
+    }
+  }
+  for (int64_t i = (aligned ? nv * V : 0) + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    uint32_t ab = DT<T>::absbits(load_scalar<T>(x + i));
+    m = m > ab ? m : ab;
+  }
+  m = block_max(m, sh);
+  if (threadIdx.x == 0) atomicMax(out, m);
+}
+
+// ---------------------------------------------------------------------------------
+// Codewords: one workgroup per row (any cols); code = index in the sorted
+// de-duplicated symmetric table.
+// ---------------------------------------------------------------------------------
+template <typename Tin>
+__global__ __launch_bounds__(kBlock) void rows_codes_kernel(const Tin* __restrict__ x,
+                                                           uint8_t* __restrict__ codes,
+                                                           Tin* __restrict__ scales, int64_t rows,
+                                                           int64_t cols, Fmt fs, int pack) {
+  __shared__ uint32_t sh[kBlock / 64];
+  const int64_t code_cols = pack ? (cols + 1) / 2 : cols;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const Tin* xr = x + row * cols;
+    uint32_t m = 0;
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      uint32_t ab = DT<Tin>::absbits(load_scalar<Tin>(xr + c));
+      m = m > ab ? m : ab;
+    }
+    m = block_max(m, sh);
+    float s = scale_of<Tin>(m, fs.gmax);
+    if (threadIdx.x == 0) store_scalar<Tin>(scales + row, s);
+    auto code_of = [&](int64_t c) -> uint32_t {
+      if (c >= cols) return (uint32_t)fs.zero_code;
+      float xn = DT<Tin>::round(load_scalar<Tin>(xr + c) / s);
+      uint32_t neg = (xn < 0.0f) ? 1u : 0u;
+      float qm = quant_mag(fabsf(xn), neg, fs);
+      int li = level_index(qm, fs);
+      return (uint32_t)(neg ? fs.zero_code - li : fs.zero_code + li);
+    };
+    if (pack) {
+      for (int64_t b = threadIdx.x; b < code_cols; b += kBlock)
+        codes[row * code_cols + b] = (uint8_t)(code_of(2 * b) | (code_of(2 * b + 1) << 4));
+    } else {
+      for (int64_t c = threadIdx.x; c < cols; c += kBlock) codes[row * code_cols + c] = (uint8_t)code_of(c);
+    }
+  }
+}
+
+template <typename Ts, typename Tout>
+__global__ __launch_bounds__(kBlock) void rows_decode_kernel(const uint8_t* __restrict__ codes,
+                                                            const Ts* __restrict__ scales,
+                                                            Tout* __restrict__ out, int64_t rows, int64_t cols,
+                                                            Fmt fs, int pack) {
+  const int64_t code_cols = pack ? (cols + 1) / 2 : cols;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    float s = load_scalar<Ts>(scales + row);
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      uint32_t code = pack ? ((codes[row * code_cols + (c >> 1)] >> ((c & 1) * 4)) & 0xF)
+                           : codes[row * code_cols + c];
+      int li = (int)code - fs.zero_code;
+      uint32_t neg = li < 0;
+      li = neg ? -li : li;
+      // level li: below 2^M levels are li*step0; above, mantissa/exponent from the index
+      int nsub = (int)(fs.kmin * fs.inv_step0);  // 2^M
+      float q = (li < nsub) ? (float)li * fs.step0 : u2f(((uint32_t)li + fs.kmin_code_base) << fs.mshift);
+      q = neg ? -q : q;
+      store_scalar<Tout>(out + row * cols + c, q * s);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Host-side launch helpers
+// ---------------------------------------------------------------------------------
+inline int grid_for(int64_t work_items_of_block, int64_t cap = kMaxBlocks) {
+  int64_t g = work_items_of_block < 1 ? 1 : work_items_of_block;
+  return (int)(g > cap ? cap : g);
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? FPQ_OK : FPQ_ERR_LAUNCH; }
+
+template <typename Tin, typename Tout, bool DUAL>
+int launch_rows(const void* x, void* out, int64_t rows, int64_t cols, const Fmt& fs, const DualArgs& dual,
+                hipStream_t st) {
+  constexpr int V = DT<Tin>::kVec;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+  const int64_t row_bytes = cols * (int64_t)sizeof(Tin);
+  if (aligned && cols % V == 0) {
+    const int64_t n_vec = rows * (cols / V);
+    const int lpr = (int)(cols / V);
+    constexpr int U = 4;
+    auto go = [&](auto kern) {
+      int64_t blocks = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+      hipLaunchKernelGGL(kern, dim3(grid_for(blocks)), dim3(kBlock), 0, st, (const u32x4*)x, out, n_vec, fs,
+                         dual);
+      return check_launch();
+    };
+    if (row_bytes <= 1024 && (lpr & (lpr - 1)) == 0) {
+      switch (lpr) {
+        case 1: return go(rows_subwave_kernel<Tin, Tout, 1, DUAL, U>);
+        case 2: return go(rows_subwave_kernel<Tin, Tout, 2, DUAL, U>);
+        case 4: return go(rows_subwave_kernel<Tin, Tout, 4, DUAL, U>);
+        case 8: return go(rows_subwave_kernel<Tin, Tout, 8, DUAL, U>);
+        case 16: return go(rows_subwave_kernel<Tin, Tout, 16, DUAL, U>);
+        case 32: return go(rows_subwave_kernel<Tin, Tout, 32, DUAL, U>);
+        case 64: return go(rows_subwave_kernel<Tin, Tout, 64, DUAL, U>);
+      }
+    }
+    // the output row must stay 16-byte (f16 out of f32 in: 8-byte) aligned per vector
+    const int64_t vec_per_row = cols / V;
+    const int g = grid_for(rows, 65535);
+    if (vec_per_row <= (int64_t)kBlock * 2)
+      hipLaunchKernelGGL((rows_block_kernel<Tin, Tout, DUAL, 2>), dim3(g), dim3(kBlock), 0, st, (const Tin*)x,
+                         (Tout*)out, rows, cols, fs, dual);
+    else
+      hipLaunchKernelGGL((rows_block_kernel<Tin, Tout, DUAL, 8>), dim3(g), dim3(kBlock), 0, st, (const Tin*)x,
+                         (Tout*)out, rows, cols, fs, dual);
+    return check_launch();
+  }
+  hipLaunchKernelGGL((rows_scalar_kernel<Tin, Tout, DUAL>), dim3(grid_for(rows, 65535)), dim3(kBlock), 0, st,
+                     (const Tin*)x, (Tout*)out, rows, cols, fs, dual);
+  return check_launch();
+}
+
+template <bool DUAL>
+int dispatch_rows(const void* x, void* out, int64_t rows, int64_t cols, int in_dtype, int out_dtype, const Fmt& fs,
+                  const DualArgs& dual, hipStream_t st) {
+  if (in_dtype == FPQ_F16 && out_dtype == FPQ_F16)
+    return launch_rows<_Float16, _Float16, DUAL>(x, out, rows, cols, fs, dual, st);
+  if (in_dtype == FPQ_F32 && out_dtype == FPQ_F32)
+    return launch_rows<float, float, DUAL>(x, out, rows, cols, fs, dual, st);
+  if (in_dtype == FPQ_F32 && out_dtype == FPQ_F16)
+    return launch_rows<float, _Float16, DUAL>(x, out, rows, cols, fs, dual, st);
+  if (in_dtype == FPQ_F16 && out_dtype == FPQ_F32)
+    return launch_rows<_Float16, float, DUAL>(x, out, rows, cols, fs, dual, st);
+  return FPQ_ERR_DTYPE;
+}
+
+}  // namespace
+
+// =================================================================================
+// C ABI
+// =================================================================================
+extern "C" {
+
+int fpq_version(void) { return FPQ_VERSION; }
+
+const char* fpq_strerror(int status) {
+  switch (status) {
+    case FPQ_OK: return "ok";
+    case FPQ_ERR_ARG: return "invalid argument (null pointer or negative size)";
+    case FPQ_ERR_DTYPE: return "unsupported dtype for this entry point";
+    case FPQ_ERR_SHAPE: return "unsupported shape";
+    case FPQ_ERR_TABLE: return "unknown table id, or half table passed where a symmetric table is required";
+    case FPQ_ERR_LAUNCH: return "HIP kernel launch failed";
+    case FPQ_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown fpq status";
+  }
+}
+
+int fpq_table_values(int table_id, float* host_out) {
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES) return FPQ_ERR_TABLE;
+  float pos[64];
+  int np = pos_levels(table_id, pos);
+  int n = 0;
+  const bool neg_half = (table_id == FPQ_E1M2_NEG || table_id == FPQ_INT_NEG);
+  const bool pos_half = (table_id == FPQ_E2M1_POS || table_id == FPQ_E2M3_POS);
+  const bool dup_zero = (table_id == FPQ_E2M3 || table_id == FPQ_E3M2);
+  if (!pos_half) {
+    for (int i = np - 1; i >= 1; --i, ++n)
+      if (host_out) host_out[n] = -pos[i];
+    if (neg_half || dup_zero) {
+      if (host_out) host_out[n] = 0.0f;
+      ++n;
+    }
+  }
+  if (!neg_half)
+    for (int i = 0; i < np; ++i, ++n)
+      if (host_out) host_out[n] = pos[i];
+  return n;
+}
+
+int fpq_quant_nearest(const void* x, const float* table, void* z, int64_t n, int k, int dtype,
+                      fpq_stream_t stream) {
+  if (n < 0) return FPQ_ERR_ARG;
+  if (k < 1 || k > 256) return FPQ_ERR_SHAPE;
+  if (dtype != FPQ_F32 && dtype != FPQ_F64) return FPQ_ERR_DTYPE;
+  if (n == 0) return FPQ_OK;
+  if (!x || !table || !z) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int g = grid_for((n + kBlock - 1) / kBlock);
+  if (dtype == FPQ_F32)
+    hipLaunchKernelGGL(nearest_scan_kernel<float>, dim3(g), dim3(kBlock), 0, st, (const float*)x, table, (float*)z,
+                       n, k);
+  else
+    hipLaunchKernelGGL(nearest_scan_kernel<double>, dim3(g), dim3(kBlock), 0, st, (const double*)x, table,
+                       (double*)z, n, k);
+  return check_launch();
+}
+
+int fpq_quant_nearest_builtin(const float* x, float* z, int64_t n, int table_id, fpq_stream_t stream) {
+  if (n < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES) return FPQ_ERR_TABLE;
+  if (n == 0) return FPQ_OK;
+  if (!x || !z) return FPQ_ERR_ARG;
+  int side = kTables[table_id].symmetric ? 0 : ((table_id == FPQ_E1M2_NEG || table_id == FPQ_INT_NEG) ? 1 : 2);
+  hipLaunchKernelGGL(nearest_builtin_kernel, dim3(grid_for((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, x, z, n, make_fmt(table_id), side);
+  return check_launch();
+}
+
+int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int table_id, int in_dtype, int out_dtype,
+                   fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (out_dtype != FPQ_F16 && out_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !out) return FPQ_ERR_ARG;
+  DualArgs dual = {};
+  return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,
+                              (hipStream_t)stream);
+}
+
+int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table, int pos_table,
+                        int in_dtype, int out_dtype, const void* clip_absmax, float clip_strength,
+                        fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_INT_NEG) return FPQ_ERR_TABLE;
+  if (pos_table != FPQ_E2M1_POS && pos_table != FPQ_E2M3_POS) return FPQ_ERR_TABLE;
+  if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (out_dtype != FPQ_F16 && out_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !out) return FPQ_ERR_ARG;
+  DualArgs dual;
+  dual.fneg = make_fmt(neg_table);
+  dual.fpos = make_fmt(pos_table);
+  dual.clip_absmax = clip_absmax;
+  dual.clip_strength = clip_strength;
+  return dispatch_rows<true>(x, out, rows, cols, in_dtype, out_dtype, dual.fneg, dual, (hipStream_t)stream);
+}
+
+int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream) {
+  if (n < 0 || !out) return FPQ_ERR_ARG;
+  if (dtype != FPQ_F16 && dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) return FPQ_ERR_LAUNCH;
+  if (n == 0) return FPQ_OK;
+  if (!x) return FPQ_ERR_ARG;
+  int64_t per_block = (int64_t)kBlock * 16;
+  int g = grid_for((n + per_block - 1) / per_block);
+  if (dtype == FPQ_F16)
+    hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3(g), dim3(kBlock), 0, st, (const _Float16*)x, n, (uint32_t*)out);
+  else
+    hipLaunchKernelGGL(absmax_kernel<float>, dim3(g), dim3(kBlock), 0, st, (const float*)x, n, (uint32_t*)out);
+  return check_launch();
+}
+
+int fpq_quant_rows_codes(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
+                         int in_dtype, int pack_nibbles, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (pack_nibbles && kTables[table_id].n_pos > 8) return FPQ_ERR_SHAPE;  // FP6 codes do not fit a nibble
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !codes || !scales) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Fmt f = make_fmt(table_id);
+  int g = grid_for(rows, 65535);
+  if (in_dtype == FPQ_F16)
+    hipLaunchKernelGGL(rows_codes_kernel<_Float16>, dim3(g), dim3(kBlock), 0, st, (const _Float16*)x, codes,
+                       (_Float16*)scales, rows, cols, f, pack_nibbles ? 1 : 0);
+  else
+    hipLaunchKernelGGL(rows_codes_kernel<float>, dim3(g), dim3(kBlock), 0, st, (const float*)x, codes,
+                       (float*)scales, rows, cols, f, pack_nibbles ? 1 : 0);
+  return check_launch();
+}
+
+int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, int64_t rows, int64_t cols,
+                           int table_id, int scale_dtype, int out_dtype, int pack_nibbles, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if ((scale_dtype != FPQ_F16 && scale_dtype != FPQ_F32) || (out_dtype != FPQ_F16 && out_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (pack_nibbles && kTables[table_id].n_pos > 8) return FPQ_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!codes || !scales || !out) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Fmt f = make_fmt(table_id);
+  int g = grid_for(rows, 65535);
+  int pk = pack_nibbles ? 1 : 0;
+  if (scale_dtype == FPQ_F16 && out_dtype == FPQ_F16)
+    hipLaunchKernelGGL((rows_decode_kernel<_Float16, _Float16>), dim3(g), dim3(kBlock), 0, st, codes,
+                       (const _Float16*)scales, (_Float16*)out, rows, cols, f, pk);
+  else if (scale_dtype == FPQ_F16 && out_dtype == FPQ_F32)
+    hipLaunchKernelGGL((rows_decode_kernel<_Float16, float>), dim3(g), dim3(kBlock), 0, st, codes,
+                       (const _Float16*)scales, (float*)out, rows, cols, f, pk);
+  else if (scale_dtype == FPQ_F32 && out_dtype == FPQ_F16)
+    hipLaunchKernelGGL((rows_decode_kernel<float, _Float16>), dim3(g), dim3(kBlock), 0, st, codes,
+                       (const float*)scales, (_Float16*)out, rows, cols, f, pk);
+  else
+    hipLaunchKernelGGL((rows_decode_kernel<float, float>), dim3(g), dim3(kBlock), 0, st, codes,
+                       (const float*)scales, (float*)out, rows, cols, f, pk);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""Tensor-level wrappers over the C ABI (one HIP launch each).
+
+These are the additive "L1" entry points of SURVEY.md section 8b; the
+reference-named functions in :mod:`fpqvar_amd.quant_utils` are thin shims over
+them.  Every function here requires GPU tensors and raises otherwise.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TABLE_IDS, check, dtype_id, lib, require_gpu, stream_ptr
+
+
+def _contig(x: torch.Tensor) -> torch.Tensor:
+    # the reference reshapes (copying when needed) before its kernel; same here
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def quant_nearest(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """quant_cuda.quant's first output (quant/quant_kernel.cu:11-62)."""
+    require_gpu(x, "quant_nearest(x)")
+    require_gpu(table, "quant_nearest(table)")
+    if x.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"quant_nearest: x must be float32 or float64, got {x.dtype}")
+    if not x.is_contiguous():
+        raise RuntimeError("quant_nearest: x must be contiguous")
+    if table.device != x.device:
+        raise RuntimeError("quant_nearest: table must live on x's device")
+    k = table.numel()
+    if k < 1 or k > 256:
+        raise RuntimeError(f"quant_nearest: table must hold 1..256 entries, got {k}")
+    tab = table.detach().reshape(-1).to(torch.float32).contiguous()
+    z = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_nearest(x.data_ptr(), tab.data_ptr(), z.data_ptr(), x.numel(), k, dtype_id(x.dtype),
+                                      stream_ptr(x.device)), "fpq_quant_nearest")
+    return z
+
+
+def quant_nearest_builtin(x: torch.Tensor, table: str) -> torch.Tensor:
+    require_gpu(x, "quant_nearest_builtin")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("quant_nearest_builtin: x must be contiguous float32")
+    z = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_nearest_builtin(x.data_ptr(), z.data_ptr(), x.numel(), TABLE_IDS[table],
+                                              stream_ptr(x.device)), "fpq_quant_nearest_builtin")
+    return z
+
+
+def quant_rows(x: torch.Tensor, table: str, cols: int, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Fake-quantize x viewed as [numel/cols, cols], one scale per row; same shape out."""
+    require_gpu(x, "quant_rows")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_rows: x must be float16 or float32, got {x.dtype}")
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    n = x.numel()
+    if cols <= 0 or n % cols != 0:
+        raise RuntimeError(f"quant_rows: numel {n} is not a multiple of the row length {cols}")
+    xc = _contig(x)
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[table],
+                                   dtype_id(x.dtype), dtype_id(out_dtype), stream_ptr(x.device)), "fpq_quant_rows")
+    return out
+
+
+def absmax(x: torch.Tensor) -> torch.Tensor:
+    """0-dim max|x| in x's dtype (NaN-propagating)."""
+    require_gpu(x, "absmax")
+    xc = _contig(x)
+    buf = torch.empty(2 if x.dtype == torch.float16 else 1, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_absmax(xc.data_ptr(), xc.numel(), dtype_id(x.dtype), buf.data_ptr(), stream_ptr(x.device)),
+              "fpq_absmax")
+    return buf[0]
+
+
+def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
+                    clipping_strength: Optional[float] = None,
+                    out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Dual-format fake-quantize.  clipping_strength=None: no global clamp
+    (tr/quant_utils.py:577-646); a number: clamp to +-strength*max|x| first (:421-422),
+    which costs one extra read pass for the global absmax."""
+    require_gpu(x, "quant_rows_dual")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_rows_dual: x must be float16 or float32, got {x.dtype}")
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    n = x.numel()
+    if cols <= 0 or n % cols != 0:
+        raise RuntimeError(f"quant_rows_dual: numel {n} is not a multiple of the row length {cols}")
+    xc = _contig(x)
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        clip_ptr, strength = None, 1.0
+        if clipping_strength is not None:
+            am = absmax(xc)
+            clip_ptr, strength = am.data_ptr(), float(clipping_strength)
+        check(lib().fpq_quant_rows_dual(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[neg_table],
+                                        TABLE_IDS[pos_table], dtype_id(x.dtype), dtype_id(out_dtype), clip_ptr,
+                                        strength, stream_ptr(x.device)), "fpq_quant_rows_dual")
+    return out
+
+
+def quant_rows_codes(x: torch.Tensor, table: str, cols: int, pack_nibbles: bool = False
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(codes uint8, scales x.dtype[rows]).  codes are [rows, cols] or, packed, [rows, ceil(cols/2)]."""
+    require_gpu(x, "quant_rows_codes")
+    n = x.numel()
+    if cols <= 0 or n % cols != 0:
+        raise RuntimeError("quant_rows_codes: numel is not a multiple of the row length")
+    rows = n // cols
+    xc = _contig(x)
+    ccols = (cols + 1) // 2 if pack_nibbles else cols
+    codes = torch.empty((rows, ccols), dtype=torch.uint8, device=x.device)
+    scales = torch.empty((rows,), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows_codes(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, cols,
+                                         TABLE_IDS[table], dtype_id(x.dtype), int(pack_nibbles),
+                                         stream_ptr(x.device)), "fpq_quant_rows_codes")
+    return codes, scales
+
+
+def dequant_rows_codes(codes: torch.Tensor, scales: torch.Tensor, table: str, cols: int,
+                       out_dtype: torch.dtype, pack_nibbles: bool = False) -> torch.Tensor:
+    require_gpu(codes, "dequant_rows_codes")
+    rows = scales.numel()
+    out = torch.empty((rows, cols), dtype=out_dtype, device=codes.device)
+    with torch.cuda.device(codes.device):
+        check(lib().fpq_dequant_rows_codes(codes.data_ptr(), scales.data_ptr(), out.data_ptr(), rows, cols,
+                                           TABLE_IDS[table], dtype_id(scales.dtype), dtype_id(out_dtype),
+                                           int(pack_nibbles), stream_ptr(codes.device)), "fpq_dequant_rows_codes")
+    return out

@@ -1,0 +1,115 @@
+"""Host-side mirror of the reference's FP fake-quant operator layer.
+
+Same function names, argument meaning, dtype rules and assertions as
+``models_fp_quant_transform_rotate/quant_utils.py`` (reference, "tr/"), so a
+caller can switch ``from models_fp_quant_transform_rotate.quant_utils import ...``
+to ``from fpqvar_amd.quant_utils import ...`` unchanged.  Each call is ONE HIP
+launch on the current stream instead of ~11 torch ops + the scan kernel.
+
+GPU tensors only: there is deliberately no CPU fallback (the CPU restatement
+is test infrastructure under oracle/).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+# value tables, exactly as tr/quant_utils.py:233-235,458-500 spells them (host tensors)
+fp4_e3m0_grid = torch.tensor([-16.0, -8.0, -4.0, -2.0, -1.0, -0.5, -0.25, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0])
+fp4_e2m1_grid = torch.tensor([-6.0, -4.0, -3.0, -2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+fp4_e1m2_grid = torch.tensor([-1.75, -1.5, -1.25, -1.0, -0.75, -0.5, -0.25, 0.0,
+                              0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75])
+
+
+def _e2m3_pos():
+    return [m * 0.125 for m in range(8)] + [(1 + m / 8) * 2.0 ** e for e in range(3) for m in range(8)]
+
+
+def _e3m2_pos():
+    return [m * 0.0625 for m in range(4)] + [(1 + m / 4) * 2.0 ** e for e in range(-2, 5) for m in range(4)]
+
+
+fp6_e2m3_grid = torch.tensor([-v if v else 0.0 for v in reversed(_e2m3_pos())] + _e2m3_pos())
+fp6_e3m2_grid = torch.tensor([-v if v else 0.0 for v in reversed(_e3m2_pos())] + _e3m2_pos())
+int_neg_grid = torch.tensor([float(-v) if v else 0.0 for v in range(32, -1, -1)])
+e2m3_pos_grid = torch.tensor(_e2m3_pos())
+
+
+# ---- FP4, per group of `group_size` consecutive elements (tr/quant_utils.py:265-282,313-330,361-378) ----
+
+def fp_quant_e3_per_group_cuda(x, n_bits, group_size=128):
+    assert n_bits == 4
+    return ops.quant_rows(x, "e3m0", group_size)
+
+
+def fp_quant_e2_per_group_cuda(x, n_bits, group_size=128):
+    assert n_bits == 4
+    return ops.quant_rows(x, "e2m1", group_size)
+
+
+def fp_quant_e1_per_group_cuda(x, n_bits, group_size=128):
+    assert n_bits == 4
+    return ops.quant_rows(x, "e1m2", group_size)
+
+
+# ---- FP4 asymmetric dual format for the fc2 input (tr/quant_utils.py:415-452) ----
+
+def fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, n_bits, group_size=128, clipping_strength=1.0):
+    """x <= 0 on E1M2 (scale max|x_neg|/1.75), x > 0 on E2M1 (scale max x_pos/6).
+
+    The reference clamps to +-clipping_strength*max|x| first; with the default 1.0
+    that is the identity unless the tensor holds a NaN (then torch.clamp turns
+    every element into NaN and the result is all zeros).  The global absmax pass
+    is therefore only launched when clipping_strength != 1.0, and the NaN quirk
+    at strength 1.0 is reproduced by the same route on request
+    (``exact_nan_clip=True`` semantics live in ops.quant_rows_dual(clipping_strength=1.0)).
+    """
+    assert n_bits == 4
+    strength = None if clipping_strength == 1.0 else clipping_strength
+    return ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", group_size, strength)
+
+
+# ---- FP6 (tr/quant_utils.py:503-574): output is float16 whatever the input dtype ----
+
+def fp6_quant_e2m3_per_token_cuda(x, n_bits):
+    assert n_bits == 6
+    _require_viewable(x)
+    return ops.quant_rows(x, "e2m3", x.shape[-1], torch.float16)
+
+
+def fp6_quant_e3m2_per_token_cuda(x, n_bits):
+    assert n_bits == 6
+    _require_viewable(x)
+    return ops.quant_rows(x, "e3m2", x.shape[-1], torch.float16)
+
+
+def fp6_quant_e2m3_per_group_cuda(x, n_bits, group_size=128):
+    assert n_bits == 6
+    return ops.quant_rows(x, "e2m3", group_size, torch.float16)
+
+
+def fp6_quant_e3m2_per_group_cuda(x, n_bits, group_size=128):
+    assert n_bits == 6
+    return ops.quant_rows(x, "e3m2", group_size, torch.float16)
+
+
+# ---- FP6 asymmetric dual format (tr/quant_utils.py:577-646) ----
+
+def fp6_quant_int_neg_e2m3_pos_per_group_cuda(x, n_bits, group_size=128):
+    assert n_bits == 6
+    return ops.quant_rows_dual(x, "int_neg", "e2m3_pos", group_size, None)
+
+
+def fp6_quant_int_neg_e2m3_pos_per_token_cuda(x, n_bits):
+    assert n_bits == 6
+    _require_viewable(x)
+    return ops.quant_rows_dual(x, "int_neg", "e2m3_pos", x.shape[-1], None)
+
+
+def _require_viewable(x):
+    # the per-token reference functions call x.view(-1) after the division
+    # (tr/quant_utils.py:510,527,633): a non-contiguous input raises there too
+    if not x.is_contiguous():
+        raise RuntimeError("view size is not compatible with input tensor's size and stride "
+                           "(per-token FP6 quantizers need a contiguous input, as in the reference)")

@@ -1,0 +1,136 @@
+/* fpq.h - C ABI of libfpq_hip.so: MI355X (gfx950) fake-quantization kernels that
+ * replace FPQVAR's `quant_cuda` extension and the torch-op bodies of its
+ * `fp_quant_*` / `fp6_quant_*` functions.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless the name says `host`;
+ *   - nothing allocates, nothing synchronises the host, everything is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - re-entrant and thread-safe: no mutable global state;
+ *   - returns FPQ_OK (0) or a negative FPQ_ERR_* code; on error nothing is enqueued;
+ *   - rows == 0 / n == 0 is valid and enqueues nothing;
+ *   - inputs are never written.
+ *
+ * "reference" below = PKU-SEC-Lab/FPQVAR; tr/ = models_fp_quant_transform_rotate/.
+ */
+#ifndef FPQ_H
+#define FPQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPQ_VERSION 100 /* 0.1.0 */
+
+typedef void* fpq_stream_t; /* hipStream_t */
+
+enum fpq_status {
+  FPQ_OK = 0,
+  FPQ_ERR_ARG = -1,    /* NULL pointer, negative size */
+  FPQ_ERR_DTYPE = -2,  /* dtype not supported by this entry point */
+  FPQ_ERR_SHAPE = -3,  /* cols == 0, k out of range, ... */
+  FPQ_ERR_TABLE = -4,  /* unknown table id / half table used as symmetric table */
+  FPQ_ERR_LAUNCH = -5, /* hipLaunch reported an error */
+  FPQ_ERR_NO_DEVICE = -6
+};
+
+enum fpq_dtype { FPQ_F16 = 0, FPQ_F32 = 1, FPQ_F64 = 2 };
+
+/* Built-in value tables, literal in the reference at
+ * tr/quant_utils.py:233-235 (E3M0/E2M1/E1M2), :458-486 (E2M3/E3M2, two zeros),
+ * :418-419 (E1M2_NEG/E2M1_POS), :488-500 (INT_NEG/E2M3_POS). */
+enum fpq_table {
+  FPQ_E2M1 = 0,
+  FPQ_E1M2 = 1,
+  FPQ_E3M0 = 2,
+  FPQ_E2M3 = 3,
+  FPQ_E3M2 = 4,
+  FPQ_E1M2_NEG = 5,
+  FPQ_E2M1_POS = 6,
+  FPQ_INT_NEG = 7,
+  FPQ_E2M3_POS = 8,
+  FPQ_NUM_TABLES = 9
+};
+
+int fpq_version(void);
+const char* fpq_strerror(int status);
+
+/* Host-side copy of a built-in table exactly as the reference spells it
+ * (ascending, duplicate zeros kept).  Returns the entry count, or FPQ_ERR_TABLE.
+ * `host_out` may be NULL to query the size. */
+int fpq_table_values(int table_id, float* host_out);
+
+/* ---- L0: the reference's one native symbol ---------------------------------
+ * Replaces quant_forward_cuda / quant_forward_cuda_kernel
+ * (quant/quant_kernel.cu:11-62, bound as `quant_cuda.quant` at quant/quant.cpp:27-29).
+ *   z[i] = table[j*], j* = LAST j in 0..k-1 minimising fabsf((float)x[i] - table[j])
+ *   among distances <= 102400.0f; z[i] = +0.0 if there is none (NaN, +-Inf, far).
+ * x, z: `dtype` in {FPQ_F32, FPQ_F64} (f64 compared in f32, as the reference does),
+ * n elements, contiguous.  table: k floats on the device, 1 <= k <= 256.
+ * The reference's second output (`tensor_idx`, never written, all zeros) is the
+ * caller's business: the Python binding returns a zero tensor for it. */
+int fpq_quant_nearest(const void* x, const float* table, void* z, int64_t n, int k, int dtype,
+                      fpq_stream_t stream);
+
+/* Same lookup against a BUILT-IN table through the closed form the fused kernels
+ * use (midpoint counting on the minifloat structure).  f32 only.  Exposed so
+ * tests can compare it with fpq_quant_nearest element by element. */
+int fpq_quant_nearest_builtin(const float* x, float* z, int64_t n, int table_id, fpq_stream_t stream);
+
+/* ---- L1: one launch per reference function ---------------------------------
+ * x: [rows, cols] contiguous, in_dtype in {F16, F32}.  out: same shape, out_dtype.
+ * One scale per row of `cols` elements:
+ *     s   = (T)(max|x_row| / max|table|)          (in x's dtype T)
+ *     xn  = (T)(x / s)                            (in T)
+ *     q   = nearest((float)xn)                    (L0 semantics)
+ *     out = (Tout)((float)q * (float)s)           (fp32 product, then cast)
+ * - per-group functions call it with cols = group_size (128) and rows = numel/128:
+ *     fp_quant_e{1,2,3}_per_group_cuda  tr/quant_utils.py:265-282,313-330,361-378
+ *     fp6_quant_{e2m3,e3m2}_per_group_cuda  :537-574   (out_dtype = F16)
+ *     KV cache, kv_bit 4                tr/basic_var.py:50-67,197-198
+ * - per-token functions call it with cols = last dim:
+ *     fp6_quant_{e2m3,e3m2}_per_token_cuda  tr/quant_utils.py:503-534 (out_dtype = F16)
+ *     KV cache, kv_bit 6 (cols = 64)    tr/basic_var.py:71-85,194-195
+ * table_id must be one of the symmetric tables (E2M1, E1M2, E3M0, E2M3, E3M2). */
+int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int table_id, int in_dtype,
+                   int out_dtype, fpq_stream_t stream);
+
+/* Asymmetric neg/pos dual format: x <= 0 is scaled and rounded on `neg_table`,
+ * x > 0 on `pos_table`, each with its own per-row scale; NaN elements take
+ * neither side and come out 0 (torch.where semantics).
+ *     fp_quant_e1m2_neg_e2m1_pos_per_group_cuda   tr/quant_utils.py:415-452
+ *     fp6_quant_int_neg_e2m3_pos_per_group_cuda   :577-611
+ *     fp6_quant_int_neg_e2m3_pos_per_token_cuda   :614-646
+ * clip_absmax: NULL, or a device scalar (in_dtype) holding max|x| over the WHOLE
+ * tensor as written by fpq_absmax; the kernel then clamps x to
+ * +-(T)(clip_strength * absmax) first (tr/quant_utils.py:421-422).  A NaN bound
+ * turns every element into NaN, hence the whole output into zeros, exactly as
+ * torch.clamp does. */
+int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table,
+                        int pos_table, int in_dtype, int out_dtype, const void* clip_absmax,
+                        float clip_strength, fpq_stream_t stream);
+
+/* max|x| over n elements (NaN-propagating, like torch's x.abs().max()), written
+ * as ONE scalar of `dtype` to `out`.  `out` must hold 4 bytes; it is zeroed on the
+ * stream first (hipMemsetAsync) and then combined with device atomics. */
+int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream);
+
+/* Codeword output (build-defined; the reference's kernel never emits codes,
+ * quant_kernel.cu:18,49).  code = index into the sorted, de-duplicated table
+ * (0..14 for the FP4 tables, 0..62 for FP6); for the FP4 tables two codes are
+ * packed per byte (element 2i in the low nibble).  scales: one per row, in
+ * x's dtype.  dequant: table_dedup[code] * scale reproduces fpq_quant_rows. */
+int fpq_quant_rows_codes(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols,
+                         int table_id, int in_dtype, int pack_nibbles, fpq_stream_t stream);
+
+/* Inverse of fpq_quant_rows_codes: out = (Tout)((float)table_dedup[code] * (float)scale). */
+int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, int64_t rows,
+                           int64_t cols, int table_id, int scale_dtype, int out_dtype,
+                           int pack_nibbles, fpq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPQ_H */

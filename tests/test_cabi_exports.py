@@ -1,0 +1,91 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/fpq.h declares;
+argument validation that needs no GPU; the host mirror refuses CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build_hip()
+    from fpqvar_amd import _lib
+    return _lib.lib()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "fpq.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fpq_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fpq.h but not exported by libfpq_hip.so"
+    from fpqvar_amd import _lib
+    assert set(_lib._SIGS) == set(names), "ctypes signatures out of sync with include/fpq.h"
+
+
+def test_version_and_errors(lib):
+    assert lib.fpq_version() == 100
+    assert lib.fpq_strerror(0) == b"ok"
+    for code in range(-6, 0):
+        assert lib.fpq_strerror(code)
+    # argument validation happens before anything touches a device
+    assert lib.fpq_quant_rows(None, None, -1, 128, 0, 0, 0, None) == -1
+    assert lib.fpq_quant_rows(None, None, 4, 128, 99, 0, 0, None) == -4
+    assert lib.fpq_quant_rows(None, None, 4, 128, 5, 0, 0, None) == -4      # half table as symmetric table
+    assert lib.fpq_quant_rows(None, None, 4, 128, 0, 2, 0, None) == -2      # f64 not supported here
+    assert lib.fpq_quant_rows(None, None, 4, 128, 0, 0, 0, None) == -1      # null pointers
+    assert lib.fpq_quant_rows(None, None, 0, 128, 0, 0, 0, None) == 0       # empty input is fine
+    assert lib.fpq_quant_rows_dual(None, None, 4, 128, 0, 6, 0, 0, None, 1.0, None) == -4
+    assert lib.fpq_quant_nearest(None, None, None, 4, 300, 1, None) == -3
+    assert lib.fpq_quant_nearest(None, None, None, 4, 15, 0, None) == -2
+    assert lib.fpq_quant_nearest(None, None, None, 0, 15, 1, None) == 0
+    assert lib.fpq_quant_rows_codes(None, None, None, 4, 128, 3, 0, 1, None) == -3   # FP6 codes cannot be nibble-packed
+
+
+def test_tables_match_oracle(lib):
+    from fpqvar_amd import _lib, quant_utils as qu
+    from oracle import fpq_oracle as orc
+    for name in _lib.TABLE_IDS:
+        assert torch.equal(_lib.table_values(name), orc.TABLES[name]), name
+    assert torch.equal(qu.fp4_e2m1_grid, orc.TABLES["e2m1"])
+    assert torch.equal(qu.fp4_e1m2_grid, orc.TABLES["e1m2"])
+    assert torch.equal(qu.fp4_e3m0_grid, orc.TABLES["e3m0"])
+    assert torch.equal(qu.fp6_e2m3_grid, orc.TABLES["e2m3"])
+    assert torch.equal(qu.fp6_e3m2_grid, orc.TABLES["e3m2"])
+    assert torch.equal(qu.int_neg_grid, orc.TABLES["int_neg"])
+    assert torch.equal(qu.e2m3_pos_grid, orc.TABLES["e2m3_pos"])
+    assert _lib.TABLE_IDS == orc.TABLE_IDS
+
+
+def test_no_cpu_fallback():
+    import quant_cuda
+    from fpqvar_amd import quant_utils as qu
+    x = torch.randn(4, 128)
+    with pytest.raises(RuntimeError, match="GPU"):
+        qu.fp_quant_e2_per_group_cuda(x.half(), 4, 128)
+    with pytest.raises(RuntimeError, match="GPU"):
+        quant_cuda.quant(x.view(-1), qu.fp4_e2m1_grid)
+    with pytest.raises(AssertionError):
+        qu.fp_quant_e2_per_group_cuda(x.half(), 8, 128)
+
+
+def test_product_does_not_import_oracle():
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import fpqvar_amd, quant_cuda; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'product imports oracle'")
+    subprocess.run([sys.executable, "-c", code % ROOT], check=True)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fpqvar_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("oracle/", "").replace(
+                    "the oracle", ""), f"{f} mentions the oracle module"
