@@ -125,6 +125,10 @@ __device__ __forceinline__ float h2f(uint32_t hbits) {
   return (float)h;
 }
 __device__ __forceinline__ uint32_t f2h(float f) {
+  // The value must exist as a rounded fp32 before it is narrowed: torch materialises
+  // the fp32 product and then casts (two roundings when x is fp32).  Without the
+  // barrier LLVM folds fmul + fptrunc into v_fma_mixlo_f16, which rounds once.
+  asm volatile("" : "+v"(f));
   _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round to nearest even
   return (uint32_t)__builtin_bit_cast(uint16_t, h);
 }
@@ -190,6 +194,7 @@ __device__ __forceinline__ float load_scalar(const T* p) {
 }
 template <typename T>
 __device__ __forceinline__ void store_scalar(T* p, float v) {
+  asm volatile("" : "+v"(v));  // see f2h
   *p = (T)v;
 }
 
