@@ -1,0 +1,256 @@
+// fpq_fast16.h - the fp16 -> fp16 hot path (activations, KV cache).  Included by
+// fpq_kernels.hip inside its anonymous namespace, after the generic helpers.
+//
+// Same results as the generic kernels (rows_subwave_kernel / rows_block_kernel),
+// about a fifth of their VALU work per element:
+//
+//   * xn = fp16(x / s) costs 3 fp32 ops instead of an IEEE division sequence:
+//         y  = x * inv            inv = v_rcp_f32(s)   (once per row)
+//         e  = fma(-y, s, x)      exact residual
+//         y2 = fma(e, inv, y)     = RN32(x/s * (1 - O(2^-44)))
+//     x and s carry 11 significant bits, so x/s is either exactly a 12-bit number
+//     (then y2 lands on it exactly and the fp16 tie rounds to even as IEEE does) or at
+//     least 2^-23 (relative) away from every 12-bit number, i.e. from every fp16
+//     rounding boundary (then y2 is on the same side).  Either way
+//     fp16(y2) == fp16(RN32(x/s)) == what torch's fp16 division produces.
+//     (Rounding the LAST fma straight to fp16 - v_fma_mixlo_f16 - would be wrong in
+//     the tie case: the fp32 rounding is what snaps y2 onto the tie.)
+//   * scale = fp16(amax / gmax) the same way with the compile-time-free constant 1/gmax.
+//   * the minifloat rounding is a table in LDS indexed by the top bits of xn's fp16
+//     pattern: every rounding threshold of every supported table is a multiple of
+//     2^shift in that bit pattern (E2M1: shift 8 -> 256 entries; int_neg: shift 5),
+//     so bucket -> level is exact.  "tie goes to the larger VALUE" becomes: subtract
+//     1 from a negative pattern's magnitude before bucketing.  The entry is the fp16
+//     pattern of the (signed) level with the table's zero as +0, so -0.0 never appears.
+//     The table is filled per workgroup from the same closed form the generic kernels
+//     use (quant_mag), which tests pin to the reference's scan.
+//   * out = v_pk_mul_f16(level, scale): the exact product rounded once = fp16(fp32(q*s)).
+//   * absmax on packed 16-bit integer patterns (NaN = largest pattern propagates like
+//     torch.max), row reduction in DPP (rows of 8/16 lanes never leave a DPP row).
+#pragma once
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef uint16_t us2_t __attribute__((ext_vector_type(2)));
+typedef int16_t s2_t __attribute__((ext_vector_type(2)));
+
+struct Lut16Args {
+  Fmt fneg, fpos;      // identical for the symmetric tables
+  float inv_gneg;      // RN32(1 / gmax) per side
+  float inv_gpos;
+  int shift;           // bucket width = 2^shift fp16 patterns
+};
+
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  us2_t r = __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b));
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
+  us2_t r = __builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, int n) {
+  us2_t r = __builtin_bit_cast(us2_t, a) >> (uint16_t)n;
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_ashr_i16(uint32_t a, int n) {
+  s2_t r = __builtin_bit_cast(s2_t, a) >> (int16_t)n;
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_mul_f16(uint32_t a, uint32_t b) {
+  h2_t r = __builtin_bit_cast(h2_t, a) * __builtin_bit_cast(h2_t, b);
+  return __builtin_bit_cast(uint32_t, r);
+}
+
+// max over the LPR lanes that own a row; LPR lanes are contiguous and LPR-aligned
+template <int LPR>
+__device__ __forceinline__ uint32_t row_max_dpp(uint32_t v) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  if (LPR >= 2) v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  if (LPR >= 4) v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if (LPR >= 8) v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if (LPR >= 16) v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true)); // row_mirror
+  if (LPR >= 32) v = mx(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+  if (LPR >= 64) v = mx(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+  return v;
+}
+
+// fp16(a / g) for an fp16-valued a and a constant g given as inv_g = RN32(1/g):
+// y = a*inv_g is within 2^-23 of a/g, one residual step makes it RN32(a/g(1+tiny)).
+__device__ __forceinline__ uint32_t scale_bits_f16(uint32_t amax_bits, float g, float inv_g) {
+  float a = h2f(amax_bits);
+  if (!(a < __builtin_inff())) return amax_bits;   // inf -> inf, NaN -> NaN
+  float y = a * inv_g;
+  float e = __builtin_fmaf(-y, g, a);
+  float y2 = __builtin_fmaf(e, inv_g, y);
+  return f2h(y2);   // NaN/Inf propagate: amax = inf -> inf, NaN -> NaN
+}
+
+__device__ __forceinline__ void lut16_fill(uint16_t* lut, const Lut16Args& a) {
+  const int n = 1 << (16 - a.shift);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    uint32_t u = (uint32_t)i << a.shift;
+    bool neg = (u >> 15) != 0;
+    float r = h2f(u & 0x7FFFu);   // lowest magnitude pattern of the bucket
+    float qm = quant_mag(r, 0u, neg ? a.fneg : a.fpos);
+    uint32_t qb = f2h(qm);
+    lut[i] = (uint16_t)((neg && qm != 0.0f) ? (qb | 0x8000u) : qb);
+  }
+}
+
+// Quantize the 8 halves of one 16-byte vector.  s16x2 = scale replicated in both
+// halves; sf = (float)scale; inv = sf == 0 ? 0 : 1/sf (approximate reciprocal).
+// In DUAL mode each element picks the negative or positive side's scale.
+template <bool DUAL>
+__device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut, int shift, float sf_n, float inv_n,
+                                             uint32_t s16x2_n, float sf_p, float inv_p, uint32_t s16x2_p) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t wk = w[k];
+    float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
+    float s0 = sf_n, s1 = sf_n, i0 = inv_n, i1 = inv_n;
+    uint32_t sc = s16x2_n;
+    if (DUAL) {
+      bool n0 = (wk & 0x8000u) != 0, n1 = (wk & 0x80000000u) != 0;
+      s0 = n0 ? sf_n : sf_p;  i0 = n0 ? inv_n : inv_p;
+      s1 = n1 ? sf_n : sf_p;  i1 = n1 ? inv_n : inv_p;
+      sc = (n0 ? (s16x2_n & 0xFFFFu) : (s16x2_p & 0xFFFFu)) | (n1 ? (s16x2_n & 0xFFFF0000u) : (s16x2_p & 0xFFFF0000u));
+    }
+    float y0 = x0 * i0, y1 = x1 * i1;
+    float e0 = __builtin_fmaf(-y0, s0, x0), e1 = __builtin_fmaf(-y1, s1, x1);
+    float r0 = __builtin_fmaf(e0, i0, y0), r1 = __builtin_fmaf(e1, i1, y1);
+    uint32_t rb = f2h(r0) | (f2h(r1) << 16);
+    uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
+    uint32_t q0 = lut[(u & 0xFFFFu) >> shift];
+    uint32_t q1 = lut[u >> (16 + shift)];
+    o[k] = pk_mul_f16(q0 | (q1 << 16), sc);
+  }
+  return o;
+}
+
+// |x| patterns of one vector reduced to a per-lane maximum (symmetric tables)
+__device__ __forceinline__ uint32_t vec_absmax16(const u32x4& w) {
+  uint32_t m = pk_max_u16(pk_max_u16(w[0] & 0x7FFF7FFFu, w[1] & 0x7FFF7FFFu),
+                          pk_max_u16(w[2] & 0x7FFF7FFFu, w[3] & 0x7FFF7FFFu));
+  uint32_t lo = m & 0xFFFFu, hi = m >> 16;
+  return lo > hi ? lo : hi;
+}
+
+// dual format: max|x| over x <= 0 and over x > 0 separately; NaN belongs to neither
+__device__ __forceinline__ void vec_absmax16_dual(const u32x4& w, uint32_t& mneg, uint32_t& mpos) {
+  uint32_t mn = 0, mp = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t a = w[k] & 0x7FFF7FFFu;
+    uint32_t nanm = pk_ashr_i16(pk_sub_u16(0x7C007C00u, a), 15);   // 0xFFFF where a > 0x7C00
+    a &= ~nanm;
+    uint32_t sm = pk_ashr_i16(w[k], 15);                            // 0xFFFF where the sign bit is set
+    mn = pk_max_u16(mn, a & sm);
+    mp = pk_max_u16(mp, a & ~sm);
+  }
+  uint32_t lo = mn & 0xFFFFu, hi = mn >> 16;
+  mneg = lo > hi ? lo : hi;
+  lo = mp & 0xFFFFu; hi = mp >> 16;
+  mpos = lo > hi ? lo : hi;
+}
+
+struct RowScale16 {
+  float sf, inv;
+  uint32_t s16x2;
+};
+
+__device__ __forceinline__ RowScale16 row_scale16(uint32_t amax_bits, float g, float inv_g) {
+  RowScale16 r;
+  uint32_t sb = scale_bits_f16(amax_bits, g, inv_g);
+  r.sf = h2f(sb);
+  r.inv = (r.sf == 0.0f) ? 0.0f : __builtin_amdgcn_rcpf(r.sf);   // s = 0: x/0 -> level 0 -> +0
+  r.s16x2 = sb | (sb << 16);
+  return r;
+}
+
+// dual format: a non-finite scale on either side poisons the whole row (0 * inf = NaN
+// is added to every element by the reference's `q_neg*s_neg + q_pos*s_pos`)
+__device__ __forceinline__ void dual_poison(RowScale16& n, RowScale16& p) {
+  bool bad = !(fabsf(n.sf) < __builtin_inff()) || !(fabsf(p.sf) < __builtin_inff());
+  if (bad) {
+    n.sf = p.sf = __builtin_nanf("");
+    n.s16x2 = p.s16x2 = 0x7E007E00u;
+  }
+}
+
+// The bucket -> level table, prebuilt on the host (immutable, cached per table pair)
+// and handed over BY VALUE in the kernel arguments: no device-side global state, and a
+// workgroup pays one 2-byte load per lane instead of evaluating the closed form.
+constexpr int kLutArgEntries = 1024;   // shift >= 6: every table pair except int_neg/e2m3_pos
+struct Lut16Tab {
+  uint16_t e[kLutArgEntries];
+};
+
+inline void lut16_build_host(uint16_t* lut, const Lut16Args& a) {
+  const int n = 1 << (16 - a.shift);
+  for (int i = 0; i < n; ++i) {
+    uint32_t u = (uint32_t)i << a.shift;
+    bool neg = (u >> 15) != 0;
+    float r = h2f(u & 0x7FFFu);
+    float qm = quant_mag(r, 0u, neg ? a.fneg : a.fpos);
+    uint32_t qb = f2h(qm);
+    lut[i] = (uint16_t)((neg && qm != 0.0f) ? (qb | 0x8000u) : qb);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// rows of 1..64 lanes x 16 bytes inside one wavefront (per-group 128, KV c=64, ...).
+// A workgroup owns TILE = 256*U consecutive vectors (U*4 KiB, contiguous in HBM);
+// workgroups are dispatched in address order, so the chip sweeps the tensor front
+// to back.  All U loads are issued before the table is staged and the barrier.
+// ---------------------------------------------------------------------------------
+template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true>
+__global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4* __restrict__ x,
+                                                                   u32x4* __restrict__ out, int64_t n_vec,
+                                                                   Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  bool first = true;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t v0 = tile * ((int64_t)kBlock * U) + threadIdx.x;
+    u32x4 raw[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t v = v0 + u * kBlock;
+      live[u] = v < n_vec;
+      raw[u] = live[u] ? (NTL ? __builtin_nontemporal_load(x + v) : x[v]) : u32x4{0, 0, 0, 0};
+    }
+    if (first) {
+      if (TAB_ARG) {
+        const int n = 1 << (16 - a.shift);
+        for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+      } else {
+        lut16_fill(lut, a);
+      }
+      __syncthreads();
+      first = false;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      u32x4 o;
+      if (DUAL) {
+        uint32_t mn, mp;
+        vec_absmax16_dual(raw[u], mn, mp);
+        mn = row_max_dpp<LPR>(mn);
+        mp = row_max_dpp<LPR>(mp);
+        RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
+        dual_poison(sn, sp);
+        o = quant_vec16<true>(raw[u], lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+      } else {
+        uint32_t m = row_max_dpp<LPR>(vec_absmax16(raw[u]));
+        RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+        o = quant_vec16<false>(raw[u], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      }
+      if (live[u]) {
+        if (NTS) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
+        else out[v0 + u * kBlock] = o;
+      }
+    }
+  }
+}

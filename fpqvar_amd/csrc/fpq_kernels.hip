@@ -117,36 +117,38 @@ int pos_levels(int id, float* out) {
 // ---------------------------------------------------------------------------------
 // Device helpers
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
-__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
+__host__ __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__host__ __device__ __forceinline__ uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
-__device__ __forceinline__ float h2f(uint32_t hbits) {
+__host__ __device__ __forceinline__ float h2f(uint32_t hbits) {
   _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)hbits);
   return (float)h;
 }
-__device__ __forceinline__ uint32_t f2h(float f) {
+__host__ __device__ __forceinline__ uint32_t f2h(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
   // The value must exist as a rounded fp32 before it is narrowed: torch materialises
   // the fp32 product and then casts (two roundings when x is fp32).  Without the
   // barrier LLVM folds fmul + fptrunc into v_fma_mixlo_f16, which rounds once.
   asm volatile("" : "+v"(f));
+#endif
   _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round to nearest even
   return (uint32_t)__builtin_bit_cast(uint16_t, h);
 }
 
 // Magnitude of the nearest level for r = |xn| (r >= 0 or NaN); neg01 = 1 when xn < 0
 // (a tie then resolves to the smaller magnitude).  NaN, Inf and r > limit give 0.
-__device__ __forceinline__ float quant_mag(float r, uint32_t neg01, const Fmt& f) {
+__host__ __device__ __forceinline__ float quant_mag(float r, uint32_t neg01, const Fmt& f) {
   // binades at or above kmin: keep M mantissa bits, round half up (or half down)
   uint32_t nb = (fbits(r) + f.half_add - neg01) & f.keep_mask;
   float qn = u2f(nb);
   // below kmin: equally spaced levels
   float t = r * f.inv_step0;  // exact (power of two)
-  float fl = floorf(t);
+  float fl = __builtin_floorf(t);
   float fr = t - fl;          // exact
   bool up = neg01 ? (fr > 0.5f) : (fr >= 0.5f);
   float qs = (fl + (up ? 1.0f : 0.0f)) * f.step0;
   float q = (r >= f.kmin) ? qn : qs;
-  q = fminf(q, f.gmax);
+  q = __builtin_fminf(q, f.gmax);
   return (r <= f.limit) ? q : 0.0f;
 }
 
@@ -476,6 +478,8 @@ __global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restri
   }
 }
 
+#include "fpq_fast16.h"
+
 // ---------------------------------------------------------------------------------
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
 // The table index is wave-uniform, so table[j] is a scalar load (SGPR broadcast).
@@ -686,6 +690,75 @@ int dispatch_rows(const void* x, void* out, int64_t rows, int64_t cols, int in_d
   return FPQ_ERR_DTYPE;
 }
 
+// ---- fast fp16 -> fp16 path (fpq_fast16.h) ------------------------------------------
+inline int table_shift16(int id) {   // rounding thresholds are multiples of 2^shift in fp16 patterns
+  return id == FPQ_INT_NEG ? 5 : 9 - kTables[id].mbits;
+}
+
+inline bool fast16_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int out_dtype) {
+  if (in_dtype != FPQ_F16 || out_dtype != FPQ_F16) return false;
+  if ((((uintptr_t)x | (uintptr_t)out) & 15) != 0 || cols % 8 != 0) return false;
+  const int64_t lpr = cols / 8;
+  return lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+}
+
+// host cache of prebuilt tables: built once per (neg, pos) pair, immutable afterwards
+struct Lut16Host {
+  Lut16Args args;
+  Lut16Tab tab;
+  bool tab_valid;
+};
+
+inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
+  static const auto* cache = [] {
+    auto* c = new Lut16Host[FPQ_NUM_TABLES * FPQ_NUM_TABLES];
+    for (int n = 0; n < FPQ_NUM_TABLES; ++n)
+      for (int p = 0; p < FPQ_NUM_TABLES; ++p) {
+        Lut16Host& h = c[n * FPQ_NUM_TABLES + p];
+        h.args.fneg = make_fmt(n);
+        h.args.fpos = make_fmt(p);
+        h.args.inv_gneg = 1.0f / h.args.fneg.gmax;
+        h.args.inv_gpos = 1.0f / h.args.fpos.gmax;
+        h.args.shift = table_shift16(n) < table_shift16(p) ? table_shift16(n) : table_shift16(p);
+        h.tab_valid = (1 << (16 - h.args.shift)) <= kLutArgEntries;
+        for (int i = 0; i < kLutArgEntries; ++i) h.tab.e[i] = 0;
+        if (h.tab_valid) lut16_build_host(h.tab.e, h.args);
+      }
+    return c;
+  }();
+  return cache[neg_id * FPQ_NUM_TABLES + pos_id];
+}
+
+// Defaults measured on MI355X with tools/kbench (cold HBM, 4 rotating 252 MB buffer pairs):
+// U = 2 with non-temporal loads and stores matches the best plain copy (78 us for
+// fp16 [65536x1920] = 6.45 TB/s); grid-stride with a capped grid or U = 8 lose 3-8 %.
+template <bool DUAL, int U = 2, bool NTL = true, bool NTS = true>
+int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id, hipStream_t st,
+                  int grid_cap = 1 << 20) {
+  const Lut16Host& h = lut16_host(neg_id, pos_id);
+  const int64_t n_vec = rows * (cols / 8);
+  const int lpr = (int)(cols / 8);
+  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  auto go = [&](auto kern_tab, auto kern_fill) {
+    if (h.tab_valid)
+      hipLaunchKernelGGL(kern_tab, dim3(grid_for(tiles, grid_cap)), dim3(kBlock), lds, st, (const u32x4*)x,
+                         (u32x4*)out, n_vec, h.args, h.tab);
+    else
+      hipLaunchKernelGGL(kern_fill, dim3(grid_for(tiles, grid_cap)), dim3(kBlock), lds, st, (const u32x4*)x,
+                         (u32x4*)out, n_vec, h.args, h.tab);
+    return check_launch();
+  };
+#define FPQ_FAST16_CASE(L) \
+  case L: return go(rows16_lut_subwave_kernel<L, DUAL, U, true, NTL, NTS>, rows16_lut_subwave_kernel<L, DUAL, U, false, NTL, NTS>);
+  switch (lpr) {
+    FPQ_FAST16_CASE(1) FPQ_FAST16_CASE(2) FPQ_FAST16_CASE(4) FPQ_FAST16_CASE(8)
+    FPQ_FAST16_CASE(16) FPQ_FAST16_CASE(32) FPQ_FAST16_CASE(64)
+  }
+#undef FPQ_FAST16_CASE
+  return FPQ_ERR_SHAPE;
+}
+
 }  // namespace
 
 // =================================================================================
@@ -767,6 +840,8 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
     return FPQ_ERR_DTYPE;
   if (rows == 0 || cols == 0) return FPQ_OK;
   if (!x || !out) return FPQ_ERR_ARG;
+  if (fast16_eligible(x, out, cols, in_dtype, out_dtype))
+    return launch_fast16<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
   DualArgs dual = {};
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,
                               (hipStream_t)stream);
@@ -782,6 +857,8 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
     return FPQ_ERR_DTYPE;
   if (rows == 0 || cols == 0) return FPQ_OK;
   if (!x || !out) return FPQ_ERR_ARG;
+  if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype))
+    return launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, (hipStream_t)stream);
   DualArgs dual;
   dual.fneg = make_fmt(neg_table);
   dual.fpos = make_fmt(pos_table);
