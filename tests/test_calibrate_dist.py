@@ -1,0 +1,93 @@
+"""Sharded weight calibration: partition logic and the world-size-2 all-gather on
+CPU with gloo.  The quantizer is injected (the oracle plays the HIP kernel's
+part here; the GPU test runs the real thing)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fpqvar_amd import calibrate as cal
+from oracle import fpq_oracle as orc
+
+
+def test_var_shapes_and_partition_balance():
+    shapes = cal.var_linear_shapes(30)
+    assert len(shapes) == 120
+    per_block = sum(o * i for (o, i) in list(shapes.values())[:4])
+    assert per_block == 44_236_800                       # 44.24 M / block
+    assert sum(o * i for o, i in shapes.values()) == 1_327_104_000
+    sizes = [(n, o * i) for n, (o, i) in shapes.items()]
+    for world in (1, 2, 4, 8):
+        plan = cal.partition(sizes, world)
+        flat = [n for p in plan for n in p]
+        assert sorted(flat) == sorted(shapes)            # every layer exactly once
+        loads = [sum(dict(sizes)[n] for n in p) for p in plan]
+        assert max(loads) / (sum(loads) / world) < 1.03   # within 3 % of perfect balance
+    assert sum(o * i for o, i in cal.var_linear_shapes(36).values()) == 2_293_235_712
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy_weights():
+    g = torch.Generator().manual_seed(1234)
+    shapes = {"b0.qkv": (384, 128), "b0.proj": (128, 128), "b0.fc1": (512, 128), "b0.fc2": (128, 512),
+              "b1.qkv": (384, 128), "b1.proj": (128, 128), "b1.fc1": (512, 128)}
+    return {n: torch.randn(*s, generator=g) * 0.02 for n, s in shapes.items()}
+
+
+def _oracle_quant(name, w):
+    return orc.per_group_kernel_sem(w, "e2m1", 128).to(torch.float16)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        weights = _toy_weights()
+        # poison the layers this rank does not own: they must never be read
+        plan = cal.partition([(n, w.numel()) for n, w in weights.items()], world)
+        for n in weights:
+            if n not in plan[rank]:
+                weights[n] = torch.full_like(weights[n], float("nan"))
+        got = cal.calibrate_sharded(weights, quantize=_oracle_quant, exchange="fp16")
+        want = {n: _oracle_quant(n, w) for n, w in _toy_weights().items()}
+        ok = list(got) == list(want) and all(
+            torch.equal(got[n].view(torch.int16), want[n].view(torch.int16)) and got[n].shape == want[n].shape
+            for n in want)
+        local = cal.calibrate_sharded(weights, quantize=_oracle_quant, gather=False)
+        ok = ok and sorted(local) == sorted(plan[rank])
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", (2, 3))
+def test_calibrate_all_gather_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]
+
+
+def test_single_process_no_dist():
+    weights = _toy_weights()
+    got = cal.calibrate_sharded(weights, quantize=_oracle_quant)
+    for n, w in weights.items():
+        assert torch.equal(got[n], _oracle_quant(n, w))

@@ -319,3 +319,22 @@ def test_full_size_metric_shape(dev, qu):
     assert bool((got.view(-1, 128)[17 * 15 + 2] == 0).all())
     # sign preserved or flushed to +0
     assert bool(((got.float() * x.float()) >= 0).all())
+
+
+# ------------------------------------------------------------------ sharded calibration on the GPU (world = 1)
+def test_calibrate_on_gpu(dev):
+    from fpqvar_amd import calibrate as cal
+    g = torch.Generator().manual_seed(77)
+    shapes = {"b0.qkv": (384, 128), "b0.fc1": (512, 128), "b0.fc2": (128, 512), "b0.proj": (128, 128)}
+    w_cpu = {n: torch.randn(*s, generator=g) * 0.02 for n, s in shapes.items()}
+    w_gpu = {n: w.to(dev) for n, w in w_cpu.items()}
+    want = {n: orc.per_group_kernel_sem(w, "e2m1", 128).to(torch.float16) for n, w in w_cpu.items()}
+    got = cal.calibrate_sharded(w_gpu)                        # default HIP quantizer: fp32 in -> fp16 out
+    got_codes = cal.calibrate_sharded(w_gpu, exchange="codes")
+    for n in shapes:
+        assert_bits_equal(got[n], want[n], f"calibrate fp16 {n}")
+        assert_bits_equal(got_codes[n], want[n], f"calibrate codes {n}")
+    # FP6 per-channel weights (W6A6 run, tr/quant_utils.py:808-815)
+    q6 = cal.default_weight_quantizer("per_channel", "fp6_e2m3", 6)
+    for n in shapes:
+        assert_bits_equal(q6(n, w_gpu[n]), orc.per_token_kernel_sem(w_cpu[n], "e2m3"), f"fp6 per-channel {n}")
