@@ -254,3 +254,85 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
     }
   }
 }
+
+// ---------------------------------------------------------------------------------
+// long fp16 rows (per-token 1920 / 7680 / 2304 / 9216, per-channel weights in fp16):
+// one workgroup walks a contiguous run of rows; a row's vectors stay in registers
+// (<= MAXC per lane) between the max reduction (DPP + LDS) and the rounding.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_max16(uint32_t v, uint32_t* sh) {
+  v = row_max_dpp<64>(v);
+  __syncthreads();   // sh may still be read from the previous reduction
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t r = sh[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / 64; ++i) r = r > sh[i] ? r : sh[i];
+  return r;
+}
+
+template <bool DUAL, int MAXC, bool TAB_ARG>
+__global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t* __restrict__ x,
+                                                                 uint16_t* __restrict__ out, int64_t rows,
+                                                                 int64_t cols, int64_t rows_per_block, Lut16Args a,
+                                                                 Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ uint32_t sh[kBlock / 64];
+  const int64_t vec_per_row = cols >> 3;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  bool first = true;
+  for (int64_t row = r0; row < r1; ++row) {
+    const u32x4* xr = (const u32x4*)(x + row * cols);
+    u32x4* orow = (u32x4*)(out + row * cols);
+    u32x4 raw[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      int64_t v = (int64_t)c * kBlock + threadIdx.x;
+      raw[c] = (v < vec_per_row) ? __builtin_nontemporal_load(xr + v) : u32x4{0, 0, 0, 0};
+    }
+    if (first) {
+      if (TAB_ARG) {
+        const int n = 1 << (16 - a.shift);
+        for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+      } else {
+        lut16_fill(lut, a);
+      }
+      first = false;   // the barriers inside block_max16 order the table before its first use
+    }
+    RowScale16 sn, sp;
+    if (DUAL) {
+      uint32_t mn = 0, mp = 0;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        uint32_t a1, b1;
+        vec_absmax16_dual(raw[c], a1, b1);
+        mn = mn > a1 ? mn : a1;
+        mp = mp > b1 ? mp : b1;
+      }
+      mn = block_max16(mn, sh);
+      mp = block_max16(mp, sh);
+      sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg);
+      sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
+      dual_poison(sn, sp);
+    } else {
+      uint32_t m = 0;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        uint32_t t = vec_absmax16(raw[c]);
+        m = m > t ? m : t;
+      }
+      m = block_max16(m, sh);
+      sn = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      sp = sn;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      int64_t v = (int64_t)c * kBlock + threadIdx.x;
+      if (v < vec_per_row) {
+        u32x4 o = quant_vec16<DUAL>(raw[c], lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+        __builtin_nontemporal_store(o, orow + v);
+      }
+    }
+  }
+}

@@ -695,11 +695,21 @@ inline int table_shift16(int id) {   // rounding thresholds are multiples of 2^s
   return id == FPQ_INT_NEG ? 5 : 9 - kTables[id].mbits;
 }
 
+inline bool fast16_aligned(const void* x, const void* out, int64_t cols, int in_dtype, int out_dtype) {
+  return in_dtype == FPQ_F16 && out_dtype == FPQ_F16 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0 &&
+         cols % 8 == 0;
+}
+
+// rows that live inside one wavefront
 inline bool fast16_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int out_dtype) {
-  if (in_dtype != FPQ_F16 || out_dtype != FPQ_F16) return false;
-  if ((((uintptr_t)x | (uintptr_t)out) & 15) != 0 || cols % 8 != 0) return false;
+  if (!fast16_aligned(x, out, cols, in_dtype, out_dtype)) return false;
   const int64_t lpr = cols / 8;
   return lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+}
+
+// long rows: one workgroup per row, at most 8 vectors (64 halves) per lane in registers
+inline bool fast16_block_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int out_dtype) {
+  return fast16_aligned(x, out, cols, in_dtype, out_dtype) && cols / 8 <= (int64_t)kBlock * 8;
 }
 
 // host cache of prebuilt tables: built once per (neg, pos) pair, immutable afterwards
@@ -757,6 +767,33 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   }
 #undef FPQ_FAST16_CASE
   return FPQ_ERR_SHAPE;
+}
+
+template <bool DUAL>
+int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id,
+                        hipStream_t st) {
+  const Lut16Host& h = lut16_host(neg_id, pos_id);
+  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const int64_t vec_per_row = cols / 8;
+  const int maxc = (int)((vec_per_row + kBlock - 1) / kBlock);
+  // enough workgroups to fill the chip several times over, each walking consecutive rows
+  int64_t rpb = (rows + 16383) / 16384;
+  if (rpb < 1) rpb = 1;
+  const int64_t grid = (rows + rpb - 1) / rpb;
+  auto go = [&](auto kern_tab, auto kern_fill) {
+    if (h.tab_valid)
+      hipLaunchKernelGGL(kern_tab, dim3((unsigned)grid), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out,
+                         rows, cols, rpb, h.args, h.tab);
+    else
+      hipLaunchKernelGGL(kern_fill, dim3((unsigned)grid), dim3(kBlock), lds, st, (const uint16_t*)x,
+                         (uint16_t*)out, rows, cols, rpb, h.args, h.tab);
+    return check_launch();
+  };
+  if (maxc <= 1) return go(rows16_lut_block_kernel<DUAL, 1, true>, rows16_lut_block_kernel<DUAL, 1, false>);
+  if (maxc <= 2) return go(rows16_lut_block_kernel<DUAL, 2, true>, rows16_lut_block_kernel<DUAL, 2, false>);
+  if (maxc <= 4) return go(rows16_lut_block_kernel<DUAL, 4, true>, rows16_lut_block_kernel<DUAL, 4, false>);
+  if (maxc <= 5) return go(rows16_lut_block_kernel<DUAL, 5, true>, rows16_lut_block_kernel<DUAL, 5, false>);
+  return go(rows16_lut_block_kernel<DUAL, 8, true>, rows16_lut_block_kernel<DUAL, 8, false>);
 }
 
 }  // namespace
@@ -842,6 +879,8 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
   if (!x || !out) return FPQ_ERR_ARG;
   if (fast16_eligible(x, out, cols, in_dtype, out_dtype))
     return launch_fast16<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
+  if (fast16_block_eligible(x, out, cols, in_dtype, out_dtype))
+    return launch_fast16_block<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
   DualArgs dual = {};
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,
                               (hipStream_t)stream);
@@ -859,6 +898,8 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   if (!x || !out) return FPQ_ERR_ARG;
   if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype))
     return launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, (hipStream_t)stream);
+  if (!clip_absmax && fast16_block_eligible(x, out, cols, in_dtype, out_dtype))
+    return launch_fast16_block<true>(x, out, rows, cols, neg_table, pos_table, (hipStream_t)stream);
   DualArgs dual;
   dual.fneg = make_fmt(neg_table);
   dual.fpos = make_fmt(pos_table);

@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
   for (int mode = 0; mode < 4; ++mode) {
     hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, x, n, mode, 1234u + mode);
     for (const Case& c : cases) {
-      for (int g : {128, 64}) {
+      for (int g : {128, 64, 1920, 7680, 15360}) {
         int64_t nr = chk_rows * cols / g;
         int r1, r2;
         if (c.sym_table >= 0) {
@@ -128,9 +128,9 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, st, o1, o2, nr * g, cnt, first);
         unsigned long long hc; long long hf;
         CK(hipMemcpy(&hc, cnt, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hf, first, 8, hipMemcpyDeviceToHost));
-        printf("check mode %d %-9s g=%-3d: %llu mismatches", mode, c.name, g, hc);
+        printf("check mode %d %-9s g=%-5d: %llu mismatches", mode, c.name, g, hc);
         if (hc) {
-          uint16_t hx[128], ha, hb; int64_t g0 = hf / g * g;
+          static uint16_t hx[16384]; uint16_t ha, hb; int64_t g0 = hf / g * g;
           CK(hipMemcpy(&ha, o1 + hf, 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hb, o2 + hf, 2, hipMemcpyDeviceToHost));
           CK(hipMemcpy(hx, x + g0, 2 * g, hipMemcpyDeviceToHost));
           uint16_t am = 0; for (int i = 0; i < g; ++i) am = std::max<uint16_t>(am, hx[i] & 0x7FFF);
@@ -173,6 +173,10 @@ int main(int argc, char** argv) {
   add("fast e2m1 U4 cap2048", [&] { launch_fast16<false, 4>(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_E2M1, st, 2048); });
   add("fast e2m1 U4 cap8192", [&] { launch_fast16<false, 4>(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_E2M1, st, 8192); });
   add("fast dualfp6 U4 (fill)", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st); });
+  add("fast e2m3 token1920", [&] { fpq_quant_rows(X(), O(), n / 1920, 1920, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
+  add("fast e2m3 token7680", [&] { fpq_quant_rows(X(), O(), n / 7680, 7680, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
+  add("fast dualfp6 tok7680", [&] { fpq_quant_rows_dual(X(), O(), n / 7680, 7680, FPQ_INT_NEG, FPQ_E2M3_POS, FPQ_F16, FPQ_F16, nullptr, 1.f, st); });
+  add("generic e2m3 tok1920", [&] { fpq_quant_rows_generic(X(), O(), n / 1920, 1920, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
   add("generic e2m1 g128", [&] { fpq_quant_rows_generic(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_F16, FPQ_F16, st); });
   add("fast e2m1 g128", [&] { fpq_quant_rows(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_F16, FPQ_F16, st); });
   add("fast e2m3 g128", [&] { fpq_quant_rows(X(), O(), n / 128, 128, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
