@@ -52,6 +52,9 @@ struct Fmt {
   int32_t zero_code;   // index of 0.0 in the sorted de-duplicated SYMMETRIC table
   int32_t mshift;      // 23 - M
   uint32_t kmin_code_base;  // (bits(kmin) >> mshift) - 2^M : level index = (bits>>mshift) - base
+  int32_t argmin;     // 1: torch.argmin semantics of the reference's pure-torch path (ties to the
+                      //    SMALLER value, NaN/Inf -> table[0], no reach limit) instead of the scan's
+  float preclamp;     // > 0: x = clamp(x, -preclamp, preclamp) first (the reference's clamp(x,-3,3))
 };
 
 struct TableInfo {
@@ -93,6 +96,8 @@ Fmt make_fmt(int id) {
   f.zero_code = t.n_pos - 1;
   f.mshift = 23 - t.mbits;
   f.kmin_code_base = (f2u(t.kmin) >> f.mshift) - (1u << t.mbits);
+  f.argmin = 0;
+  f.preclamp = 0.0f;
   return f;
 }
 
@@ -211,6 +216,17 @@ template <typename T>
 __device__ __forceinline__ float quant_sym(float xf, float s, const Fmt& f) {
   float xn = DT<T>::round(xf / s);
   uint32_t neg = (xn < 0.0f) ? 1u : 0u;
+  if (f.argmin) {
+    // tr/quant_utils.py:209-230: first minimal index = the smaller value on a tie, i.e. down in
+    // magnitude for xn > 0 and up for xn < 0; an all-NaN / all-Inf distance row gives index 0
+    float r = fabsf(xn);
+    Fmt g = f;
+    g.limit = __builtin_inff();
+    float qm = quant_mag(r, neg ^ 1u, g);
+    float q = (neg && qm != 0.0f) ? -qm : qm;
+    if (!(r < __builtin_inff())) q = -f.gmax;
+    return q * s;
+  }
   float qm = quant_mag(fabsf(xn), neg, f);
   float q = (neg && qm != 0.0f) ? -qm : qm;  // the table's zero is +0.0
   return q * s;                              // fp32 product; 0*inf and 0*nan poison the row
@@ -278,10 +294,10 @@ __global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __res
   constexpr int V = DT<Tin>::kVec;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   int64_t v0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  float clip = 0.0f;
+  float clip = fs.preclamp;
   bool clip_nan = false;
-  const bool has_clip = DUAL && dual.clip_absmax != nullptr;
-  if (has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+  const bool has_clip = DUAL ? (dual.clip_absmax != nullptr) : (fs.preclamp > 0.0f);
+  if (DUAL && has_clip) clip = clip_value<Tin>(dual, &clip_nan);
 
   // n_vec is a multiple of LPR (whole rows) and LPR divides 64, so a row never
   // straddles the `live` boundary inside a wavefront.
@@ -368,10 +384,10 @@ __global__ __launch_bounds__(kBlock) void rows_block_kernel(const Tin* __restric
   constexpr int V = DT<Tin>::kVec;
   __shared__ uint32_t sh[kBlock / 64];
   const int64_t vec_per_row = cols / V;  // cols % V == 0 guaranteed by the host
-  float clip = 0.0f;
+  float clip = fs.preclamp;
   bool clip_nan = false;
-  const bool has_clip = DUAL && dual.clip_absmax != nullptr;
-  if (has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+  const bool has_clip = DUAL ? (dual.clip_absmax != nullptr) : (fs.preclamp > 0.0f);
+  if (DUAL && has_clip) clip = clip_value<Tin>(dual, &clip_nan);
 
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const u32x4* xr = (const u32x4*)(x + row * cols);
@@ -446,10 +462,10 @@ __global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restri
                                                             Tout* __restrict__ out, int64_t rows,
                                                             int64_t cols, Fmt fs, DualArgs dual) {
   __shared__ uint32_t sh[kBlock / 64];
-  float clip = 0.0f;
+  float clip = fs.preclamp;
   bool clip_nan = false;
-  const bool has_clip = DUAL && dual.clip_absmax != nullptr;
-  if (has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+  const bool has_clip = DUAL ? (dual.clip_absmax != nullptr) : (fs.preclamp > 0.0f);
+  if (DUAL && has_clip) clip = clip_value<Tin>(dual, &clip_nan);
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const Tin* xr = x + row * cols;
     uint32_t mneg = 0, mpos = 0;
@@ -884,6 +900,20 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
   DualArgs dual = {};
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,
                               (hipStream_t)stream);
+}
+
+int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols, int table_id, int in_dtype,
+                          int clamp3, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !out) return FPQ_ERR_ARG;
+  Fmt f = make_fmt(table_id);
+  f.argmin = 1;
+  f.preclamp = clamp3 ? 3.0f : 0.0f;
+  DualArgs dual = {};
+  return dispatch_rows<false>(x, out, rows, cols, in_dtype, FPQ_F32, f, dual, (hipStream_t)stream);
 }
 
 int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table, int pos_table,

@@ -68,6 +68,23 @@ def quant_rows(x: torch.Tensor, table: str, cols: int, out_dtype: Optional[torch
     return out
 
 
+def quant_rows_argmin(x: torch.Tensor, table: str, cols: int, clamp3: bool) -> torch.Tensor:
+    """The reference's pure-torch quantizers (argmin lookup, float32 result) in one launch."""
+    require_gpu(x, "quant_rows_argmin")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_rows_argmin: x must be float16 or float32, got {x.dtype}")
+    n = x.numel()
+    if cols <= 0 or n % cols != 0:
+        raise RuntimeError(f"quant_rows_argmin: numel {n} is not a multiple of the row length {cols}")
+    xc = _contig(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows_argmin(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[table],
+                                          dtype_id(x.dtype), int(clamp3), stream_ptr(x.device)),
+              "fpq_quant_rows_argmin")
+    return out
+
+
 def absmax(x: torch.Tensor) -> torch.Tensor:
     """0-dim max|x| in x's dtype (NaN-propagating)."""
     require_gpu(x, "absmax")

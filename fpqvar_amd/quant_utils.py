@@ -36,6 +36,45 @@ int_neg_grid = torch.tensor([float(-v) if v else 0.0 for v in range(32, -1, -1)]
 e2m3_pos_grid = torch.tensor(_e2m3_pos())
 
 
+# ---- the reference's pure-torch quantizers (tr/quant_utils.py:237-262,285-310,333-358) ----
+# argmin lookup (ties to the smaller value), clamp(x, -3, 3) first except e2_per_group,
+# float32 result.  QuantizedLinear uses the per_token ones for per_channel weights and
+# per_token activations in FP4 even on the GPU (tr/quant_utils.py:699-704,796-807).
+
+def fp_quant_e3_per_token(x, n_bits):
+    assert n_bits == 4
+    return ops.quant_rows_argmin(x, "e3m0", x.shape[-1], clamp3=True)
+
+
+def fp_quant_e2_per_token(x, n_bits):
+    assert n_bits == 4
+    return ops.quant_rows_argmin(x, "e2m1", x.shape[-1], clamp3=True)
+
+
+def fp_quant_e1_per_token(x, n_bits):
+    assert n_bits == 4
+    return ops.quant_rows_argmin(x, "e1m2", x.shape[-1], clamp3=True)
+
+
+def fp_quant_e3_per_group(x, n_bits, group_size=128):
+    assert n_bits == 4
+    return ops.quant_rows_argmin(x, "e3m0", group_size, clamp3=True)
+
+
+def fp_quant_e2_per_group(x, n_bits, group_size=128):
+    """No +-3 clamp here (commented out in the reference, :302).  The reference divides
+    its argument in place through a view; this version leaves x untouched."""
+    assert n_bits == 4
+    if not x.is_contiguous():
+        raise RuntimeError("view size is not compatible with input tensor's size and stride")
+    return ops.quant_rows_argmin(x, "e2m1", group_size, clamp3=False)
+
+
+def fp_quant_e1_per_group(x, n_bits, group_size=128):
+    assert n_bits == 4
+    return ops.quant_rows_argmin(x, "e1m2", group_size, clamp3=True)
+
+
 # ---- FP4, per group of `group_size` consecutive elements (tr/quant_utils.py:265-282,313-330,361-378) ----
 
 def fp_quant_e3_per_group_cuda(x, n_bits, group_size=128):

@@ -97,6 +97,20 @@ int fpq_quant_nearest_builtin(const float* x, float* z, int64_t n, int table_id,
 int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int table_id, int in_dtype,
                    int out_dtype, fpq_stream_t stream);
 
+/* The reference's pure-torch quantizers ("CPU path", also what QuantizedLinear uses on
+ * the GPU for per_channel / per_token FP4, tr/quant_utils.py:699-704,796-807):
+ *     fp_quant_e{1,2,3}_per_token   tr/quant_utils.py:237-247,285-295,333-343   (clamp3 = 1)
+ *     fp_quant_e{1,3}_per_group     :250-262,346-358                            (clamp3 = 1)
+ *     fp_quant_e2_per_group         :298-310                                    (clamp3 = 0)
+ * Same scale / normalise arithmetic as fpq_quant_rows, but the lookup is
+ * quantize_to_nearest_grid (:209-230) = torch.argmin over |x - grid|: a tie goes to the
+ * SMALLER value, a NaN or +-Inf normalised value selects grid[0] (so an all-zero row
+ * yields -0.0), and the result is float32 whatever the input dtype.  clamp3: clamp x to
+ * [-3, 3] first.  The input is never written (the reference's fp_quant_e2_per_group
+ * divides its argument in place; that side effect is not reproduced). */
+int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols, int table_id, int in_dtype,
+                          int clamp3, fpq_stream_t stream);
+
 /* Asymmetric neg/pos dual format: x <= 0 is scaled and rounded on `neg_table`,
  * x > 0 on `pos_table`, each with its own per-row scale; NaN elements take
  * neither side and come out 0 (torch.where semantics).

@@ -338,3 +338,51 @@ def test_calibrate_on_gpu(dev):
     q6 = cal.default_weight_quantizer("per_channel", "fp6_e2m3", 6)
     for n in shapes:
         assert_bits_equal(q6(n, w_gpu[n]), orc.per_token_kernel_sem(w_cpu[n], "e2m3"), f"fp6 per-channel {n}")
+
+
+# ------------------------------------------------------------------ the reference's pure-torch quantizers (argmin)
+@pytest.mark.parametrize("dn", ("f16", "f32"))
+@pytest.mark.parametrize("kind", KINDS)
+def test_argmin_path_golden(dev, qu, golden, kind, dn):
+    x = from_bits(golden[f"in/{kind}_{dn}"]).to(dev)
+    fns_g = {"e2m1": qu.fp_quant_e2_per_group, "e1m2": qu.fp_quant_e1_per_group, "e3m0": qu.fp_quant_e3_per_group}
+    fns_t = {"e2m1": qu.fp_quant_e2_per_token, "e1m2": qu.fp_quant_e1_per_token, "e3m0": qu.fp_quant_e3_per_token}
+    for name in SYM4:
+        want = from_bits(golden[f"out/per_group_argmin/{name}/{kind}_{dn}"])
+        assert want.dtype == torch.float32
+        assert_bits_equal(fns_g[name](x, 4, 128), want, f"argmin group {name} {kind} {dn}")
+        want = from_bits(golden[f"out/per_token_argmin/{name}/{kind}_{dn}"])
+        assert_bits_equal(fns_t[name](x, 4), want, f"argmin token {name} {kind} {dn}")
+
+
+@pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
+def test_argmin_path_vs_oracle(dev, qu, dtype):
+    x = _inputs("heavy", (128, 1920), dtype, 41)
+    x[2, :128] = 0
+    # exact ties of the normalised value: group maximum 6 -> scale 1
+    tie = torch.tensor([6.0, 0.25, -0.25, 0.75, -0.75, 1.25, -1.25, 1.75, -1.75, 2.5, -2.5, 3.5, -3.5, 5.0, -5.0])
+    x[4, :128] = 0
+    x[4, :tie.numel()] = tie.to(dtype)
+    xd = x.to(dev)
+    for name, fg, ft in (("e2m1", qu.fp_quant_e2_per_group, qu.fp_quant_e2_per_token),
+                         ("e1m2", qu.fp_quant_e1_per_group, qu.fp_quant_e1_per_token),
+                         ("e3m0", qu.fp_quant_e3_per_group, qu.fp_quant_e3_per_token)):
+        assert_bits_equal(fg(xd, 4, 128), orc.per_group_argmin_sem(x, name, 128, clamp3=(name != "e2m1")),
+                          f"argmin group {name}")
+        assert_bits_equal(ft(xd, 4), orc.per_token_argmin_sem(x, name), f"argmin token {name}")
+    # the lookup alone on every fp16 value and on fp32 neighbourhoods of the midpoints:
+    # one row whose maximum makes the scale exactly 1
+    for name in SYM4:
+        tab = orc.TABLES[name]
+        gmax = float(tab.abs().max())
+        v = torch.cat([all_fp16_as_f32(), neighbourhoods(tab)])
+        v = v[torch.isfinite(v) & (v.abs() <= gmax)]
+        pad = (-v.numel() - 1) % 8
+        row = torch.cat([torch.tensor([gmax]), v, torch.zeros(pad)]).unsqueeze(0)
+        got = ops_argmin(dev, row, name)
+        assert_bits_equal(got, orc.nearest_argmin(row / 1.0, tab) * 1.0, f"argmin lookup {name}")
+
+
+def ops_argmin(dev, row, name):
+    from fpqvar_amd import ops
+    return ops.quant_rows_argmin(row.to(dev), name, row.shape[-1], clamp3=False)
