@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference's quantized Linear wrappers.
+
+``QuantizedLinear`` / ``QuantizedLinear_fc2`` / ``quantize_VAR`` keep the reference's
+constructor arguments, string flags and dispatch
+(models_fp_quant_transform_rotate/quant_utils.py:649-867, 870-1092, 1095-1167):
+activations are fake-quantized on every forward, weights once in ``from_float``;
+``forward`` is ``F.linear(act_quant(x), W, b)``.
+
+Only the floating-point formats are wired up (``activation_fp_quant`` /
+``weight_fp_quant`` = True): the INT / log2 RTN baselines of the reference are single
+fused torch ops already and are out of scope here; asking
+for them raises ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+from torch import nn
+
+from . import quant_utils as qu
+
+_GROUP = 128   # hard-coded in every partial(...) of the reference (tr/quant_utils.py:727-735)
+
+
+def _act_quantizer(act_quant, activation_fp_quant, act_fp_type, a_bit, fc2: bool):
+    """tr/quant_utils.py:696-746 (QuantizedLinear) and :917-973 (QuantizedLinear_fc2)."""
+    if act_quant not in ("per_token", "per_tensor", "per_group"):
+        raise ValueError(f"Invalid act_quant: {act_quant}")
+    if not activation_fp_quant or act_quant == "per_tensor":
+        raise NotImplementedError("INT / log2 activation quantizers are out of scope (SURVEY.md section 2 row 4)")
+    if act_quant == "per_token":
+        table = {"fp_e1": qu.fp_quant_e1_per_token, "fp_e2": qu.fp_quant_e2_per_token,
+                 "fp_e3": qu.fp_quant_e3_per_token, "fp6_e2m3": qu.fp6_quant_e2m3_per_token_cuda,
+                 "fp6_e3m2": qu.fp6_quant_e3m2_per_token_cuda}
+        if fc2:
+            table["fp6_int_neg_e2m3_pos"] = qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda
+        if act_fp_type not in table:
+            raise ValueError("Unsupported fp_type.")
+        return partial(table[act_fp_type], n_bits=a_bit)
+    table = {"fp_e1": qu.fp_quant_e1_per_group_cuda, "fp_e2": qu.fp_quant_e2_per_group_cuda,
+             "fp_e3": qu.fp_quant_e3_per_group_cuda, "fp6_e2m3": qu.fp6_quant_e2m3_per_group_cuda,
+             "fp6_e3m2": qu.fp6_quant_e3m2_per_group_cuda}
+    if fc2:
+        table["fp_e1m2_neg_e2m1_pos"] = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda
+        table["fp6_int_neg_e2m3_pos"] = qu.fp6_quant_int_neg_e2m3_pos_per_group_cuda
+    if act_fp_type not in table:
+        raise ValueError("Unsupported fp_type.")
+    return partial(table[act_fp_type], n_bits=a_bit, group_size=_GROUP)
+
+
+def _quantize_weight(w, weight_quant, weight_fp_quant, weight_fp_type, w_bit):
+    """tr/quant_utils.py:794-855.  per_channel FP4 goes through the pure-torch (argmin)
+    functions exactly as in the reference; per_group through the `_cuda` ones."""
+    if weight_quant == "per_tensor" or not weight_fp_quant:
+        raise NotImplementedError("INT weight quantizers are out of scope (SURVEY.md section 2 row 4)")
+    if weight_quant == "per_channel":
+        table = {"fp_e1": qu.fp_quant_e1_per_token, "fp_e2": qu.fp_quant_e2_per_token,
+                 "fp_e3": qu.fp_quant_e3_per_token, "fp6_e2m3": qu.fp6_quant_e2m3_per_token_cuda,
+                 "fp6_e3m2": qu.fp6_quant_e3m2_per_token_cuda}
+        if weight_fp_type not in table:
+            raise ValueError("Unsupported fp_type.")
+        return table[weight_fp_type](w, n_bits=w_bit)
+    if weight_quant == "per_group":
+        table = {"fp_e1": qu.fp_quant_e1_per_group_cuda, "fp_e2": qu.fp_quant_e2_per_group_cuda,
+                 "fp_e3": qu.fp_quant_e3_per_group_cuda, "fp6_e2m3": qu.fp6_quant_e2m3_per_group_cuda,
+                 "fp6_e3m2": qu.fp6_quant_e3m2_per_group_cuda}
+        if weight_fp_type not in table:
+            raise ValueError("Unsupported fp_type.")
+        return table[weight_fp_type](w, n_bits=w_bit, group_size=_GROUP)
+    raise ValueError(f"Invalid weight_quant: {weight_quant}")
+
+
+class QuantizedLinear(nn.Module):
+    _FC2 = False
+
+    def __init__(self, in_features, out_features, bias=True, act_quant=None, quantize_output=False,
+                 w_bit=8, a_bit=8, act_quant_sym=True, fc2_act_log2_quant=False, activation_fp_quant=False,
+                 weight_fp_quant=False, act_fp_type=False, weight_fp_type=False):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.w_bit = w_bit
+        self.a_bit = a_bit
+        self.act_quant_sym = act_quant_sym
+        self.fc2_act_log2_quant = fc2_act_log2_quant
+        self.activation_fp_quant = activation_fp_quant
+        self.weight_fp_quant = weight_fp_quant
+        self.act_fp_type = act_fp_type
+        self.register_buffer("weight", torch.randn(out_features, in_features, dtype=torch.float16))
+        if bias:
+            self.register_buffer("bias", torch.zeros((1, out_features), dtype=torch.float16))
+        else:
+            self.register_buffer("bias", None)
+        self.act_quant_name = act_quant
+        self.act_quant = _act_quantizer(act_quant, activation_fp_quant, act_fp_type, a_bit, self._FC2)
+        if quantize_output:
+            self.output_quant_name = self.act_quant_name
+            self.output_quant = self.act_quant
+        else:
+            self.output_quant_name = "None"
+            self.output_quant = lambda x: x
+        self.weight_quant_name = None
+
+    def to(self, *args, **kwargs):
+        super().to(*args, **kwargs)
+        self.weight = self.weight.to(*args, **kwargs)
+        if self.bias is not None:
+            self.bias = self.bias.to(*args, **kwargs)
+        return self
+
+    @torch.no_grad()
+    def forward(self, x):
+        q_x = self.act_quant(x)
+        y = torch.functional.F.linear(q_x, self.weight, self.bias)
+        return self.output_quant(y)
+
+    @classmethod
+    def from_float(cls, module, weight_quant="per_channel", act_quant="per_token", quantize_output=False,
+                   w_bit=8, a_bit=8, act_quant_sym=None, fc2_act_log2_quant=False, activation_fp_quant=False,
+                   weight_fp_quant=False, act_fp_type=None, weight_fp_type=None):
+        assert isinstance(module, torch.nn.Linear)
+        new = cls(module.in_features, module.out_features, module.bias is not None, act_quant=act_quant,
+                  quantize_output=quantize_output, w_bit=w_bit, a_bit=a_bit, act_quant_sym=act_quant_sym,
+                  fc2_act_log2_quant=fc2_act_log2_quant, activation_fp_quant=activation_fp_quant,
+                  weight_fp_quant=weight_fp_quant, act_fp_type=act_fp_type, weight_fp_type=weight_fp_type)
+        new.weight = _quantize_weight(module.weight.detach(), weight_quant, weight_fp_quant, weight_fp_type, w_bit)
+        new.weight_quant_name = weight_quant
+        if module.bias is not None:
+            new.bias = module.bias
+        return new
+
+    def __repr__(self):
+        return (f"{type(self).__name__}{self.in_features}, {self.out_features}, bias={self.bias is not None}, "
+                f"weight_quant={self.weight_quant_name}, act_quant={self.act_quant_name}, "
+                f"output_quant={self.output_quant_name}, w_bit={self.w_bit}, a_bit={self.a_bit}, "
+                f"act_quant_sym={self.act_quant_sym}, act_log2_quant={self.fc2_act_log2_quant},"
+                f"activation_fp_quant={self.activation_fp_quant}, weight_fp_quant={self.weight_fp_quant}, "
+                f"activation_quant_type={self.act_fp_type}")
+
+
+class QuantizedLinear_fc2(QuantizedLinear):
+    """The fc2 variant accepts the asymmetric dual formats for its (post-GELU) input
+    (tr/quant_utils.py:917-973)."""
+    _FC2 = True
+
+
+def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=False, w_bit=8, a_bit=8, kv_bit=8,
+                 act_quant_sym=None, fc2_act_log2_quant=None, quant_kv=None, activation_fp_quant=False,
+                 weight_fp_quant=False, act_fp_type=None, weight_fp_type=None, fc2_fp_type=None):
+    """tr/quant_utils.py:1095-1167.  The reference matches its own FFN / SelfAttention
+    classes; here a module with Linear children ``fc1``+``fc2`` is an FFN and one with
+    ``mat_qkv``+``proj`` is a self-attention block.  As in the reference,
+    ``quantize_bmm_input``, ``kv_bit`` and ``quant_kv`` are accepted and ignored, the
+    ada_lin Linears stay in full precision, and fc2's input format is ``fc2_fp_type``."""
+    common = dict(weight_quant=weight_quant, act_quant=act_quant, w_bit=w_bit, a_bit=a_bit,
+                  activation_fp_quant=activation_fp_quant, weight_fp_quant=weight_fp_quant,
+                  weight_fp_type=weight_fp_type)
+    for _, m in list(model.named_modules()):
+        fc1, fc2 = getattr(m, "fc1", None), getattr(m, "fc2", None)
+        qkv, proj = getattr(m, "mat_qkv", None), getattr(m, "proj", None)
+        if isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear):
+            m.fc1 = QuantizedLinear.from_float(fc1, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+            m.fc2 = QuantizedLinear_fc2.from_float(fc2, act_quant_sym=False, fc2_act_log2_quant=fc2_act_log2_quant,
+                                                   act_fp_type=fc2_fp_type, **common)
+        elif isinstance(qkv, nn.Linear) and isinstance(proj, nn.Linear):
+            m.mat_qkv = QuantizedLinear.from_float(qkv, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+            m.proj = QuantizedLinear.from_float(proj, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+    return model

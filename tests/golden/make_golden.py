@@ -168,6 +168,58 @@ def main():
     scale = x.abs().max() / grid.abs().max()
     out["out/per_tensor_argmin/e2m1"] = bits(qu.quantize_to_nearest_grid(x / scale, grid) * scale)
 
+    # ---- 3b. QuantizedLinear / QuantizedLinear_fc2 / quantize_VAR through the reference classes --
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(5)
+            self.ffn = bv.FFN(in_features=128, hidden_features=256, fused_if_available=False)
+            self.attn = bv.SelfAttention(block_idx=0, embed_dim=128, num_heads=2, flash_if_available=False)
+
+    run_cfgs = {
+        # README.md:33 / run.sh:4  (W4A4)
+        "w4a4": dict(weight_quant="per_group", act_quant="per_group", w_bit=4, a_bit=4, act_quant_sym=True,
+                     activation_fp_quant=True, weight_fp_quant=True, act_fp_type="fp_e2", weight_fp_type="fp_e2",
+                     fc2_fp_type="fp_e1m2_neg_e2m1_pos"),
+        # run.sh:7 (W6A6)
+        "w6a6": dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True,
+                     activation_fp_quant=True, weight_fp_quant=True, act_fp_type="fp6_e2m3",
+                     weight_fp_type="fp6_e2m3", fc2_fp_type="fp6_int_neg_e2m3_pos"),
+        # per_channel / per_token FP4: the pure-torch (argmin) functions even for "GPU" runs
+        "w4a4_tok": dict(weight_quant="per_channel", act_quant="per_token", w_bit=4, a_bit=4, act_quant_sym=True,
+                         activation_fp_quant=True, weight_fp_quant=True, act_fp_type="fp_e2",
+                         weight_fp_type="fp_e2", fc2_fp_type="fp_e3"),
+    }
+    gx = torch.Generator().manual_seed(77)
+    xin = torch.randn(6, 128, generator=gx)
+    hid = torch.nn.functional.gelu(torch.randn(6, 256, generator=gx) * 1.5, approximate="tanh")
+    out["ql/x_f32"] = bits(xin)
+    out["ql/h_f32"] = bits(hid)
+    toy0 = Toy()
+    for lname in ("ffn.fc1", "ffn.fc2", "attn.mat_qkv", "attn.proj"):
+        mod = dict(toy0.named_modules())[lname]
+        out[f"ql/w0/{lname}"] = bits(mod.weight.detach())
+        if mod.bias is not None:
+            out[f"ql/b0/{lname}"] = bits(mod.bias.detach())
+    for cname, cfg in run_cfgs.items():
+        toy = Toy()
+        qu.quantize_VAR(toy, **cfg)
+        for lname in ("ffn.fc1", "ffn.fc2", "attn.mat_qkv", "attn.proj"):
+            mod = dict(toy.named_modules())[lname]
+            out[f"ql/{cname}/weight/{lname}"] = bits(mod.weight.detach())
+            out[f"ql/{cname}/class/{lname}"] = np.array(type(mod).__name__)
+            src = hid if lname == "ffn.fc2" else xin
+            for dtype, dn in ((torch.float16, "f16"), (torch.float32, "f32")):
+                out[f"ql/{cname}/act/{lname}/{dn}"] = bits(mod.act_quant(src.to(dtype).clone()))
+            # forward as the driver runs it: module cast to half, fp16 input (CPU fp16 linear here;
+            # only compared approximately, GEMM accumulation order is not a contract)
+            mod.weight = mod.weight.half()
+            if mod.bias is not None:
+                mod.bias = torch.nn.Parameter(mod.bias.detach().half(), requires_grad=False)
+            with torch.autocast('cpu', dtype=torch.float16):   # the driver runs generation under fp16 autocast
+                y = mod.forward(src.half().clone())
+            out[f"ql/{cname}/fwd_f32/{lname}"] = bits(y.float())
+
     # ---- 4. rotation pieces ----------------------------------------------------------
     q128 = hu.random_hadamard_matrix(128, "cpu", 42)            # fp64
     out["rot/q128_f64"] = q128.numpy().copy()

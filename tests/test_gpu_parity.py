@@ -386,3 +386,74 @@ def test_argmin_path_vs_oracle(dev, qu, dtype):
 def ops_argmin(dev, row, name):
     from fpqvar_amd import ops
     return ops.quant_rows_argmin(row.to(dev), name, row.shape[-1], clamp3=False)
+
+
+# ------------------------------------------------------------------ QuantizedLinear / quantize_VAR mirror
+RUN_CFGS = {
+    "w4a4": dict(weight_quant="per_group", act_quant="per_group", w_bit=4, a_bit=4, act_quant_sym=True,
+                 activation_fp_quant=True, weight_fp_quant=True, act_fp_type="fp_e2", weight_fp_type="fp_e2",
+                 fc2_fp_type="fp_e1m2_neg_e2m1_pos"),
+    "w6a6": dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True,
+                 activation_fp_quant=True, weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3",
+                 fc2_fp_type="fp6_int_neg_e2m3_pos"),
+    "w4a4_tok": dict(weight_quant="per_channel", act_quant="per_token", w_bit=4, a_bit=4, act_quant_sym=True,
+                     activation_fp_quant=True, weight_fp_quant=True, act_fp_type="fp_e2", weight_fp_type="fp_e2",
+                     fc2_fp_type="fp_e3"),
+}
+
+
+class _FFN(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(128, 256)
+        self.fc2 = torch.nn.Linear(256, 128)
+
+
+class _Attn(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mat_qkv = torch.nn.Linear(128, 384, bias=False)
+        self.proj = torch.nn.Linear(128, 128)
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.ffn = _FFN()
+        self.attn = _Attn()
+
+
+@pytest.mark.parametrize("cname", list(RUN_CFGS))
+def test_quantize_var_mirror(dev, golden, cname):
+    from fpqvar_amd.quant_linear import QuantizedLinear, QuantizedLinear_fc2, quantize_VAR
+    toy = _Toy()
+    names = ("ffn.fc1", "ffn.fc2", "attn.mat_qkv", "attn.proj")
+    mods = dict(toy.named_modules())
+    with torch.no_grad():
+        for n in names:
+            mods[n].weight.copy_(from_bits(golden[f"ql/w0/{n}"]))
+            if mods[n].bias is not None:
+                mods[n].bias.copy_(from_bits(golden[f"ql/b0/{n}"]))
+    toy = toy.to(dev)
+    quantize_VAR(toy, **RUN_CFGS[cname])
+    mods = dict(toy.named_modules())
+    x = from_bits(golden["ql/x_f32"]).to(dev)
+    h = from_bits(golden["ql/h_f32"]).to(dev)
+    for n in names:
+        m = mods[n]
+        assert type(m).__name__ == str(golden[f"ql/{cname}/class/{n}"])
+        assert isinstance(m, QuantizedLinear_fc2 if n == "ffn.fc2" else QuantizedLinear)
+        assert_bits_equal(m.weight, from_bits(golden[f"ql/{cname}/weight/{n}"]), f"{cname} weight {n}")
+        src = h if n == "ffn.fc2" else x
+        for dt, dn in ((torch.float16, "f16"), (torch.float32, "f32")):
+            assert_bits_equal(m.act_quant(src.to(dt)), from_bits(golden[f"ql/{cname}/act/{n}/{dn}"]),
+                              f"{cname} act {n} {dn}")
+        # forward as the driver runs it (fp16 module under fp16 autocast); GEMM order is not a contract
+        m.weight = m.weight.half()
+        if m.bias is not None:
+            m.bias = torch.nn.Parameter(m.bias.detach().half(), requires_grad=False)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = m(src.half())
+        want = from_bits(golden[f"ql/{cname}/fwd_f32/{n}"])
+        assert y.dtype == torch.float16
+        torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=2e-2)
