@@ -336,3 +336,142 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
     }
   }
 }
+
+// ---------------------------------------------------------------------------------
+// F1: the online rotate fused in front of the per-group quant.
+//
+// Reference (tr/basic_var.py:263,266 under the driver's fp16 autocast):
+//     x1 = matmul(half(producer * s), half(Q))            fp16 GEMM, fp32 accumulation
+//     q  = fp_quant_*_per_group_cuda(x1, 4, 128)
+// with Q block-diagonal, every 128x128 block = diag(D) . H128 / sqrt(128)
+// (rotate_utils/rotation_utils.py:69-104, hadamard_utils.py:63-99), so per 128-chunk
+//     x1 = half( c_h * FWHT128(h * D) ),   c_h = half(float32(1/sqrt(128))) = 0.08837890625
+// Here: h = half(x * s) (s optional), sign flip by xor, 3 butterfly stages inside the lane's
+// 8 values, 4 across the 16 lanes of the group (DPP quad_perm for lane^1, lane^2; ds_swizzle
+// for lane^4, lane^8 - no LDS memory is touched), fp32 throughout, one rounding to fp16, and
+// the result feeds the quantizer of this file without leaving registers.  A dense fp16 GEMM
+// of 2*rows*C^2 FLOPs and a 2 B/elem round trip disappear.
+//
+// Parity contract: the quant stage is bit-exact for the rotated values this kernel
+// produces (it can emit them); the rotated values are within 1 fp16 ulp of the
+// fp64-accumulated product (the reference GEMM's own summation order is unspecified).
+// ---------------------------------------------------------------------------------
+struct RotArgs {
+  const float* smooth;   // [cols] per-channel factor (GALT s) or nullptr
+  uint32_t sign[4];      // bit j set <=> D[j] = -1, j = 0..127
+  float c_h;             // (float)half(float32(1/sqrt(128)))
+  int64_t vec_per_row;   // cols / 8
+};
+
+__device__ __forceinline__ float xlane_xor4(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F));
+}
+__device__ __forceinline__ float xlane_xor8(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x201F));
+}
+__device__ __forceinline__ float xlane_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float xlane_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+// FWHT over the 128 values held by 16 lanes x 8 registers; natural (Sylvester) order
+__device__ __forceinline__ void fwht128(float (&t)[8], int lane_in_group) {
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if ((i & m) == 0) {
+        float a = t[i], b = t[i | m];
+        t[i] = a + b;
+        t[i | m] = a - b;
+      }
+    }
+  }
+  const float s1 = (lane_in_group & 1) ? -1.0f : 1.0f, s2 = (lane_in_group & 2) ? -1.0f : 1.0f;
+  const float s4 = (lane_in_group & 4) ? -1.0f : 1.0f, s8 = (lane_in_group & 8) ? -1.0f : 1.0f;
+  // partner + sign*mine: the lower lane gets a+b, the upper lane a-b (both exact as a sum of two terms)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s1, xlane_xor1(t[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s2, xlane_xor2(t[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s4, xlane_xor4(t[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s8, xlane_xor8(t[i]));
+}
+
+template <typename Tin, bool EMIT, int U>
+__global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __restrict__ xv, u32x4* __restrict__ out,
+                                                               u32x4* __restrict__ rot_out, int64_t n_vec,
+                                                               RotArgs r, Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  const int lg = threadIdx.x & 15;
+  // this lane's 8 sign bits -> xor masks on packed halves
+  const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
+  uint32_t sx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sx[k] = (((sb >> (2 * k)) & 1u) << 15) | (((sb >> (2 * k + 1)) & 1u) << 31);
+  const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  bool first = true;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t v0 = tile * ((int64_t)kBlock * U) + threadIdx.x;
+    u32x4 raw[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t v = v0 + u * kBlock;
+      live[u] = v < n_vec;
+      u32x4 w = {0, 0, 0, 0};
+      if (live[u]) {
+        if constexpr (sizeof(Tin) == 2) {
+          w = __builtin_nontemporal_load((const u32x4*)xv + v);
+          if (r.smooth) {   // h = half(float(x) * s)
+            const float* sp = r.smooth + (v % r.vec_per_row) * 8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              w[k] = f2h(h2f(w[k] & 0xFFFFu) * sp[2 * k]) | (f2h(h2f(w[k] >> 16) * sp[2 * k + 1]) << 16);
+          }
+        } else {            // fp32 producer output: h = half(x * s)
+          u32x4 lo = __builtin_nontemporal_load((const u32x4*)xv + 2 * v);
+          u32x4 hi = __builtin_nontemporal_load((const u32x4*)xv + 2 * v + 1);
+          float f[8] = {u2f(lo[0]), u2f(lo[1]), u2f(lo[2]), u2f(lo[3]), u2f(hi[0]), u2f(hi[1]), u2f(hi[2]), u2f(hi[3])};
+          if (r.smooth) {
+            const float* sp = r.smooth + (v % r.vec_per_row) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] *= sp[i];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = f2h(f[2 * k]) | (f2h(f[2 * k + 1]) << 16);
+        }
+      }
+      raw[u] = w;
+    }
+    if (first) {
+      const int n = 1 << (16 - a.shift);
+      for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+      __syncthreads();
+      first = false;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t w = raw[u][k] ^ sx[k];
+        t[2 * k] = h2f(w & 0xFFFFu);
+        t[2 * k + 1] = h2f(w >> 16);
+      }
+      fwht128(t, lg);
+      u32x4 y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = f2h(t[2 * k] * r.c_h) | (f2h(t[2 * k + 1] * r.c_h) << 16);
+      if (EMIT && live[u]) __builtin_nontemporal_store(y, rot_out + v0 + u * kBlock);
+      uint32_t m = row_max_dpp<16>(vec_absmax16(y));
+      RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      if (live[u]) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
+    }
+  }
+}

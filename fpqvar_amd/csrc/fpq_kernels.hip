@@ -785,6 +785,29 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   return FPQ_ERR_SHAPE;
 }
 
+template <typename Tin>
+int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, int64_t cols, const float* smooth,
+                        const uint32_t sign[4], int table_id, hipStream_t st) {
+  const Lut16Host& h = lut16_host(table_id, table_id);
+  if (!h.tab_valid) return FPQ_ERR_TABLE;
+  RotArgs r;
+  r.smooth = smooth;
+  for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
+  r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));   // torch.tensor(128).sqrt() is float32; autocast makes Q fp16
+  r.vec_per_row = cols / 8;
+  const int64_t n_vec = rows * (cols / 8);
+  constexpr int U = 2;
+  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  if (rot_out)
+    hipLaunchKernelGGL((rotate_quant16_kernel<Tin, true, U>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st, x,
+                       (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, h.tab);
+  else
+    hipLaunchKernelGGL((rotate_quant16_kernel<Tin, false, U>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st,
+                       x, (u32x4*)out, (u32x4*)nullptr, n_vec, r, h.args, h.tab);
+  return check_launch();
+}
+
 template <bool DUAL>
 int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id,
                         hipStream_t st) {
@@ -936,6 +959,22 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   dual.clip_absmax = clip_absmax;
   dual.clip_strength = clip_strength;
   return dispatch_rows<true>(x, out, rows, cols, in_dtype, out_dtype, dual.fneg, dual, (hipStream_t)stream);
+}
+
+int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols, int in_dtype,
+                          const float* smooth, const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0 || !sign_mask_host) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (cols % 128 != 0) return FPQ_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)rotated_out | (uintptr_t)smooth) & 15) != 0) return FPQ_ERR_ARG;
+  if (in_dtype == FPQ_F16)
+    return launch_rotate_quant<_Float16>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
+                                         (hipStream_t)stream);
+  return launch_rotate_quant<float>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
+                                    (hipStream_t)stream);
 }
 
 int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream) {

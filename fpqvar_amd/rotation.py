@@ -1,0 +1,98 @@
+"""Randomized-Hadamard rotation pieces (reference: rotate_utils/hadamard_utils.py:63-99,
+rotate_utils/rotation_utils.py:69-104) and the fused online rotate + quant op.
+
+The reference builds a dense block-diagonal Q (15 or 18 identical 128x128 blocks
+``diag(D) . H128 / sqrt(128)``, D = +-1 drawn with ``torch.manual_seed(42)``) and
+multiplies activations by it with a dense fp16 GEMM on every forward
+(tr/basic_var.py:263,266).  Here Q exists only for the offline weight side and for
+tests; online, ``rotate_quant`` runs the 128-point butterfly inside the quant kernel.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import TABLE_IDS, check, dtype_id, lib, require_gpu, stream_ptr
+
+
+def sign_vector(size: int = 128, seed: int = 42) -> torch.Tensor:
+    """D of random_hadamard_matrix(size, device, seed): ``torch.manual_seed(seed);
+    randint(0, 2, (size,)) * 2 - 1`` on the CPU generator (hadamard_utils.py:92-99),
+    drawn from a private generator so the global RNG state is left alone."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randint(low=0, high=2, size=(size,), generator=g).to(torch.float64) * 2 - 1
+
+
+def sylvester(n: int) -> torch.Tensor:
+    assert n & (n - 1) == 0, "only power-of-two Hadamard sizes (the reference's block_rotate uses 128)"
+    h = torch.ones(1, 1, dtype=torch.float64)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return h
+
+
+def random_hadamard_matrix(size: int, device, seed: int) -> torch.Tensor:
+    """diag(D) . H_size / float32(sqrt(size)) in float64 (hadamard_utils.py:63-99)."""
+    d = sign_vector(size, seed)
+    return ((d[:, None] * sylvester(size)) / torch.tensor(size).sqrt()).to(device)
+
+
+def block_random_hadamard_matrix(total_size: int = 1920, block_size: int = 128, device="cuda", seed: int = 42
+                                 ) -> torch.Tensor:
+    """Block-diagonal Q with IDENTICAL blocks (every block re-seeds with `seed`,
+    rotation_utils.py:69-104)."""
+    assert total_size % block_size == 0
+    q = random_hadamard_matrix(block_size, device, seed)
+    return torch.block_diag(*([q] * (total_size // block_size)))
+
+
+def sign_mask(d: torch.Tensor) -> Tuple[int, int, int, int]:
+    """128 signs -> 4 x uint32, bit j set <=> d[j] == -1."""
+    assert d.numel() == 128
+    bits = (d.reshape(-1) < 0).to(torch.int64).tolist()
+    return tuple(sum(b << k for k, b in enumerate(bits[32 * w:32 * w + 32])) for w in range(4))
+
+
+def rotate_weight(w: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    """Offline weight side: W <- W . Q in float64, back to W's dtype (rotation_utils.py:129-154)."""
+    return (w.to(torch.float64) @ q.to(w.device, torch.float64)).to(w.dtype)
+
+
+def transform_weight(w: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """GALT smoothing, weight side: W <- W / s per input channel (transform_model_utils.py:8-28)."""
+    return w / s.to(w.device)
+
+
+def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor] = None,
+                 smooth: Optional[torch.Tensor] = None, return_rotated: bool = False):
+    """out = fp_quant_*_per_group_cuda( half(x*smooth) @ half(Q_block) , 128 ) in one launch.
+
+    x: [..., C] fp16 or fp32 on the GPU, C % 128 == 0.  Returns fp16 (and the rotated
+    fp16 tensor when return_rotated)."""
+    require_gpu(x, "rotate_quant")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"rotate_quant: x must be float16 or float32, got {x.dtype}")
+    c = x.shape[-1]
+    if c % 128 != 0:
+        raise RuntimeError("rotate_quant: the last dimension must be a multiple of 128")
+    d = sign_vector(128, 42) if d is None else d
+    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    xc = x if x.is_contiguous() else x.contiguous()
+    sm_ptr = None
+    if smooth is not None:
+        sm = smooth.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if sm.numel() == 1:
+            sm = sm.expand(c).contiguous()
+        if sm.numel() != c:
+            raise RuntimeError("rotate_quant: smooth must have one entry per channel")
+        sm_ptr = sm.data_ptr()
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    rot = torch.empty_like(out) if return_rotated else None
+    with torch.cuda.device(x.device):
+        check(lib().fpq_rotate_quant_rows(xc.data_ptr(), out.data_ptr(), rot.data_ptr() if rot is not None else None,
+                                          x.numel() // c, c, dtype_id(x.dtype), sm_ptr, mask, TABLE_IDS[table],
+                                          stream_ptr(x.device)), "fpq_rotate_quant_rows")
+    return (out, rot) if return_rotated else out

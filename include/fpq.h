@@ -126,6 +126,23 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
                         int pos_table, int in_dtype, int out_dtype, const void* clip_absmax,
                         float clip_strength, fpq_stream_t stream);
 
+/* Online rotate fused in front of the per-group(128) quantizer.
+ * Replaces, for the block-diagonal randomized-Hadamard rotation
+ * (rotate_utils/rotation_utils.py:69-104: every 128x128 block = diag(D).H128/sqrt(128)),
+ *     x1 = torch.matmul(producer.mul(s), Q)            tr/basic_var.py:263,266 (fp16 autocast)
+ *     q  = fp_quant_e{1,2,3}_per_group_cuda(x1, 4, 128) / fp6_quant_*_per_group_cuda
+ * by one launch:  h = half(x * s);  y = half(c_h * FWHT128(h * D));  out = quant(y).
+ * x: [rows, cols] F16 or F32 (the producer's output), cols % 128 == 0;
+ * smooth: device float[cols] (the GALT factor s of this block) or NULL;
+ * sign_mask_host: HOST pointer to 4 x uint32, bit j set <=> D[j] == -1 (seed-42 vector);
+ * out: fp16 [rows, cols]; rotated_out: NULL, or fp16 [rows, cols] receiving y.
+ * Parity: out == fpq_quant_rows(y) bit for bit; y is within 1 fp16 ulp of the
+ * fp64-accumulated half(x*s) @ half(Q) (the reference GEMM's summation order is
+ * unspecified).  All pointers 16-byte aligned. */
+int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols,
+                          int in_dtype, const float* smooth, const uint32_t* sign_mask_host, int table_id,
+                          fpq_stream_t stream);
+
 /* max|x| over n elements (NaN-propagating, like torch's x.abs().max()), written
  * as ONE scalar of `dtype` to `out`.  `out` must hold 4 bytes; it is zeroed on the
  * stream first (hipMemsetAsync) and then combined with device atomics. */

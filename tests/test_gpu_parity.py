@@ -457,3 +457,45 @@ def test_quantize_var_mirror(dev, golden, cname):
         want = from_bits(golden[f"ql/{cname}/fwd_f32/{n}"])
         assert y.dtype == torch.float16
         torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=2e-2)
+
+
+# ------------------------------------------------------------------ F1: fused rotate + quant
+def _ulp_diff_f16(a, b):
+    ai = a.view(torch.int16).to(torch.int32)
+    bi = b.view(torch.int16).to(torch.int32)
+    ai = torch.where(ai < 0, -(ai & 0x7FFF), ai)
+    bi = torch.where(bi < 0, -(bi & 0x7FFF), bi)
+    return (ai - bi).abs()
+
+
+@pytest.mark.parametrize("in_dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("with_smooth", (False, True))
+def test_rotate_quant_fused(dev, in_dtype, with_smooth):
+    from fpqvar_amd import rotation as rot
+    g = torch.Generator().manual_seed(55)
+    x = (torch.randn(300, 1920, generator=g) * torch.exp(0.5 * torch.randn(300, 1920, generator=g))).to(in_dtype)
+    x[7, 128:256] = 0
+    s = (torch.rand(1920, generator=g) * 1.5 + 0.25) if with_smooth else None
+    out, y = rot.rotate_quant(x.to(dev), "e2m1", smooth=s, return_rotated=True)
+    out2 = rot.rotate_quant(x.to(dev), "e2m1", smooth=s)
+    assert_bits_equal(out2, out, "emit vs no-emit")
+    # (1) rotated values: within 1 fp16 ulp of the fp64-accumulated half(x*s) @ half(Q)
+    h = (x.float() * s).half() if with_smooth else x.half()
+    q_h = rot.block_random_hadamard_matrix(1920, 128, "cpu", 42).float().half()
+    y_ref = orc.rotate_fp16_reference(h, q_h)
+    d = _ulp_diff_f16(y.cpu(), y_ref)
+    assert int(d.max()) <= 1, f"rotated value off by {int(d.max())} ulp"
+    assert float((d > 0).float().mean()) < 0.01
+    # (2) the quant stage is bit-exact on the rotated values the kernel produced
+    assert_bits_equal(out, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "quant of rotated")
+    # (3) against the reference's op sequence on this GPU (fp16 GEMM under autocast + quant)
+    import fpqvar_amd.quant_utils as qu
+    with torch.autocast("cuda", dtype=torch.float16):
+        x1 = torch.matmul(h.to(dev), rot.block_random_hadamard_matrix(1920, 128, dev, 42).float())
+    ref = qu.fp_quant_e2_per_group_cuda(x1, 4, 128)
+    agree = float((ref.view(torch.int16) == out.view(torch.int16)).float().mean())
+    assert agree > 0.97, f"only {agree:.4f} of the outputs agree with matmul+quant"
+    # other tables go through the same kernel
+    o3, y3 = rot.rotate_quant(x.to(dev), "e2m3", smooth=s, return_rotated=True)
+    assert_bits_equal(o3, orc.per_group_kernel_sem(y3.cpu(), "e2m3", 128, out_dtype=torch.float16), "e2m3 after rotate")
+    assert_bits_equal(y3, y, "rotation independent of the table")

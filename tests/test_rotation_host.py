@@ -1,0 +1,41 @@
+"""CPU-only: the rotation pieces of fpqvar_amd.rotation against the vectors produced by the
+reference's hadamard_utils / rotation_utils (tests/golden/make_golden.py)."""
+import torch
+
+from fpqvar_amd import rotation as rot
+from oracle import fpq_oracle as orc
+
+
+def test_q128_equals_reference(golden):
+    q_ref = torch.from_numpy(golden["rot/q128_f64"])
+    assert torch.equal(rot.random_hadamard_matrix(128, "cpu", 42), q_ref)
+    qb = rot.block_random_hadamard_matrix(1920, 128, "cpu", 42)
+    assert qb.shape == (1920, 1920)
+    for i in (0, 7, 14):
+        assert torch.equal(qb[i * 128:(i + 1) * 128, i * 128:(i + 1) * 128], q_ref)
+    assert float(qb[:128, 128:].abs().max()) == 0.0
+    assert bool(golden["rot/blocks_identical_1920"])
+
+
+def test_sign_mask_roundtrip():
+    d = rot.sign_vector(128, 42)
+    assert torch.equal(d, orc.sign_vector(128, 42))
+    before = torch.get_rng_state()
+    rot.sign_vector(128, 42)
+    assert torch.equal(before, torch.get_rng_state())        # global RNG untouched
+    m = rot.sign_mask(d)
+    back = torch.tensor([-1.0 if (m[j // 32] >> (j % 32)) & 1 else 1.0 for j in range(128)], dtype=torch.float64)
+    assert torch.equal(back, d)
+    assert d[:16].tolist() == [-1, 1, -1, -1, -1, 1, -1, -1, -1, 1, -1, -1, -1, -1, 1, -1]
+
+
+def test_weight_side_helpers():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 256, generator=g)
+    q = rot.block_random_hadamard_matrix(256, 128, "cpu", 42)
+    wr = rot.rotate_weight(w, q)
+    assert wr.dtype == w.dtype
+    # Q is orthogonal up to the float32 sqrt: (W Q) Q^T ~ W
+    torch.testing.assert_close(rot.rotate_weight(wr, q.t()), w, rtol=1e-5, atol=1e-5)
+    s = torch.rand(256, generator=g) + 0.5
+    assert torch.equal(rot.transform_weight(w, s), w / s)
