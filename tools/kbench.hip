@@ -177,6 +177,8 @@ int main(int argc, char** argv) {
   add("fast e2m3 token7680", [&] { fpq_quant_rows(X(), O(), n / 7680, 7680, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
   add("fast dualfp6 tok7680", [&] { fpq_quant_rows_dual(X(), O(), n / 7680, 7680, FPQ_INT_NEG, FPQ_E2M3_POS, FPQ_F16, FPQ_F16, nullptr, 1.f, st); });
   add("generic e2m3 tok1920", [&] { fpq_quant_rows_generic(X(), O(), n / 1920, 1920, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
+  static const uint32_t kSign[4] = {0x5a5ac3c3u, 0x0ff0a55au, 0x12345678u, 0x9abcdef0u};
+  add("rotate+quant e2m1 f16", [&] { fpq_rotate_quant_rows(X(), O(), nullptr, n / 1920, 1920, FPQ_F16, nullptr, kSign, FPQ_E2M1, st); });
   add("generic e2m1 g128", [&] { fpq_quant_rows_generic(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_F16, FPQ_F16, st); });
   add("fast e2m1 g128", [&] { fpq_quant_rows(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_F16, FPQ_F16, st); });
   add("fast e2m3 g128", [&] { fpq_quant_rows(X(), O(), n / 128, 128, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
