@@ -292,8 +292,10 @@ __global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __res
                                                              void* __restrict__ outv, int64_t n_vec,
                                                              Fmt fs, DualArgs dual) {
   constexpr int V = DT<Tin>::kVec;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t v0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // a workgroup owns contiguous tiles of kBlock*UNROLL vectors, dispatched in address order
+  constexpr int64_t stride = kBlock;
+  const int64_t tile_vecs = (int64_t)kBlock * UNROLL;
+  const int64_t tiles = (n_vec + tile_vecs - 1) / tile_vecs;
   float clip = fs.preclamp;
   bool clip_nan = false;
   const bool has_clip = DUAL ? (dual.clip_absmax != nullptr) : (fs.preclamp > 0.0f);
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __res
 
   // n_vec is a multiple of LPR (whole rows) and LPR divides 64, so a row never
   // straddles the `live` boundary inside a wavefront.
-  for (; v0 < n_vec; v0 += stride * UNROLL) {
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t v0 = tile * tile_vecs + threadIdx.x;
     u32x4 raw[UNROLL];
     bool live[UNROLL];
 #pragma unroll
@@ -658,11 +661,11 @@ int launch_rows(const void* x, void* out, int64_t rows, int64_t cols, const Fmt&
   if (aligned && cols % V == 0) {
     const int64_t n_vec = rows * (cols / V);
     const int lpr = (int)(cols / V);
-    constexpr int U = 4;
+    constexpr int U = 2;
     auto go = [&](auto kern) {
       int64_t blocks = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
-      hipLaunchKernelGGL(kern, dim3(grid_for(blocks)), dim3(kBlock), 0, st, (const u32x4*)x, out, n_vec, fs,
-                         dual);
+      hipLaunchKernelGGL(kern, dim3(grid_for(blocks, 1 << 20)), dim3(kBlock), 0, st, (const u32x4*)x, out, n_vec,
+                         fs, dual);
       return check_launch();
     };
     if (row_bytes <= 1024 && (lpr & (lpr - 1)) == 0) {

@@ -177,6 +177,11 @@ int main(int argc, char** argv) {
   add("fast e2m3 token7680", [&] { fpq_quant_rows(X(), O(), n / 7680, 7680, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
   add("fast dualfp6 tok7680", [&] { fpq_quant_rows_dual(X(), O(), n / 7680, 7680, FPQ_INT_NEG, FPQ_E2M3_POS, FPQ_F16, FPQ_F16, nullptr, 1.f, st); });
   add("generic e2m3 tok1920", [&] { fpq_quant_rows_generic(X(), O(), n / 1920, 1920, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
+  // fp32 weights path: the same buffers seen as n/2 floats (bit patterns of two random halves = wild floats,
+  // fine for timing; correctness of this path is covered by the pytest suite)
+  auto add32 = [&](std::string name, std::function<void()> f) { vs.push_back({name + " [8B/el]", f, {}}); };
+  add32("generic f32 e2m1 g128", [&] { DualArgs d = {}; dispatch_rows<false>(X(), O(), n / 2 / 128, 128, FPQ_F32, FPQ_F32, make_fmt(FPQ_E2M1), d, st); });
+  add32("generic f32->f16 e2m3 row1920", [&] { DualArgs d = {}; dispatch_rows<false>(X(), O(), n / 2 / 1920, 1920, FPQ_F32, FPQ_F16, make_fmt(FPQ_E2M3), d, st); });
   static const uint32_t kSign[4] = {0x5a5ac3c3u, 0x0ff0a55au, 0x12345678u, 0x9abcdef0u};
   add("rotate+quant e2m1 f16", [&] { fpq_rotate_quant_rows(X(), O(), nullptr, n / 1920, 1920, FPQ_F16, nullptr, kSign, FPQ_E2M1, st); });
   add("generic e2m1 g128", [&] { fpq_quant_rows_generic(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_F16, FPQ_F16, st); });
@@ -201,7 +206,9 @@ int main(int argc, char** argv) {
   for (auto& v : vs) {
     std::sort(v.ms.begin(), v.ms.end());
     float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
-    double gbs = (double)n * 4 / (med * 1e-3) / 1e9;
+    double bytes = (v.name.find("[8B/el]") != std::string::npos) ? (double)n / 2 * 8 : (double)n * 4;
+    if (v.name.find("f32->f16") != std::string::npos) bytes = (double)n / 2 * 6;
+    double gbs = bytes / (med * 1e-3) / 1e9;
     printf("%-24s %10.1f %10.1f %10.0f %8.3f\n", v.name.c_str(), med * 1e3, mn * 1e3, gbs, gbs / 8000.0);
   }
   printf("\nbad=%d\n", bad_total);
