@@ -1,0 +1,78 @@
+"""Per-layer format search inner loop (reference: search/search_fp6_format.py:584-608,
+827-846 and its FP4 twin search/search_fp4_format.py): for every (weight format,
+activation format) pair accumulate  mean((x_j W^T - q_a(x_j) q_w(W)^T)^2)  over the
+calibration activations x_j and keep the argmin.  The quantizers are this package's
+fused kernels; the two GEMMs are plain library calls.  Blocks are independent, so the
+search shards by block over the ranks of a process group and ends with one tiny
+all-gather of (loss, w_fmt, a_fmt) per block.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import quant_utils as qu
+
+# the reference's candidate sets
+FP6_FORMATS = ("fp6_e2m3", "fp6_e3m2")                 # per-token quantizers (search_fp6_format.py:513-554)
+FP4_FORMATS = ("fp_e1", "fp_e2", "fp_e3")              # per-group-128 quantizers (search_fp4_format.py:484-553)
+
+
+def quantizer(fmt: str) -> Callable[[torch.Tensor], torch.Tensor]:
+    table = {
+        "fp6_e2m3": lambda t: qu.fp6_quant_e2m3_per_token_cuda(t, 6),
+        "fp6_e3m2": lambda t: qu.fp6_quant_e3m2_per_token_cuda(t, 6),
+        "fp_e1": lambda t: qu.fp_quant_e1_per_group_cuda(t, 4, 128),
+        "fp_e2": lambda t: qu.fp_quant_e2_per_group_cuda(t, 4, 128),
+        "fp_e3": lambda t: qu.fp_quant_e3_per_group_cuda(t, 4, 128),
+    }
+    return table[fmt]
+
+
+@torch.no_grad()
+def search_layer(xs: Sequence[torch.Tensor], w: torch.Tensor, formats: Sequence[str] = FP6_FORMATS,
+                 quant: Callable[[str], Callable] = quantizer) -> Tuple[str, str, Dict[Tuple[str, str], float]]:
+    """(best weight format, best activation format, {(w_fmt, a_fmt): summed MSE})."""
+    losses: Dict[Tuple[str, str], float] = {}
+    refs = [x.to(w.dtype) @ w.t() for x in xs]
+    for wf in formats:
+        wq = quant(wf)(w).to(w.dtype)
+        for af in formats:
+            qa = quant(af)
+            total = torch.zeros((), dtype=torch.float32, device=w.device)
+            for x, ref in zip(xs, refs):
+                y = qa(x).to(w.dtype) @ wq.t()
+                total += torch.mean((ref.float() - y.float()) ** 2)
+            losses[(wf, af)] = float(total)
+    best = min(losses, key=lambda k: (losses[k], formats.index(k[0]), formats.index(k[1])))
+    return best[0], best[1], losses
+
+
+def search_blocks_sharded(n_blocks: int, evaluate: Callable[[int], Tuple[str, str, float]],
+                          formats: Sequence[str] = FP6_FORMATS, group=None) -> List[Tuple[str, str, float]]:
+    """Block b is evaluated on rank b % world; every rank gets all results.
+    `evaluate(b)` returns (w_fmt, a_fmt, loss).  The collective is one all-gather of
+    n_blocks x (loss, w index, a index) float32 triples."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    per_rank = (n_blocks + world - 1) // world
+    buf = torch.full((per_rank, 3), -1.0, dtype=torch.float32)
+    for slot, b in enumerate(range(rank, n_blocks, world)):
+        wf, af, loss = evaluate(b)
+        buf[slot] = torch.tensor([loss, formats.index(wf), formats.index(af)], dtype=torch.float32)
+    if world == 1:
+        gathered = [buf]
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else buf.device
+        send = buf.to(dev)
+        gathered = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(gathered, send, group=group)
+        gathered = [g.cpu() for g in gathered]
+    out: List[Optional[Tuple[str, str, float]]] = [None] * n_blocks
+    for r in range(world):
+        for slot, b in enumerate(range(r, n_blocks, world)):
+            loss, wi, ai = gathered[r][slot].tolist()
+            out[b] = (formats[int(wi)], formats[int(ai)], loss)
+    return out  # type: ignore[return-value]

@@ -91,3 +91,37 @@ def test_single_process_no_dist():
     got = cal.calibrate_sharded(weights, quantize=_oracle_quant)
     for n, w in weights.items():
         assert torch.equal(got[n], _oracle_quant(n, w))
+
+
+# ---- format search sharded by block: tiny all-gather of (loss, w_fmt, a_fmt) -----------------
+def _search_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fpqvar_amd import format_search as fs
+        seen = []
+
+        def evaluate(b):
+            seen.append(b)
+            return fs.FP6_FORMATS[b % 2], fs.FP6_FORMATS[(b // 2) % 2], 0.5 + b
+
+        res = fs.search_blocks_sharded(7, evaluate)
+        want = [(fs.FP6_FORMATS[b % 2], fs.FP6_FORMATS[(b // 2) % 2], 0.5 + b) for b in range(7)]
+        q.put((rank, res == want and seen == list(range(rank, 7, world))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_format_search_sharded_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_search_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]

@@ -499,3 +499,54 @@ def test_rotate_quant_fused(dev, in_dtype, with_smooth):
     o3, y3 = rot.rotate_quant(x.to(dev), "e2m3", smooth=s, return_rotated=True)
     assert_bits_equal(o3, orc.per_group_kernel_sem(y3.cpu(), "e2m3", 128, out_dtype=torch.float16), "e2m3 after rotate")
     assert_bits_equal(y3, y, "rotation independent of the table")
+
+
+# ------------------------------------------------------------------ KV cache step and format search
+def test_kv_cache_step(dev):
+    from fpqvar_amd import kv_cache as kv
+    g = torch.Generator().manual_seed(61)
+    B, H, c = 4, 30, 64
+    ck = torch.randn(B, 5, H, c, generator=g).half()      # BLHc (flash layout, tr/basic_var.py:173)
+    cv = torch.randn(B, 5, H, c, generator=g).half()
+    k = torch.randn(B, 4, H, c, generator=g).half()
+    v = torch.randn(B, 4, H, c, generator=g).half()
+    for bit, want_fn in ((6, lambda t: orc.per_token_kernel_sem(t, "e2m3")),
+                         (4, lambda t: orc.per_group_kernel_sem(t, "e2m1", 128))):
+        nk, nv = kv.update_kv_cache(ck.to(dev), cv.to(dev), k.to(dev), v.to(dev), True, bit, 1)
+        assert_bits_equal(nk, torch.cat((want_fn(ck), k), 1), f"kv k bit {bit}")
+        assert_bits_equal(nv, torch.cat((want_fn(cv), v), 1), f"kv v bit {bit}")
+    nk, nv = kv.update_kv_cache(None, None, k.to(dev), v.to(dev), True, 6, 1)
+    assert nk.data_ptr() == k.to(dev).data_ptr() or torch.equal(nk.cpu(), k)
+    with pytest.raises(RuntimeError):          # permuted (BHLc) cache + kv_bit 6 raises, as in the reference
+        kv.quantize_kv(ck.to(dev).permute(0, 2, 1, 3), 6)
+    with pytest.raises(AssertionError):
+        bad = k.clone()
+        bad[0, 0, 0, 0] = float("nan")
+        kv.update_kv_cache(ck.to(dev), cv.to(dev), bad.to(dev), v.to(dev), True, 6, 1)
+
+
+def test_format_search_layer(dev):
+    from fpqvar_amd import format_search as fs
+    g = torch.Generator().manual_seed(62)
+    w = torch.randn(256, 512, generator=g) * 0.05
+    xs = [torch.randn(2, 9, 512, generator=g) * torch.exp(torch.randn(2, 9, 512, generator=g)) for _ in range(3)]
+    wf, af, losses = fs.search_layer([x.to(dev).half() for x in xs], w.to(dev).half(), fs.FP6_FORMATS)
+    # the same loop with the oracle's quantizers in float32 on the CPU
+    tab = {"fp6_e2m3": "e2m3", "fp6_e3m2": "e3m2"}
+    want = {}
+    for a in fs.FP6_FORMATS:
+        wq = orc.per_token_kernel_sem(w.half(), tab[a]).float()
+        for b in fs.FP6_FORMATS:
+            tot = 0.0
+            for x in xs:
+                xh = x.half()
+                ref = xh.float() @ w.half().float().t()
+                y = orc.per_token_kernel_sem(xh, tab[b]).float() @ wq.t()
+                tot += float(torch.mean((ref - y) ** 2))
+            want[(a, b)] = tot
+    for key in want:
+        assert abs(losses[key] - want[key]) <= 0.05 * want[key] + 1e-6, (key, losses[key], want[key])
+    best = min(want, key=want.get)
+    assert (wf, af) == best
+    wf4, af4, l4 = fs.search_layer([x.to(dev).half() for x in xs], w.to(dev).half(), fs.FP4_FORMATS)
+    assert len(l4) == 9 and wf4 in fs.FP4_FORMATS and af4 in fs.FP4_FORMATS
