@@ -38,6 +38,7 @@ struct Lut16Args {
   float inv_gneg;      // RN32(1 / gmax) per side
   float inv_gpos;
   int shift;           // bucket width = 2^shift fp16 patterns
+  uint32_t* nan_flag;  // dual format only: nullptr, or device word OR-ed with 1 when an input is NaN
 };
 
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
@@ -137,13 +138,14 @@ __device__ __forceinline__ uint32_t vec_absmax16(const u32x4& w) {
 }
 
 // dual format: max|x| over x <= 0 and over x > 0 separately; NaN belongs to neither
-__device__ __forceinline__ void vec_absmax16_dual(const u32x4& w, uint32_t& mneg, uint32_t& mpos) {
-  uint32_t mn = 0, mp = 0;
+__device__ __forceinline__ uint32_t vec_absmax16_dual(const u32x4& w, uint32_t& mneg, uint32_t& mpos) {
+  uint32_t mn = 0, mp = 0, any_nan = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     uint32_t a = w[k] & 0x7FFF7FFFu;
     uint32_t nanm = pk_ashr_i16(pk_sub_u16(0x7C007C00u, a), 15);   // 0xFFFF where a > 0x7C00
     a &= ~nanm;
+    any_nan |= nanm;
     uint32_t sm = pk_ashr_i16(w[k], 15);                            // 0xFFFF where the sign bit is set
     mn = pk_max_u16(mn, a & sm);
     mp = pk_max_u16(mp, a & ~sm);
@@ -152,6 +154,7 @@ __device__ __forceinline__ void vec_absmax16_dual(const u32x4& w, uint32_t& mneg
   mneg = lo > hi ? lo : hi;
   lo = mp & 0xFFFFu; hi = mp >> 16;
   mpos = lo > hi ? lo : hi;
+  return any_nan;
 }
 
 struct RowScale16 {
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
       u32x4 o;
       if (DUAL) {
         uint32_t mn, mp;
-        vec_absmax16_dual(raw[u], mn, mp);
+        if (vec_absmax16_dual(raw[u], mn, mp) && a.nan_flag) atomicOr(a.nan_flag, 1u);
         mn = row_max_dpp<LPR>(mn);
         mp = row_max_dpp<LPR>(mp);
         RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) {
         uint32_t a1, b1;
-        vec_absmax16_dual(raw[c], a1, b1);
+        if (vec_absmax16_dual(raw[c], a1, b1) && a.nan_flag) atomicOr(a.nan_flag, 1u);
         mn = mn > a1 ? mn : a1;
         mp = mp > b1 ? mp : b1;
       }

@@ -272,6 +272,7 @@ struct DualArgs {
   Fmt fneg, fpos;
   const void* clip_absmax;  // device scalar or nullptr
   float clip_strength;
+  uint32_t* nan_flag;       // nullptr, or device word that is OR-ed with 1 when an input element is NaN
 };
 
 template <typename T>
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __res
   bool clip_nan = false;
   const bool has_clip = DUAL ? (dual.clip_absmax != nullptr) : (fs.preclamp > 0.0f);
   if (DUAL && has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+  bool saw_nan = false;
 
   // n_vec is a multiple of LPR (whole rows) and LPR divides 64, so a row never
   // straddles the `live` boundary inside a wavefront.
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __res
         uint32_t ab = DT<Tin>::absbits(e);
         if (DUAL) {
           uint32_t bn = (e <= 0.0f) ? ab : 0u, bp = (e > 0.0f) ? ab : 0u;
+          saw_nan |= DT<Tin>::bits_nan(ab);
           mneg = mneg > bn ? mneg : bn;
           mpos = mpos > bp ? mpos : bp;
         } else {
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __res
       }
     }
   }
+  if (DUAL && saw_nan && dual.nan_flag) atomicOr(dual.nan_flag, 1u);
 }
 
 // ---------------------------------------------------------------------------------
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(kBlock) void rows_block_kernel(const Tin* __restric
   bool clip_nan = false;
   const bool has_clip = DUAL ? (dual.clip_absmax != nullptr) : (fs.preclamp > 0.0f);
   if (DUAL && has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+  bool saw_nan = false;
 
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const u32x4* xr = (const u32x4*)(x + row * cols);
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void rows_block_kernel(const Tin* __restric
         uint32_t ab = DT<Tin>::absbits(e);
         if (DUAL) {
           uint32_t bn = (e <= 0.0f) ? ab : 0u, bp = (e > 0.0f) ? ab : 0u;
+          saw_nan |= DT<Tin>::bits_nan(ab);
           mneg = mneg > bn ? mneg : bn;
           mpos = mpos > bp ? mpos : bp;
         } else {
@@ -455,6 +461,7 @@ __global__ __launch_bounds__(kBlock) void rows_block_kernel(const Tin* __restric
     }
     for (int64_t v = (int64_t)MAXC * kBlock + threadIdx.x; v < vec_per_row; v += kBlock) emit(xr[v], v);
   }
+  if (DUAL && saw_nan && dual.nan_flag) atomicOr(dual.nan_flag, 1u);
 }
 
 // ---------------------------------------------------------------------------------
@@ -469,6 +476,7 @@ __global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restri
   bool clip_nan = false;
   const bool has_clip = DUAL ? (dual.clip_absmax != nullptr) : (fs.preclamp > 0.0f);
   if (DUAL && has_clip) clip = clip_value<Tin>(dual, &clip_nan);
+  bool saw_nan = false;
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const Tin* xr = x + row * cols;
     uint32_t mneg = 0, mpos = 0;
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restri
       uint32_t ab = DT<Tin>::absbits(e);
       if (DUAL) {
         uint32_t bn = (e <= 0.0f) ? ab : 0u, bp = (e > 0.0f) ? ab : 0u;
+        saw_nan |= DT<Tin>::bits_nan(ab);
         mneg = mneg > bn ? mneg : bn;
         mpos = mpos > bp ? mpos : bp;
       } else {
@@ -495,6 +504,7 @@ __global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restri
       store_scalar<Tout>(out + row * cols + c, p);
     }
   }
+  if (DUAL && saw_nan && dual.nan_flag) atomicOr(dual.nan_flag, 1u);
 }
 
 #include "fpq_fast16.h"
@@ -548,6 +558,19 @@ __global__ __launch_bounds__(kBlock) void nearest_builtin_kernel(const float* __
     }
     z[i] = q;
   }
+}
+
+// ---------------------------------------------------------------------------------
+// "any NaN in the tensor => the whole result is zero" (the reference's global clamp with a
+// NaN bound, tr/quant_utils.py:421-422): second launch, exits at once when the flag is clear.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void zero_if_flag_kernel(uint8_t* __restrict__ out, int64_t n_bytes,
+                                                             const uint32_t* __restrict__ flag) {
+  if (*flag == 0u) return;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t n16 = ((uintptr_t)out & 15) == 0 ? n_bytes / 16 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) ((u32x4*)out)[i] = u32x4{0, 0, 0, 0};
+  for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_bytes; i += stride) out[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------
@@ -749,6 +772,7 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
         h.args.inv_gneg = 1.0f / h.args.fneg.gmax;
         h.args.inv_gpos = 1.0f / h.args.fpos.gmax;
         h.args.shift = table_shift16(n) < table_shift16(p) ? table_shift16(n) : table_shift16(p);
+        h.args.nan_flag = nullptr;
         h.tab_valid = (1 << (16 - h.args.shift)) <= kLutArgEntries;
         for (int i = 0; i < kLutArgEntries; ++i) h.tab.e[i] = 0;
         if (h.tab_valid) lut16_build_host(h.tab.e, h.args);
@@ -763,8 +787,10 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
 // fp16 [65536x1920] = 6.45 TB/s); grid-stride with a capped grid or U = 8 lose 3-8 %.
 template <bool DUAL, int U = 2, bool NTL = true, bool NTS = true>
 int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id, hipStream_t st,
-                  int grid_cap = 1 << 20) {
+                  int grid_cap = 1 << 20, uint32_t* nan_flag = nullptr) {
   const Lut16Host& h = lut16_host(neg_id, pos_id);
+  Lut16Args args = h.args;
+  args.nan_flag = nan_flag;
   const int64_t n_vec = rows * (cols / 8);
   const int lpr = (int)(cols / 8);
   const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
@@ -772,10 +798,10 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   auto go = [&](auto kern_tab, auto kern_fill) {
     if (h.tab_valid)
       hipLaunchKernelGGL(kern_tab, dim3(grid_for(tiles, grid_cap)), dim3(kBlock), lds, st, (const u32x4*)x,
-                         (u32x4*)out, n_vec, h.args, h.tab);
+                         (u32x4*)out, n_vec, args, h.tab);
     else
       hipLaunchKernelGGL(kern_fill, dim3(grid_for(tiles, grid_cap)), dim3(kBlock), lds, st, (const u32x4*)x,
-                         (u32x4*)out, n_vec, h.args, h.tab);
+                         (u32x4*)out, n_vec, args, h.tab);
     return check_launch();
   };
 #define FPQ_FAST16_CASE(L) \
@@ -813,8 +839,10 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
 
 template <bool DUAL>
 int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id,
-                        hipStream_t st) {
+                        hipStream_t st, uint32_t* nan_flag = nullptr) {
   const Lut16Host& h = lut16_host(neg_id, pos_id);
+  Lut16Args args = h.args;
+  args.nan_flag = nan_flag;
   const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
   const int64_t vec_per_row = cols / 8;
   const int maxc = (int)((vec_per_row + kBlock - 1) / kBlock);
@@ -825,10 +853,10 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   auto go = [&](auto kern_tab, auto kern_fill) {
     if (h.tab_valid)
       hipLaunchKernelGGL(kern_tab, dim3((unsigned)grid), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out,
-                         rows, cols, rpb, h.args, h.tab);
+                         rows, cols, rpb, args, h.tab);
     else
       hipLaunchKernelGGL(kern_fill, dim3((unsigned)grid), dim3(kBlock), lds, st, (const uint16_t*)x,
-                         (uint16_t*)out, rows, cols, rpb, h.args, h.tab);
+                         (uint16_t*)out, rows, cols, rpb, args, h.tab);
     return check_launch();
   };
   if (maxc <= 1) return go(rows16_lut_block_kernel<DUAL, 1, true>, rows16_lut_block_kernel<DUAL, 1, false>);
@@ -924,6 +952,7 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
   if (fast16_block_eligible(x, out, cols, in_dtype, out_dtype))
     return launch_fast16_block<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
   DualArgs dual = {};
+  dual.nan_flag = nullptr;
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,
                               (hipStream_t)stream);
 }
@@ -939,11 +968,12 @@ int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols,
   f.argmin = 1;
   f.preclamp = clamp3 ? 3.0f : 0.0f;
   DualArgs dual = {};
+  dual.nan_flag = nullptr;
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, FPQ_F32, f, dual, (hipStream_t)stream);
 }
 
 int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table, int pos_table,
-                        int in_dtype, int out_dtype, const void* clip_absmax, float clip_strength,
+                        int in_dtype, int out_dtype, const void* clip_absmax, float clip_strength, void* nan_flag,
                         fpq_stream_t stream) {
   if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
   if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_INT_NEG) return FPQ_ERR_TABLE;
@@ -952,16 +982,28 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
     return FPQ_ERR_DTYPE;
   if (rows == 0 || cols == 0) return FPQ_OK;
   if (!x || !out) return FPQ_ERR_ARG;
-  if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype))
-    return launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, (hipStream_t)stream);
-  if (!clip_absmax && fast16_block_eligible(x, out, cols, in_dtype, out_dtype))
-    return launch_fast16_block<true>(x, out, rows, cols, neg_table, pos_table, (hipStream_t)stream);
-  DualArgs dual;
-  dual.fneg = make_fmt(neg_table);
-  dual.fpos = make_fmt(pos_table);
-  dual.clip_absmax = clip_absmax;
-  dual.clip_strength = clip_strength;
-  return dispatch_rows<true>(x, out, rows, cols, in_dtype, out_dtype, dual.fneg, dual, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* flag = (uint32_t*)nan_flag;
+  if (flag && hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return FPQ_ERR_LAUNCH;
+  int rc;
+  if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
+    rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag);
+  } else if (!clip_absmax && fast16_block_eligible(x, out, cols, in_dtype, out_dtype)) {
+    rc = launch_fast16_block<true>(x, out, rows, cols, neg_table, pos_table, st, flag);
+  } else {
+    DualArgs dual;
+    dual.fneg = make_fmt(neg_table);
+    dual.fpos = make_fmt(pos_table);
+    dual.clip_absmax = clip_absmax;
+    dual.clip_strength = clip_strength;
+    dual.nan_flag = flag;
+    rc = dispatch_rows<true>(x, out, rows, cols, in_dtype, out_dtype, dual.fneg, dual, st);
+  }
+  if (rc != FPQ_OK || !flag) return rc;
+  const int64_t n_bytes = rows * cols * (out_dtype == FPQ_F16 ? 2 : 4);
+  hipLaunchKernelGGL(zero_if_flag_kernel, dim3(grid_for((n_bytes / 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                     (uint8_t*)out, n_bytes, flag);
+  return check_launch();
 }
 
 int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols, int in_dtype,

@@ -99,9 +99,13 @@ def absmax(x: torch.Tensor) -> torch.Tensor:
 def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
                     clipping_strength: Optional[float] = None,
                     out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """Dual-format fake-quantize.  clipping_strength=None: no global clamp
-    (tr/quant_utils.py:577-646); a number: clamp to +-strength*max|x| first (:421-422),
-    which costs one extra read pass for the global absmax."""
+    """Dual-format fake-quantize.
+
+    clipping_strength=None: no global clamp (tr/quant_utils.py:577-646).
+    clipping_strength=1.0:  the reference's clamp to +-1.0*max|x| (:421-422) is the identity
+        unless x holds a NaN, in which case everything becomes zero; reproduced with a NaN
+        flag + conditional zero-fill launch instead of a global absmax pass.
+    any other number: clamp to +-strength*max|x| first (one extra read pass for the absmax)."""
     require_gpu(x, "quant_rows_dual")
     if x.dtype not in (torch.float16, torch.float32):
         raise RuntimeError(f"quant_rows_dual: x must be float16 or float32, got {x.dtype}")
@@ -112,13 +116,16 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
     xc = _contig(x)
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
-        clip_ptr, strength = None, 1.0
-        if clipping_strength is not None:
+        clip_ptr, strength, flag_ptr = None, 1.0, None
+        if clipping_strength is not None and float(clipping_strength) == 1.0:
+            flag = torch.empty(1, dtype=torch.int32, device=x.device)
+            flag_ptr = flag.data_ptr()
+        elif clipping_strength is not None:
             am = absmax(xc)
             clip_ptr, strength = am.data_ptr(), float(clipping_strength)
         check(lib().fpq_quant_rows_dual(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[neg_table],
                                         TABLE_IDS[pos_table], dtype_id(x.dtype), dtype_id(out_dtype), clip_ptr,
-                                        strength, stream_ptr(x.device)), "fpq_quant_rows_dual")
+                                        strength, flag_ptr, stream_ptr(x.device)), "fpq_quant_rows_dual")
     return out
 
 

@@ -95,18 +95,11 @@ def fp_quant_e1_per_group_cuda(x, n_bits, group_size=128):
 # ---- FP4 asymmetric dual format for the fc2 input (tr/quant_utils.py:415-452) ----
 
 def fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, n_bits, group_size=128, clipping_strength=1.0):
-    """x <= 0 on E1M2 (scale max|x_neg|/1.75), x > 0 on E2M1 (scale max x_pos/6).
-
-    The reference clamps to +-clipping_strength*max|x| first; with the default 1.0
-    that is the identity unless the tensor holds a NaN (then torch.clamp turns
-    every element into NaN and the result is all zeros).  The global absmax pass
-    is therefore only launched when clipping_strength != 1.0, and the NaN quirk
-    at strength 1.0 is reproduced by the same route on request
-    (``exact_nan_clip=True`` semantics live in ops.quant_rows_dual(clipping_strength=1.0)).
-    """
+    """x <= 0 on E1M2 (scale max|x_neg|/1.75), x > 0 on E2M1 (scale max x_pos/6), after the
+    reference's global clamp to +-clipping_strength*max|x| (see ops.quant_rows_dual for how the
+    default strength 1.0 avoids the extra pass while keeping the NaN behaviour)."""
     assert n_bits == 4
-    strength = None if clipping_strength == 1.0 else clipping_strength
-    return ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", group_size, strength)
+    return ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", group_size, clipping_strength)
 
 
 # ---- FP6 (tr/quant_utils.py:503-574): output is float16 whatever the input dtype ----

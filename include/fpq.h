@@ -121,10 +121,15 @@ int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols,
  * tensor as written by fpq_absmax; the kernel then clamps x to
  * +-(T)(clip_strength * absmax) first (tr/quant_utils.py:421-422).  A NaN bound
  * turns every element into NaN, hence the whole output into zeros, exactly as
- * torch.clamp does. */
+ * torch.clamp does.
+ * nan_flag: NULL, or 4 bytes of device scratch.  With clip_strength == 1.0 the clamp is
+ * the identity unless x holds a NaN (then the bound is NaN and the result all zeros);
+ * passing scratch here reproduces exactly that WITHOUT the absmax pass: the kernel
+ * raises the flag when it meets a NaN and a second launch (which exits at once when the
+ * flag is clear) zero-fills `out`.  The scratch is cleared on the stream first. */
 int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table,
                         int pos_table, int in_dtype, int out_dtype, const void* clip_absmax,
-                        float clip_strength, fpq_stream_t stream);
+                        float clip_strength, void* nan_flag, fpq_stream_t stream);
 
 /* Online rotate fused in front of the per-group(128) quantizer.
  * Replaces, for the block-diagonal randomized-Hadamard rotation

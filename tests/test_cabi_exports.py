@@ -45,7 +45,7 @@ def test_version_and_errors(lib):
     assert lib.fpq_quant_rows(None, None, 4, 128, 0, 2, 0, None) == -2      # f64 not supported here
     assert lib.fpq_quant_rows(None, None, 4, 128, 0, 0, 0, None) == -1      # null pointers
     assert lib.fpq_quant_rows(None, None, 0, 128, 0, 0, 0, None) == 0       # empty input is fine
-    assert lib.fpq_quant_rows_dual(None, None, 4, 128, 0, 6, 0, 0, None, 1.0, None) == -4
+    assert lib.fpq_quant_rows_dual(None, None, 4, 128, 0, 6, 0, 0, None, 1.0, None, None) == -4
     assert lib.fpq_quant_nearest(None, None, None, 4, 300, 1, None) == -3
     assert lib.fpq_quant_nearest(None, None, None, 4, 15, 0, None) == -2
     assert lib.fpq_quant_nearest(None, None, None, 0, 15, 1, None) == 0

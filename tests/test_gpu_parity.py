@@ -137,8 +137,6 @@ def test_golden_vectors(dev, qu, golden, kind, dn):
                                     "dual_group_cuda_clip0.9", "dual_token_cuda")]
     assert len(keys) == 11
     for key in keys:
-        if kind == "nan" and key.startswith("dual_group_cuda/e1m2"):
-            continue   # NaN + clipping_strength 1.0: covered by test_dual_nan_clip_quirk
         want = from_bits(golden[f"out/{key}"])
         x_before = x.clone()
         got = _run_named(qu, key, x)
@@ -152,15 +150,28 @@ def test_golden_vectors(dev, qu, golden, kind, dn):
     assert_bits_equal(qu.fp_quant_e2_per_group_cuda(x, 4), want, "kv e2m1 g=128")
 
 
-def test_dual_nan_clip_quirk(dev, golden):
-    """A NaN anywhere + the reference's global clamp (tr/quant_utils.py:421-422)
-    zeroes the whole output; reproduced when the clamp pass is requested."""
+def test_dual_nan_clip_quirk(dev, qu, golden):
+    """A NaN anywhere + the reference's global clamp (tr/quant_utils.py:421-422) zeroes the
+    whole output.  Default strength 1.0: NaN flag + conditional zero-fill; other strengths:
+    the absmax pass.  Also on long rows and at a size that spans many workgroups."""
     from fpqvar_amd import ops
     for dn in ("f16", "f32"):
         x = from_bits(golden[f"in/nan_{dn}"]).to(dev)
         want = from_bits(golden[f"out/dual_group_cuda/e1m2_neg+e2m1_pos/nan_{dn}"])
-        got = ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", 128, clipping_strength=1.0)
-        assert_bits_equal(got, want, f"nan clip {dn}")
+        assert_bits_equal(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, 4, 128), want, f"nan clip {dn}")
+        assert_bits_equal(ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", 128, clipping_strength=0.9),
+                          from_bits(golden[f"out/dual_group_cuda_clip0.9/e1m2_neg+e2m1_pos/nan_{dn}"]), "clip .9")
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(4096, 7680, generator=g).half()
+    clean = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(big.to(dev), 4, 128)
+    assert_bits_equal(clean[:64], orc.dual_per_group_kernel_sem(big[:64], "e1m2_neg", "e2m1_pos", 128, 1.0), "clean")
+    big[4000, 7001] = float("nan")
+    out = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(big.to(dev), 4, 128)
+    assert out.shape == big.shape and not out.any(), "one NaN must zero the whole tensor (torch.clamp semantics)"
+    out = ops.quant_rows_dual(big.to(dev), "e1m2_neg", "e2m1_pos", 7680, clipping_strength=1.0)   # long-row kernel
+    assert not out.any()
+    out = ops.quant_rows_dual(big.to(dev), "int_neg", "e2m3_pos", 128, None)      # no clamp: NaN element -> 0 only
+    assert bool(out.any()) and not torch.isnan(out).any()
 
 
 # ------------------------------------------------------------------ oracle on seeded inputs
