@@ -561,3 +561,36 @@ def test_format_search_layer(dev):
     assert (wf, af) == best
     wf4, af4, l4 = fs.search_layer([x.to(dev).half() for x in xs], w.to(dev).half(), fs.FP4_FORMATS)
     assert len(l4) == 9 and wf4 in fs.FP4_FORMATS and af4 in fs.FP4_FORMATS
+
+
+# ------------------------------------------------------------------ hipGraph capture (no alloc / sync inside the ABI)
+def test_graph_capture_and_replay(dev, qu):
+    from fpqvar_amd import rotation as rot
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(400, 1920, generator=g).half().to(dev)
+    h = torch.nn.functional.gelu(torch.randn(400, 7680, generator=g)).half().to(dev)
+    static_x, static_h = x.clone(), h.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):          # warm-up on the side stream (builds the host-side table cache)
+        qu.fp_quant_e2_per_group_cuda(static_x, 4, 128)
+        qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(static_h, 4, 128)
+        rot.rotate_quant(static_x, "e2m1")
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y1 = qu.fp_quant_e2_per_group_cuda(static_x, 4, 128)
+        y2 = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(static_h, 4, 128)     # memset + 2 launches
+        y3 = qu.fp6_quant_e2m3_per_token_cuda(static_x, 6)
+        y4 = rot.rotate_quant(static_x, "e2m1")
+    for trial in range(2):
+        xn = torch.randn(400, 1920, generator=g).half()
+        hn = torch.nn.functional.gelu(torch.randn(400, 7680, generator=g)).half()
+        static_x.copy_(xn.to(dev))
+        static_h.copy_(hn.to(dev))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert_bits_equal(y1, orc.per_group_kernel_sem(xn, "e2m1", 128), f"graph replay {trial} e2m1")
+        assert_bits_equal(y2, orc.dual_per_group_kernel_sem(hn, "e1m2_neg", "e2m1_pos", 128, 1.0), "graph dual")
+        assert_bits_equal(y3, orc.per_token_kernel_sem(xn, "e2m3"), "graph token")
+        assert_bits_equal(y4, rot.rotate_quant(static_x, "e2m1"), "graph rotate")
