@@ -101,6 +101,53 @@ def unfused_gpu_sequence(x, steps=3):
     return {"value": round(x.numel() / dt / 1e9, 3), "unit": "Gelem/s", "ms": round(dt * 1e3, 4)}
 
 
+def other_kernels(dev):
+    """Secondary measurements on the same GPU (not the headline metric): the other
+    kernels of the path at the BASELINE shapes, each with its own byte denominator."""
+    from fpqvar_amd import ops, rotation as rot
+    out = {}
+
+    def timed(fn, iters=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    g = torch.Generator(device=dev).manual_seed(1)
+    hs = [torch.nn.functional.gelu(torch.randn(ROWS, 4 * COLS, device=dev, generator=g), approximate="tanh").half()
+          for _ in range(2)]
+    k = [0]
+
+    def nxt(lst):
+        k[0] += 1
+        return lst[k[0] % len(lst)]
+
+    ms = timed(lambda: ops.quant_rows_dual(nxt(hs), "e1m2_neg", "e2m1_pos", GROUP, 1.0))
+    n = hs[0].numel()
+    out["dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680"] = {"ms": round(ms, 4), "GBps": round(n * 4 / ms / 1e6, 1),
+                                                      "frac_of_8TBps": round(n * 4 / ms / 1e6 / HBM_PEAK_GBS, 3)}
+    del hs
+    xs = [torch.randn(ROWS, COLS, device=dev, generator=g).half() for _ in range(3)]
+    n = xs[0].numel()
+    ms = timed(lambda: rot.rotate_quant(nxt(xs), "e2m1"))
+    out["fused_rotate_quant_e2m1_fp16_65536x1920"] = {"ms": round(ms, 4), "GBps": round(n * 4 / ms / 1e6, 1),
+                                                      "frac_of_8TBps": round(n * 4 / ms / 1e6 / HBM_PEAK_GBS, 3)}
+    ms = timed(lambda: ops.quant_rows(nxt(xs), "e2m3", COLS, torch.float16))
+    out["fp6_e2m3_per_token_fp16_65536x1920"] = {"ms": round(ms, 4), "GBps": round(n * 4 / ms / 1e6, 1),
+                                                 "frac_of_8TBps": round(n * 4 / ms / 1e6 / HBM_PEAK_GBS, 3)}
+    ws = [torch.randn(ROWS // 2, COLS, device=dev, generator=g) * 0.02 for _ in range(3)]
+    n = ws[0].numel()
+    ms = timed(lambda: ops.quant_rows(nxt(ws), "e2m1", GROUP))
+    out["weights_e2m1_per_group_fp32_32768x1920"] = {"ms": round(ms, 4), "GBps": round(n * 8 / ms / 1e6, 1),
+                                                     "frac_of_8TBps": round(n * 8 / ms / 1e6 / HBM_PEAK_GBS, 3)}
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (null if none)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -218,6 +265,12 @@ def main():
                 res["unfused_gpu"] = unfused_gpu_sequence(x)
             except Exception as e:  # extra information only
                 res["unfused_gpu"] = {"error": str(e)[:200]}
+            try:
+                del xs, outs
+                torch.cuda.empty_cache()
+                res["other_kernels"] = other_kernels(dev)
+            except Exception as e:
+                res["other_kernels"] = {"error": str(e)[:200]}
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if dist is not None:
