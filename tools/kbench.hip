@@ -172,6 +172,11 @@ int main(int argc, char** argv) {
   add("fast e2m1 U8", [&] { launch_fast16<false, 8>(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_E2M1, st); });
   add("fast e2m1 U4 cap2048", [&] { launch_fast16<false, 4>(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_E2M1, st, 2048); });
   add("fast e2m1 U4 cap8192", [&] { launch_fast16<false, 4>(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_E2M1, st, 8192); });
+  add("dual fp4 U1", [&] { launch_fast16<true, 1>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st); });
+  add("dual fp4 U2", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st); });
+  add("dual fp4 U4", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st); });
+  static uint32_t* dflag = nullptr; if (!dflag) CK(hipMalloc(&dflag, 4));
+  add("dual fp4 U2 +nanflag", [&] { fpq_quant_rows_dual(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, FPQ_F16, FPQ_F16, nullptr, 1.f, dflag, st); });
   add("fast dualfp6 U4 (fill)", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st); });
   add("fast e2m3 token1920", [&] { fpq_quant_rows(X(), O(), n / 1920, 1920, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
   add("fast e2m3 token7680", [&] { fpq_quant_rows(X(), O(), n / 7680, 7680, FPQ_E2M3, FPQ_F16, FPQ_F16, st); });
