@@ -642,6 +642,88 @@ __global__ __launch_bounds__(kBlock) void rows_codes_kernel(const Tin* __restric
   }
 }
 
+// Vectorised codes for rows of exactly 128 elements (per-group): LPR lanes own a row, 16-byte
+// loads, one packed store per lane (FP4: V nibbles, FP6: V bytes), lane 0 of the row writes the scale.
+template <typename Tin, bool PACK>
+__global__ __launch_bounds__(kBlock) void codes128_kernel(const u32x4* __restrict__ x, uint8_t* __restrict__ codes,
+                                                         Tin* __restrict__ scales, int64_t n_vec, Fmt fs) {
+  constexpr int V = DT<Tin>::kVec;
+  constexpr int LPR = 128 / V;
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * kBlock) {
+    u32x4 raw = __builtin_nontemporal_load(x + v);
+    float xf[V];
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      xf[i] = DT<Tin>::get(raw, i);
+      uint32_t ab = DT<Tin>::absbits(xf[i]);
+      m = m > ab ? m : ab;
+    }
+    m = lanes_max<LPR>(m);
+    float s = scale_of<Tin>(m, fs.gmax);
+    if ((threadIdx.x & (LPR - 1)) == 0) store_scalar<Tin>(scales + v / LPR, s);
+    uint32_t c[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float xn = DT<Tin>::round(xf[i] / s);
+      uint32_t neg = (xn < 0.0f) ? 1u : 0u;
+      float qm = quant_mag(fabsf(xn), neg, fs);
+      int li = level_index(qm, fs);
+      c[i] = (uint32_t)(neg ? fs.zero_code - li : fs.zero_code + li);
+    }
+    if constexpr (PACK && V == 8) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w |= c[i] << (4 * i);
+      ((uint32_t*)codes)[v] = w;
+    } else if constexpr (PACK && V == 4) {
+      ((uint16_t*)codes)[v] = (uint16_t)(c[0] | (c[1] << 4) | (c[2] << 8) | (c[3] << 12));
+    } else if constexpr (V == 8) {
+      u32x2 w = {c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24), c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24)};
+      ((u32x2*)codes)[v] = w;
+    } else {
+      ((uint32_t*)codes)[v] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+    }
+  }
+}
+
+// inverse for rows of 128: every lane decodes 8 consecutive elements
+template <typename Ts, typename Tout, bool PACK>
+__global__ __launch_bounds__(kBlock) void decode128_kernel(const uint8_t* __restrict__ codes, const Ts* __restrict__ scales,
+                                                          Tout* __restrict__ out, int64_t n_oct, Fmt fs) {
+  const int nsub = (int)(fs.kmin * fs.inv_step0);
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_oct; v += (int64_t)gridDim.x * kBlock) {
+    uint32_t c[8];
+    if constexpr (PACK) {
+      uint32_t w = ((const uint32_t*)codes)[v];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c[i] = (w >> (4 * i)) & 0xFu;
+    } else {
+      u32x2 w = ((const u32x2*)codes)[v];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    }
+    float s = load_scalar<Ts>(scales + (v >> 4));
+    float p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int li = (int)c[i] - fs.zero_code;
+      uint32_t neg = li < 0;
+      li = neg ? -li : li;
+      float q = (li < nsub) ? (float)li * fs.step0 : u2f(((uint32_t)li + fs.kmin_code_base) << fs.mshift);
+      p[i] = (neg ? -q : q) * s;
+    }
+    if constexpr (sizeof(Tout) == 2) {
+      u32x4 o = {f2h(p[0]) | (f2h(p[1]) << 16), f2h(p[2]) | (f2h(p[3]) << 16), f2h(p[4]) | (f2h(p[5]) << 16),
+                 f2h(p[6]) | (f2h(p[7]) << 16)};
+      __builtin_nontemporal_store(o, (u32x4*)out + v);
+    } else {
+      __builtin_nontemporal_store(u32x4{fbits(p[0]), fbits(p[1]), fbits(p[2]), fbits(p[3])}, (u32x4*)out + 2 * v);
+      __builtin_nontemporal_store(u32x4{fbits(p[4]), fbits(p[5]), fbits(p[6]), fbits(p[7])}, (u32x4*)out + 2 * v + 1);
+    }
+  }
+}
+
 template <typename Ts, typename Tout>
 __global__ __launch_bounds__(kBlock) void rows_decode_kernel(const uint8_t* __restrict__ codes,
                                                             const Ts* __restrict__ scales,
@@ -1048,6 +1130,19 @@ int fpq_quant_rows_codes(const void* x, uint8_t* codes, void* scales, int64_t ro
   if (!x || !codes || !scales) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   Fmt f = make_fmt(table_id);
+  if (cols == 128 && (((uintptr_t)x | (uintptr_t)codes | (uintptr_t)scales) & 15) == 0) {
+    const int64_t n_vec = rows * (in_dtype == FPQ_F16 ? 16 : 32);
+    const int gv = grid_for((n_vec + kBlock - 1) / kBlock, 1 << 20);
+    if (in_dtype == FPQ_F16 && pack_nibbles)
+      hipLaunchKernelGGL((codes128_kernel<_Float16, true>), dim3(gv), dim3(kBlock), 0, st, (const u32x4*)x, codes, (_Float16*)scales, n_vec, f);
+    else if (in_dtype == FPQ_F16)
+      hipLaunchKernelGGL((codes128_kernel<_Float16, false>), dim3(gv), dim3(kBlock), 0, st, (const u32x4*)x, codes, (_Float16*)scales, n_vec, f);
+    else if (pack_nibbles)
+      hipLaunchKernelGGL((codes128_kernel<float, true>), dim3(gv), dim3(kBlock), 0, st, (const u32x4*)x, codes, (float*)scales, n_vec, f);
+    else
+      hipLaunchKernelGGL((codes128_kernel<float, false>), dim3(gv), dim3(kBlock), 0, st, (const u32x4*)x, codes, (float*)scales, n_vec, f);
+    return check_launch();
+  }
   int g = grid_for(rows, 65535);
   if (in_dtype == FPQ_F16)
     hipLaunchKernelGGL(rows_codes_kernel<_Float16>, dim3(g), dim3(kBlock), 0, st, (const _Float16*)x, codes,
@@ -1069,6 +1164,17 @@ int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, 
   if (!codes || !scales || !out) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   Fmt f = make_fmt(table_id);
+  if (cols == 128 && (((uintptr_t)out | (uintptr_t)codes) & 15) == 0) {
+    const int64_t n_oct = rows * 16;
+    const int gv = grid_for((n_oct + kBlock - 1) / kBlock, 1 << 20);
+#define FPQ_DEC(TS, TO, PK) hipLaunchKernelGGL((decode128_kernel<TS, TO, PK>), dim3(gv), dim3(kBlock), 0, st, codes, (const TS*)scales, (TO*)out, n_oct, f)
+    if (scale_dtype == FPQ_F16 && out_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DEC(_Float16, _Float16, true); else FPQ_DEC(_Float16, _Float16, false); }
+    else if (scale_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DEC(_Float16, float, true); else FPQ_DEC(_Float16, float, false); }
+    else if (out_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DEC(float, _Float16, true); else FPQ_DEC(float, _Float16, false); }
+    else { if (pack_nibbles) FPQ_DEC(float, float, true); else FPQ_DEC(float, float, false); }
+#undef FPQ_DEC
+    return check_launch();
+  }
   int g = grid_for(rows, 65535);
   int pk = pack_nibbles ? 1 : 0;
   if (scale_dtype == FPQ_F16 && out_dtype == FPQ_F16)
