@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libfpq_hip.so")
 
 F16, F32, F64 = 0, 1, 2
 TABLE_IDS = {"e2m1": 0, "e1m2": 1, "e3m0": 2, "e2m3": 3, "e3m2": 4,
-             "e1m2_neg": 5, "e2m1_pos": 6, "int_neg": 7, "e2m3_pos": 8}
+             "e1m2_neg": 5, "e2m1_pos": 6, "int_neg": 7, "e2m3_pos": 8, "e2m1_neg": 9}
 _DTYPES = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
 
 _lib: Optional[ctypes.CDLL] = None

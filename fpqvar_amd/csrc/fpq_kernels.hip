@@ -74,7 +74,7 @@ const TableInfo kTables[FPQ_NUM_TABLES] = {
     {"e3m0", 1, 0.25f, 0, 16.0f, 8},    {"e2m3", 1, 1.0f, 3, 7.5f, 32},
     {"e3m2", 1, 0.25f, 2, 28.0f, 32},   {"e1m2_neg", 0, 1.0f, 2, 1.75f, 8},
     {"e2m1_pos", 0, 1.0f, 1, 6.0f, 8},  {"int_neg", 0, 32.0f, 5, 32.0f, 33},
-    {"e2m3_pos", 0, 1.0f, 3, 7.5f, 32},
+    {"e2m3_pos", 0, 1.0f, 3, 7.5f, 32}, {"e2m1_neg", 0, 1.0f, 1, 6.0f, 8},
 };
 
 inline uint32_t f2u(float f) {
@@ -975,7 +975,7 @@ int fpq_table_values(int table_id, float* host_out) {
   float pos[64];
   int np = pos_levels(table_id, pos);
   int n = 0;
-  const bool neg_half = (table_id == FPQ_E1M2_NEG || table_id == FPQ_INT_NEG);
+  const bool neg_half = (table_id == FPQ_E1M2_NEG || table_id == FPQ_INT_NEG || table_id == FPQ_E2M1_NEG);
   const bool pos_half = (table_id == FPQ_E2M1_POS || table_id == FPQ_E2M3_POS);
   const bool dup_zero = (table_id == FPQ_E2M3 || table_id == FPQ_E3M2);
   if (!pos_half) {
@@ -1015,7 +1015,7 @@ int fpq_quant_nearest_builtin(const float* x, float* z, int64_t n, int table_id,
   if (table_id < 0 || table_id >= FPQ_NUM_TABLES) return FPQ_ERR_TABLE;
   if (n == 0) return FPQ_OK;
   if (!x || !z) return FPQ_ERR_ARG;
-  int side = kTables[table_id].symmetric ? 0 : ((table_id == FPQ_E1M2_NEG || table_id == FPQ_INT_NEG) ? 1 : 2);
+  int side = kTables[table_id].symmetric ? 0 : ((table_id == FPQ_E1M2_NEG || table_id == FPQ_INT_NEG || table_id == FPQ_E2M1_NEG) ? 1 : 2);
   hipLaunchKernelGGL(nearest_builtin_kernel, dim3(grid_for((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, x, z, n, make_fmt(table_id), side);
   return check_launch();
@@ -1058,7 +1058,7 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
                         int in_dtype, int out_dtype, const void* clip_absmax, float clip_strength, void* nan_flag,
                         fpq_stream_t stream) {
   if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
-  if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_INT_NEG) return FPQ_ERR_TABLE;
+  if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_INT_NEG && neg_table != FPQ_E2M1_NEG) return FPQ_ERR_TABLE;
   if (pos_table != FPQ_E2M1_POS && pos_table != FPQ_E2M3_POS) return FPQ_ERR_TABLE;
   if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (out_dtype != FPQ_F16 && out_dtype != FPQ_F32))
     return FPQ_ERR_DTYPE;

@@ -44,6 +44,7 @@ def _act_quantizer(act_quant, activation_fp_quant, act_fp_type, a_bit, fc2: bool
     if fc2:
         table["fp_e1m2_neg_e2m1_pos"] = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda
         table["fp6_int_neg_e2m3_pos"] = qu.fp6_quant_int_neg_e2m3_pos_per_group_cuda
+        table["fp4_afpq"] = qu.fp4_afpq_per_group_cuda          # models_fp_quant/quant_utils.py:1040-1041
     if act_fp_type not in table:
         raise ValueError("Unsupported fp_type.")
     return partial(table[act_fp_type], n_bits=a_bit, group_size=_GROUP)

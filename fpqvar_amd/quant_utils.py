@@ -102,6 +102,13 @@ def fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, n_bits, group_size=128, clippin
     return ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", group_size, clipping_strength)
 
 
+def fp4_afpq_per_group_cuda(x, n_bits, group_size=128, clipping_strength=1.0):
+    """models_fp_quant/quant_utils.py:498-535: like the function above but the negative side
+    also uses the E2M1 levels (table [-6 .. 0], scale max|x_neg|/6)."""
+    assert n_bits == 4
+    return ops.quant_rows_dual(x, "e2m1_neg", "e2m1_pos", group_size, clipping_strength)
+
+
 # ---- FP6 (tr/quant_utils.py:503-574): output is float16 whatever the input dtype ----
 
 def fp6_quant_e2m3_per_token_cuda(x, n_bits):

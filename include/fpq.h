@@ -51,7 +51,8 @@ enum fpq_table {
   FPQ_E2M1_POS = 6,
   FPQ_INT_NEG = 7,
   FPQ_E2M3_POS = 8,
-  FPQ_NUM_TABLES = 9
+  FPQ_E2M1_NEG = 9, /* [-6 .. 0]: negative half of fp4_afpq_per_group_cuda, models_fp_quant/quant_utils.py:501 */
+  FPQ_NUM_TABLES = 10
 };
 
 int fpq_version(void);
@@ -117,6 +118,7 @@ int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols,
  *     fp_quant_e1m2_neg_e2m1_pos_per_group_cuda   tr/quant_utils.py:415-452
  *     fp6_quant_int_neg_e2m3_pos_per_group_cuda   :577-611
  *     fp6_quant_int_neg_e2m3_pos_per_token_cuda   :614-646
+ *     fp4_afpq_per_group_cuda (E2M1_NEG / E2M1_POS)   models_fp_quant/quant_utils.py:498-535
  * clip_absmax: NULL, or a device scalar (in_dtype) holding max|x| over the WHOLE
  * tensor as written by fpq_absmax; the kernel then clamps x to
  * +-(T)(clip_strength * absmax) first (tr/quant_utils.py:421-422).  A NaN bound

@@ -78,10 +78,12 @@ TABLES: Dict[str, torch.Tensor] = {
     "e2m1_pos": torch.tensor(_minifloat_pos(2, 1, 1), dtype=torch.float32),
     "int_neg": torch.tensor(_sym([float(v) for v in range(33)], True)[:33], dtype=torch.float32),
     "e2m3_pos": torch.tensor(_minifloat_pos(2, 3, 1), dtype=torch.float32),
+    # negative half of fp4_afpq_per_group_cuda (models_fp_quant/quant_utils.py:501)
+    "e2m1_neg": torch.tensor(_sym(_minifloat_pos(2, 1, 1), True)[:8], dtype=torch.float32),
 }
 
 TABLE_IDS = {name: i for i, name in enumerate(
-    ["e2m1", "e1m2", "e3m0", "e2m3", "e3m2", "e1m2_neg", "e2m1_pos", "int_neg", "e2m3_pos"])}
+    ["e2m1", "e1m2", "e3m0", "e2m3", "e3m2", "e1m2_neg", "e2m1_pos", "int_neg", "e2m3_pos", "e2m1_neg"])}
 
 
 def table_absmax(name: str) -> float:

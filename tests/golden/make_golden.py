@@ -41,6 +41,7 @@ sys.modules.setdefault("quant_utils", types.ModuleType("quant_utils"))
 
 import models_fp_quant_transform_rotate.quant_utils as qu  # noqa: E402
 import models_fp_quant_transform_rotate.basic_var as bv    # noqa: E402
+import models_fp_quant.quant_utils as fqu                  # noqa: E402  (older variant: adds fp4_afpq)
 from rotate_utils import hadamard_utils as hu              # noqa: E402
 from rotate_utils import rotation_utils as ru              # noqa: E402
 
@@ -102,6 +103,7 @@ def main():
         "int_neg": qu.int_neg_grid, "e2m3_pos": qu.e2m3_pos_grid,
         "e1m2_neg": torch.tensor([-1.75, -1.5, -1.25, -1.0, -0.75, -0.5, -0.25, 0.0]),
         "e2m1_pos": torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]),
+        "e2m1_neg": torch.tensor([-6.0, -4.0, -3.0, -2.0, -1.5, -1.0, -0.5, 0.0]),   # fq/quant_utils.py:501
     }
     # the two 8-entry tables are locals of tr/quant_utils.py:418-419; check the
     # literals above against the function by feeding exact table values through it
@@ -141,6 +143,8 @@ def main():
                           qu.fp6_quant_int_neg_e2m3_pos_per_group_cuda(x.clone(), 6, 128)))
             cases.append((f"dual_token_cuda/int_neg+e2m3_pos/{kind}_{dn}",
                           qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(x.clone(), 6)))
+            cases.append((f"dual_group_cuda/e2m1_neg+e2m1_pos/{kind}_{dn}",
+                          fqu.fp4_afpq_per_group_cuda(x.clone(), P, 128)))
             # the pure-torch CPU path (A9)
             cases.append((f"per_group_argmin/e2m1/{kind}_{dn}", qu.fp_quant_e2_per_group(x.clone(), P, 128)))
             cases.append((f"per_group_argmin/e1m2/{kind}_{dn}", qu.fp_quant_e1_per_group(x.clone(), P, 128)))

@@ -118,6 +118,8 @@ def _run_named(qu, key, x):
         fn = {"e2m3": qu.fp6_quant_e2m3_per_token_cuda, "e3m2": qu.fp6_quant_e3m2_per_token_cuda}[tab]
         return fn(x, 6)
     if fam == "dual_group_cuda":
+        if tab.startswith("e2m1_neg"):
+            return qu.fp4_afpq_per_group_cuda(x, 4, 128)
         if tab.startswith("e1m2"):
             return qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, 4, 128)
         return qu.fp6_quant_int_neg_e2m3_pos_per_group_cuda(x, 6, 128)
@@ -135,7 +137,7 @@ def test_golden_vectors(dev, qu, golden, kind, dn):
     keys = [k[4:] for k in golden.files if k.startswith("out/") and k.endswith(f"/{kind}_{dn}")
             and k.split("/")[1] in ("per_group_cuda", "per_token_cuda", "dual_group_cuda",
                                     "dual_group_cuda_clip0.9", "dual_token_cuda")]
-    assert len(keys) == 11
+    assert len(keys) == 12
     for key in keys:
         want = from_bits(golden[f"out/{key}"])
         x_before = x.clone()

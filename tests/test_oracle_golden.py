@@ -98,6 +98,8 @@ def test_dual_kernel_sem(golden, kind, dn):
     assert_bits_equal(orc.dual_per_group_kernel_sem(x, "e1m2_neg", "e2m1_pos", 128, 0.9), want, "dual fp4 clip")
     want = from_bits(golden[f"out/dual_group_cuda/int_neg+e2m3_pos/{kind}_{dn}"])
     assert_bits_equal(orc.dual_per_group_kernel_sem(x, "int_neg", "e2m3_pos", 128, None), want, "dual fp6 group")
+    want = from_bits(golden[f"out/dual_group_cuda/e2m1_neg+e2m1_pos/{kind}_{dn}"])
+    assert_bits_equal(orc.dual_per_group_kernel_sem(x, "e2m1_neg", "e2m1_pos", 128, 1.0), want, "afpq")
     want = from_bits(golden[f"out/dual_token_cuda/int_neg+e2m3_pos/{kind}_{dn}"])
     assert_bits_equal(orc.dual_per_token_kernel_sem(x, "int_neg", "e2m3_pos"), want, "dual fp6 token")
 
