@@ -478,3 +478,146 @@ __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __re
     }
   }
 }
+
+// ---------------------------------------------------------------------------------
+// F1, complete form: the whole producer of tr/basic_var.py:263 / :266 in one launch
+//     h  = half( ((LN(x) * half(scale+1)) + shift) * s )      LN without affine, eps, fp32 math
+//     x1 = half( c_h * FWHT128(h * D) )
+//     q  = per-group(128) quant(x1)
+// One workgroup per token row (C <= 4096): the row stays in registers from the first load
+// to the final store; mean / variance by a two-pass block reduction (shuffles + LDS).
+// fp32 op order follows the reference's chain of torch ops (mul, add_, mul - each rounded
+// to fp32, no contraction); LayerNorm's own mean/rstd differ from torch's Welford kernel
+// by fp32 rounding only, so h can differ from torch's by 1 fp16 ulp on rare elements:
+// the contract for this entry point is the fuzzy one of SURVEY.md section 7 (quant stage
+// bit-exact on the rotated values produced here; rotated values within 1 ulp).
+// ---------------------------------------------------------------------------------
+struct AdaLnArgs {
+  const void* scale;      // [batches, cols]  (scale1 / scale2 of the block)
+  const void* shift;      // [batches, cols]
+  int mod_is_f16;         // dtype of scale / shift
+  int64_t rows_per_batch; // L: row r uses batch r / L
+  float eps;
+  int64_t cols;
+};
+
+__device__ __forceinline__ float block_sum_f32(float v, float* sh) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / 64; ++i) r += sh[i];
+  return r;
+}
+
+template <typename Tin, int MAXC>
+__global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void* __restrict__ xv,
+                                                                     u32x4* __restrict__ out, u32x4* __restrict__ h_out,
+                                                                     u32x4* __restrict__ y_out, int64_t rows,
+                                                                     AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ float shf[kBlock / 64];
+  const int lg = threadIdx.x & 15;
+  const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
+  uint32_t sx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sx[k] = (((sb >> (2 * k)) & 1u) << 15) | (((sb >> (2 * k + 1)) & 1u) << 31);
+  {
+    const int n = 1 << (16 - a.shift);
+    for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+  }   // ordered before first use by the barriers of block_sum_f32
+  const int64_t vpr = r.vec_per_row;
+  const float inv_c = 1.0f / (float)ad.cols;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    float f[MAXC][8];
+    float s1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t v = (int64_t)c * kBlock + threadIdx.x;
+      const bool live = v < vpr;
+      if constexpr (sizeof(Tin) == 2) {
+        u32x4 w = live ? __builtin_nontemporal_load((const u32x4*)xv + row * vpr + v) : u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f[c][2 * k] = h2f(w[k] & 0xFFFFu);
+          f[c][2 * k + 1] = h2f(w[k] >> 16);
+        }
+      } else {
+        u32x4 lo = live ? __builtin_nontemporal_load((const u32x4*)xv + 2 * (row * vpr + v)) : u32x4{0, 0, 0, 0};
+        u32x4 hi = live ? __builtin_nontemporal_load((const u32x4*)xv + 2 * (row * vpr + v) + 1) : u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f[c][k] = u2f(lo[k]);
+          f[c][4 + k] = u2f(hi[k]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s1 += f[c][i];
+    }
+    const float mean = block_sum_f32(s1, shf) * inv_c;
+    float s2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const bool live = (int64_t)c * kBlock + threadIdx.x < vpr;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float d = f[c][i] - mean;
+        f[c][i] = d;
+        s2 += live ? d * d : 0.0f;
+      }
+    }
+    const float var = block_sum_f32(s2, shf) * inv_c;
+    const float rstd = 1.0f / __builtin_sqrtf(var + ad.eps);
+    const int64_t b = row / ad.rows_per_batch;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t v = (int64_t)c * kBlock + threadIdx.x;
+      const bool live = v < vpr;
+      float t[8];
+      if (live) {
+        const int64_t col = v * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float sc, sh;
+          if (ad.mod_is_f16) {
+            sc = h2f(f2h(h2f(((const uint16_t*)ad.scale)[b * ad.cols + col + i]) + 1.0f));   // scale.add(1) in fp16
+            sh = h2f(((const uint16_t*)ad.shift)[b * ad.cols + col + i]);
+          } else {
+            sc = ((const float*)ad.scale)[b * ad.cols + col + i] + 1.0f;
+            sh = ((const float*)ad.shift)[b * ad.cols + col + i];
+          }
+          float ln = f[c][i] * rstd;
+          float u1 = ln * sc;
+          float u2 = u1 + sh;
+          if (r.smooth) u2 = u2 * r.smooth[col + i];
+          t[i] = u2;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = 0.0f;
+      }
+      u32x4 hw;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hw[k] = f2h(t[2 * k]) | (f2h(t[2 * k + 1]) << 16);
+      if (h_out && live) __builtin_nontemporal_store(hw, h_out + row * vpr + v);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t w = hw[k] ^ sx[k];
+        t[2 * k] = h2f(w & 0xFFFFu);
+        t[2 * k + 1] = h2f(w >> 16);
+      }
+      fwht128(t, lg);
+      u32x4 y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = f2h(t[2 * k] * r.c_h) | (f2h(t[2 * k + 1] * r.c_h) << 16);
+      if (y_out && live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
+      uint32_t m = row_max_dpp<16>(vec_absmax16(y));
+      RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      if (live) __builtin_nontemporal_store(o, out + row * vpr + v);
+    }
+  }
+}

@@ -919,6 +919,28 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   return check_launch();
 }
 
+template <typename Tin>
+int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out, int64_t rows, int64_t cols,
+                              const AdaLnArgs& ad, const float* smooth, const uint32_t sign[4], int table_id,
+                              hipStream_t st) {
+  const Lut16Host& h = lut16_host(table_id, table_id);
+  if (!h.tab_valid) return FPQ_ERR_TABLE;
+  RotArgs r;
+  r.smooth = smooth;
+  for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
+  r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));
+  r.vec_per_row = cols / 8;
+  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const int g = grid_for(rows, 1 << 20);
+  if (r.vec_per_row <= kBlock)
+    hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, 1>), dim3(g), dim3(kBlock), lds, st, x, (u32x4*)out,
+                       (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, h.tab);
+  else
+    hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, 2>), dim3(g), dim3(kBlock), lds, st, x, (u32x4*)out,
+                       (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, h.tab);
+  return check_launch();
+}
+
 template <bool DUAL>
 int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id,
                         hipStream_t st, uint32_t* nan_flag = nullptr) {
@@ -1102,6 +1124,32 @@ int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t r
                                          (hipStream_t)stream);
   return launch_rotate_quant<float>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
                                     (hipStream_t)stream);
+}
+
+int fpq_adaln_rotate_quant_rows(const void* x, void* out, void* h_out, void* rotated_out, int64_t rows, int64_t cols,
+                                int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                int64_t rows_per_batch, float eps, const float* smooth,
+                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0 || rows_per_batch <= 0 || !sign_mask_host) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (mod_dtype != FPQ_F16 && mod_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (cols % 128 != 0 || cols > 4096) return FPQ_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !out || !scale || !shift) return FPQ_ERR_ARG;
+  if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)h_out | (uintptr_t)rotated_out) & 15) != 0) return FPQ_ERR_ARG;
+  AdaLnArgs ad;
+  ad.scale = scale;
+  ad.shift = shift;
+  ad.mod_is_f16 = mod_dtype == FPQ_F16;
+  ad.rows_per_batch = rows_per_batch;
+  ad.eps = eps;
+  ad.cols = cols;
+  if (in_dtype == FPQ_F16)
+    return launch_adaln_rotate_quant<_Float16>(x, out, h_out, rotated_out, rows, cols, ad, smooth, sign_mask_host,
+                                               table_id, (hipStream_t)stream);
+  return launch_adaln_rotate_quant<float>(x, out, h_out, rotated_out, rows, cols, ad, smooth, sign_mask_host,
+                                          table_id, (hipStream_t)stream);
 }
 
 int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream) {

@@ -96,3 +96,42 @@ def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor]
                                           x.numel() // c, c, dtype_id(x.dtype), sm_ptr, mask, TABLE_IDS[table],
                                           stream_ptr(x.device)), "fpq_rotate_quant_rows")
     return (out, rot) if return_rotated else out
+
+
+def adaln_rotate_quant(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, table: str = "e2m1",
+                       d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None, eps: float = 1e-6,
+                       return_intermediates: bool = False):
+    """act_quant( matmul( LN(x).mul(scale.add(1)).add_(shift).mul(smooth), Q_block ) ) in one launch
+    (tr/basic_var.py:263,266 + tr/quant_utils.py:765 under the driver's fp16 autocast).
+
+    x: [B, L, C] fp16/fp32 on the GPU; scale, shift: [B, 1, C] (or [B, C]), both fp16 or both fp32.
+    Returns fp16 [B, L, C] (plus h and the rotated tensor when return_intermediates)."""
+    require_gpu(x, "adaln_rotate_quant")
+    if x.dim() != 3:
+        raise RuntimeError("adaln_rotate_quant: x must be [B, L, C]")
+    bsz, seq, c = x.shape
+    if c % 128 != 0 or c > 4096:
+        raise RuntimeError("adaln_rotate_quant: C must be a multiple of 128 and at most 4096")
+    if scale.dtype != shift.dtype or scale.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("adaln_rotate_quant: scale and shift must both be float16 or both float32")
+    sc = scale.reshape(bsz, c).contiguous()
+    sh = shift.reshape(bsz, c).contiguous()
+    d = sign_vector(128, 42) if d is None else d
+    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    xc = x if x.is_contiguous() else x.contiguous()
+    sm_ptr, sm = None, None
+    if smooth is not None:
+        sm = smooth.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if sm.numel() == 1:
+            sm = sm.expand(c).contiguous()
+        sm_ptr = sm.data_ptr()
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    h = torch.empty_like(out) if return_intermediates else None
+    y = torch.empty_like(out) if return_intermediates else None
+    with torch.cuda.device(x.device):
+        check(lib().fpq_adaln_rotate_quant_rows(
+            xc.data_ptr(), out.data_ptr(), h.data_ptr() if h is not None else None,
+            y.data_ptr() if y is not None else None, bsz * seq, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),
+            dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, TABLE_IDS[table], stream_ptr(x.device)),
+            "fpq_adaln_rotate_quant_rows")
+    return (out, h, y) if return_intermediates else out

@@ -150,6 +150,23 @@ int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t r
                           int in_dtype, const float* smooth, const uint32_t* sign_mask_host, int table_id,
                           fpq_stream_t stream);
 
+/* The complete producer of tr/basic_var.py:263 / :266 plus the activation quantizer, one launch:
+ *     h   = half( ((LayerNorm(x) * half(scale + 1)) + shift) * smooth )    (no affine, eps; fp32 ops in
+ *                                                                            the reference's order)
+ *     y   = half( c_h * FWHT128(h * D) )          (= h @ half(Q_block))
+ *     out = per-group(128) quant(y)
+ * x: [rows, cols] F16/F32, cols % 128 == 0, cols <= 4096; scale, shift: [rows / rows_per_batch, cols]
+ * in mod_dtype (the block's AdaLN scale1/shift1 or scale2/shift2, one row per batch element);
+ * smooth: device float[cols] or NULL; sign_mask_host as in fpq_rotate_quant_rows.
+ * h_out / rotated_out: NULL or fp16 [rows, cols] receiving h / y (for verification).
+ * Parity: out == fpq_quant_rows(y) bit for bit and y as in fpq_rotate_quant_rows given h; h itself
+ * matches torch's chain up to the fp32 rounding of LayerNorm's mean / rstd (1 fp16 ulp on rare
+ * elements) - torch's Welford reduction order is not a contract. */
+int fpq_adaln_rotate_quant_rows(const void* x, void* out, void* h_out, void* rotated_out, int64_t rows,
+                                int64_t cols, int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                int64_t rows_per_batch, float eps, const float* smooth,
+                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
+
 /* max|x| over n elements (NaN-propagating, like torch's x.abs().max()), written
  * as ONE scalar of `dtype` to `out`.  `out` must hold 4 bytes; it is zeroed on the
  * stream first (hipMemsetAsync) and then combined with device atomics. */

@@ -89,3 +89,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("oracle/", "").replace(
                     "the oracle", ""), f"{f} mentions the oracle module"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: without libfpq_hip.so the loader raises, it does not degrade."""
+    from fpqvar_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libfpq_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib().fpq_version() == 100

@@ -596,3 +596,43 @@ def test_graph_capture_and_replay(dev, qu):
         assert_bits_equal(y2, orc.dual_per_group_kernel_sem(hn, "e1m2_neg", "e2m1_pos", 128, 1.0), "graph dual")
         assert_bits_equal(y3, orc.per_token_kernel_sem(xn, "e2m3"), "graph token")
         assert_bits_equal(y4, rot.rotate_quant(static_x, "e2m1"), "graph rotate")
+
+
+@pytest.mark.parametrize("C,L", ((1920, 40), (2304, 17)))
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+def test_adaln_rotate_quant_fused(dev, C, L, x_dtype):
+    """The whole producer (LN, AdaLN modulate, GALT smooth, rotate) + quant in one launch against
+    torch's own op chain on this GPU (tr/basic_var.py:263 under fp16 autocast) feeding the fused
+    rotate+quant of the previous test."""
+    from fpqvar_amd import rotation as rot
+    g = torch.Generator().manual_seed(81)
+    B = 3
+    x = (torch.randn(B, L, C, generator=g) * 2 + 0.3).to(x_dtype).to(dev)
+    scale = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    shift = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    s = (torch.rand(C, generator=g) * 1.5 + 0.25).to(dev)
+    out, h, y = rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s, return_intermediates=True)
+    assert_bits_equal(rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s), out, "emit vs no-emit")
+    # torch's chain, op for op (layer_norm runs in fp32 under autocast)
+    ln = torch.nn.functional.layer_norm(x.float(), (C,), eps=1e-6)
+    h_ref = ln.mul(scale.add(1)).add_(shift).mul(s).half()
+    d = _ulp_diff_f16(h.cpu(), h_ref.cpu())
+    assert int(d.max()) <= 1, f"h off by {int(d.max())} fp16 ulp"
+    assert float((d > 0).float().mean()) < 2e-3
+    # given h, the rest is exactly the fused rotate+quant kernel
+    out2, y2 = rot.rotate_quant(h, "e2m1", return_rotated=True)
+    assert_bits_equal(y, y2, "rotated")
+    assert_bits_equal(out, out2, "quantized")
+    assert_bits_equal(out, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "quant of rotated")
+    # end to end against torch chain + dense GEMM + quant: agreement rate
+    import fpqvar_amd.quant_utils as qu
+    with torch.autocast("cuda", dtype=torch.float16):
+        x1 = torch.matmul(ln.mul(scale.add(1)).add_(shift).mul(s),
+                          rot.block_random_hadamard_matrix(C, 128, dev, 42).float())
+    ref = qu.fp_quant_e2_per_group_cuda(x1, 4, 128)
+    agree = float((ref.view(torch.int16) == out.view(torch.int16)).float().mean())
+    assert agree > 0.97, agree
+    # fp32 modulation tensors and no smoothing
+    o3, h3, _ = rot.adaln_rotate_quant(x, scale.float(), shift.float(), "e2m3", return_intermediates=True)
+    h3_ref = ln.mul(scale.float().add(1)).add_(shift.float()).half()
+    assert int(_ulp_diff_f16(h3.cpu(), h3_ref.cpu()).max()) <= 1
