@@ -58,6 +58,33 @@ def main():
     res = {"shape": [ROWS, C], "A_gemm_plus_unfused_quant_ms": timeit(seq_a, 3), "B_gemm_plus_fused_quant_ms": timeit(seq_b),
            "C_fused_rotate_quant_ms": timeit(seq_c, 20), "gemm_only_ms": timeit(lambda: torch.matmul(nxt(), qh))}
     res["C_GBps_at_4B_per_elem"] = ROWS * C * 4 / (res["C_fused_rotate_quant_ms"] * 1e-3) / 1e9
+    # the complete producer (tr/basic_var.py:263): LN, AdaLN modulate, smooth, rotate, quant
+    B, L = 100, ROWS // 100
+    xb = [torch.randn(B, L, C, device=dev).half() for _ in range(3)]
+    scale = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+    shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+    s = torch.rand(C, device=dev) + 0.5
+
+    def nxb():
+        k[0] += 1
+        return xb[k[0] % len(xb)]
+
+    def chain_ref():
+        x = nxb()
+        with torch.autocast("cuda", dtype=torch.float16):
+            ln = torch.nn.functional.layer_norm(x, (C,), eps=1e-6)
+            x1 = torch.matmul(ln.mul(scale.add(1)).add_(shift).mul(s), q)
+        xs_ = x1.reshape(-1, 128)
+        sc = xs_.abs().max(dim=-1, keepdim=True)[0] / grid.abs().max()
+        xn = (xs_ / sc).view(-1).to(torch.float32)
+        z = ops.quant_nearest(xn, grid)
+        torch.zeros_like(xn)
+        return (z.view(xs_.shape) * sc).view(x1.shape).to(x1.dtype)
+
+    res["D_torch_producer_chain_gemm_unfused_quant_ms"] = timeit(chain_ref, 3)
+    res["E_fused_adaln_rotate_quant_ms"] = timeit(lambda: rot.adaln_rotate_quant(nxb(), scale, shift, "e2m1", smooth=s), 20)
+    res["E_rows"] = B * L
+    res["E_GBps_at_4B_per_elem"] = B * L * C * 4 / (res["E_fused_adaln_rotate_quant_ms"] * 1e-3) / 1e9
     print(json.dumps(res))
 
 
