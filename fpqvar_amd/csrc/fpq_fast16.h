@@ -57,6 +57,10 @@ __device__ __forceinline__ uint32_t pk_ashr_i16(uint32_t a, int n) {
   s2_t r = __builtin_bit_cast(s2_t, a) >> (int16_t)n;
   return __builtin_bit_cast(uint32_t, r);
 }
+__device__ __forceinline__ uint32_t pk_add_f16(uint32_t a, uint32_t b) {
+  h2_t r = __builtin_bit_cast(h2_t, a) + __builtin_bit_cast(h2_t, b);
+  return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ uint32_t pk_mul_f16(uint32_t a, uint32_t b) {
   h2_t r = __builtin_bit_cast(h2_t, a) * __builtin_bit_cast(h2_t, b);
   return __builtin_bit_cast(uint32_t, r);
@@ -501,26 +505,41 @@ struct AdaLnArgs {
   int64_t cols;
 };
 
-__device__ __forceinline__ float block_sum_f32(float v, float* sh) {
+__device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = sh[0];
-#pragma unroll
-  for (int i = 1; i < kBlock / 64; ++i) r += sh[i];
-  return r;
+  return v;
 }
 
-template <typename Tin, int MAXC>
+// One WAVEFRONT per token row (64 lanes x MAXC vectors of 8 channels, C <= 64*8*MAXC): no LDS
+// traffic and no workgroup barrier after the table is staged; the modulation vectors of the
+// row are requested together with x so that their latency hides behind the two reductions.
+template <int LANES>
+__device__ __forceinline__ float row_sum_f32(float v, float* sh) {
+  v = wave_sum_f32(v);
+  if constexpr (LANES == 64) {
+    return v;
+  } else {   // the whole workgroup owns the row
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int i = 1; i < kBlock / 64; ++i) r += sh[i];
+    return r;
+  }
+}
+
+template <typename Tin, typename Tmod, int LANES, int MAXC>
 __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void* __restrict__ xv,
                                                                      u32x4* __restrict__ out, u32x4* __restrict__ h_out,
                                                                      u32x4* __restrict__ y_out, int64_t rows,
                                                                      AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
   __shared__ float shf[kBlock / 64];
-  const int lg = threadIdx.x & 15;
+  constexpr bool MOD16 = sizeof(Tmod) == 2;
+  const int lane = threadIdx.x & (LANES - 1);
+  const int lg = lane & 15;
   const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
   uint32_t sx[4];
 #pragma unroll
@@ -528,96 +547,139 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
   {
     const int n = 1 << (16 - a.shift);
     for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
-  }   // ordered before first use by the barriers of block_sum_f32
+    __syncthreads();
+  }
   const int64_t vpr = r.vec_per_row;
   const float inv_c = 1.0f / (float)ad.cols;
-  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-    float f[MAXC][8];
-    float s1 = 0.0f;
+  // a workgroup walks rows blockIdx.x*R + sub, (blockIdx.x + gridDim.x)*R + sub, ... (R rows per pass);
+  // the trip count is uniform over the workgroup, rows beyond the end are skipped by `row_live`
+  constexpr int R = kBlock / LANES;
+  for (int64_t base = (int64_t)blockIdx.x * R; base < rows; base += (int64_t)gridDim.x * R) {
+  const int64_t row_raw = base + (threadIdx.x / LANES);
+  const bool row_live = row_raw < rows;
+  const int64_t row = row_live ? row_raw : rows - 1;   // dead wavefronts recompute the last row, stores masked
+  const int64_t b = row / ad.rows_per_batch;
+
+  float f[MAXC][8];
+  constexpr int MV = MOD16 ? 1 : 2;
+  u32x4 m_sc[MAXC][MV], m_sh[MAXC][MV];   // raw modulation vectors, requested together with x
+  float s1 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const int64_t v = (int64_t)c * kBlock + threadIdx.x;
-      const bool live = v < vpr;
-      if constexpr (sizeof(Tin) == 2) {
-        u32x4 w = live ? __builtin_nontemporal_load((const u32x4*)xv + row * vpr + v) : u32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          f[c][2 * k] = h2f(w[k] & 0xFFFFu);
-          f[c][2 * k + 1] = h2f(w[k] >> 16);
-        }
-      } else {
-        u32x4 lo = live ? __builtin_nontemporal_load((const u32x4*)xv + 2 * (row * vpr + v)) : u32x4{0, 0, 0, 0};
-        u32x4 hi = live ? __builtin_nontemporal_load((const u32x4*)xv + 2 * (row * vpr + v) + 1) : u32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          f[c][k] = u2f(lo[k]);
-          f[c][4 + k] = u2f(hi[k]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s1 += f[c][i];
-    }
-    const float mean = block_sum_f32(s1, shf) * inv_c;
-    float s2 = 0.0f;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const bool live = (int64_t)c * kBlock + threadIdx.x < vpr;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float d = f[c][i] - mean;
-        f[c][i] = d;
-        s2 += live ? d * d : 0.0f;
-      }
-    }
-    const float var = block_sum_f32(s2, shf) * inv_c;
-    const float rstd = 1.0f / __builtin_sqrtf(var + ad.eps);
-    const int64_t b = row / ad.rows_per_batch;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const int64_t v = (int64_t)c * kBlock + threadIdx.x;
-      const bool live = v < vpr;
-      float t[8];
-      if (live) {
-        const int64_t col = v * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float sc, sh;
-          if (ad.mod_is_f16) {
-            sc = h2f(f2h(h2f(((const uint16_t*)ad.scale)[b * ad.cols + col + i]) + 1.0f));   // scale.add(1) in fp16
-            sh = h2f(((const uint16_t*)ad.shift)[b * ad.cols + col + i]);
-          } else {
-            sc = ((const float*)ad.scale)[b * ad.cols + col + i] + 1.0f;
-            sh = ((const float*)ad.shift)[b * ad.cols + col + i];
-          }
-          float ln = f[c][i] * rstd;
-          float u1 = ln * sc;
-          float u2 = u1 + sh;
-          if (r.smooth) u2 = u2 * r.smooth[col + i];
-          t[i] = u2;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = 0.0f;
-      }
-      u32x4 hw;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) hw[k] = f2h(t[2 * k]) | (f2h(t[2 * k + 1]) << 16);
-      if (h_out && live) __builtin_nontemporal_store(hw, h_out + row * vpr + v);
+  for (int c = 0; c < MAXC; ++c) {
+    const int64_t v = (int64_t)c * LANES + lane;
+    const bool live = v < vpr;
+    const int64_t col = v * 8;
+    if constexpr (sizeof(Tin) == 2) {
+      u32x4 w = live ? __builtin_nontemporal_load((const u32x4*)xv + row * vpr + v) : u32x4{0, 0, 0, 0};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        uint32_t w = hw[k] ^ sx[k];
-        t[2 * k] = h2f(w & 0xFFFFu);
-        t[2 * k + 1] = h2f(w >> 16);
+        f[c][2 * k] = h2f(w[k] & 0xFFFFu);
+        f[c][2 * k + 1] = h2f(w[k] >> 16);
       }
-      fwht128(t, lg);
-      u32x4 y;
+    } else {
+      u32x4 lo = live ? __builtin_nontemporal_load((const u32x4*)xv + 2 * (row * vpr + v)) : u32x4{0, 0, 0, 0};
+      u32x4 hi = live ? __builtin_nontemporal_load((const u32x4*)xv + 2 * (row * vpr + v) + 1) : u32x4{0, 0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = f2h(t[2 * k] * r.c_h) | (f2h(t[2 * k + 1] * r.c_h) << 16);
-      if (y_out && live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
-      uint32_t m = row_max_dpp<16>(vec_absmax16(y));
-      RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
-      if (live) __builtin_nontemporal_store(o, out + row * vpr + v);
+      for (int k = 0; k < 4; ++k) {
+        f[c][k] = u2f(lo[k]);
+        f[c][4 + k] = u2f(hi[k]);
+      }
     }
+#pragma unroll
+    for (int j = 0; j < MV; ++j) m_sc[c][j] = m_sh[c][j] = u32x4{0, 0, 0, 0};
+    if (live) {
+      const u32x4* ap = (const u32x4*)((const Tmod*)ad.scale + b * ad.cols + col);
+      const u32x4* bp = (const u32x4*)((const Tmod*)ad.shift + b * ad.cols + col);
+#pragma unroll
+      for (int j = 0; j < MV; ++j) {
+        m_sc[c][j] = ap[j];
+        m_sh[c][j] = bp[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1 += f[c][i];
   }
+  const float mean = row_sum_f32<LANES>(s1, shf) * inv_c;
+  float s2 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const bool live = (int64_t)c * LANES + lane < vpr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float d = f[c][i] - mean;
+      f[c][i] = d;
+      s2 = __builtin_fmaf(d, d, s2);
+    }
+    if (!live) s2 -= 8.0f * mean * mean;   // padding lanes hold zeros: take their (0 - mean)^2 back out
+  }
+  const float var = row_sum_f32<LANES>(s2, shf) * inv_c;
+  const float rstd = 1.0f / __builtin_sqrtf(var + ad.eps);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int64_t v = (int64_t)c * LANES + lane;
+    const bool live = v < vpr;
+    float t[8];
+    if (live) {
+      const int64_t col = v * 8;
+      float sc[8], sh[8], sm[8];
+      if constexpr (MOD16) {   // scale.add(1) is an fp16 op in the reference
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t s1p = pk_add_f16(m_sc[c][0][k], 0x3C003C00u);   // scale + 1 as a (packed) fp16 add
+          sc[2 * k] = h2f(s1p & 0xFFFFu);
+          sc[2 * k + 1] = h2f(s1p >> 16);
+          sh[2 * k] = h2f(m_sh[c][0][k] & 0xFFFFu);
+          sh[2 * k + 1] = h2f(m_sh[c][0][k] >> 16);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sc[k] = u2f(m_sc[c][0][k]) + 1.0f;
+          sc[4 + k] = u2f(m_sc[c][MV - 1][k]) + 1.0f;
+          sh[k] = u2f(m_sh[c][0][k]);
+          sh[4 + k] = u2f(m_sh[c][MV - 1][k]);
+        }
+      }
+      if (r.smooth) {
+        const u32x4* sp = (const u32x4*)(r.smooth + col);
+        u32x4 s0 = sp[0], s1v = sp[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sm[k] = u2f(s0[k]);
+          sm[4 + k] = u2f(s1v[k]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float ln = f[c][i] * rstd;
+        float u1 = ln * sc[i];
+        float u2 = u1 + sh[i];
+        if (r.smooth) u2 = u2 * sm[i];
+        t[i] = u2;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = 0.0f;
+    }
+    u32x4 hw;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hw[k] = f2h(t[2 * k]) | (f2h(t[2 * k + 1]) << 16);
+    if (h_out && live && row_live) __builtin_nontemporal_store(hw, h_out + row * vpr + v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t w = hw[k] ^ sx[k];
+      t[2 * k] = h2f(w & 0xFFFFu);
+      t[2 * k + 1] = h2f(w >> 16);
+    }
+    fwht128(t, lg);
+    u32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = f2h(t[2 * k] * r.c_h) | (f2h(t[2 * k + 1] * r.c_h) << 16);
+    if (y_out && live && row_live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
+    uint32_t m = row_max_dpp<16>(vec_absmax16(y));
+    RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+    u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+    if (live && row_live) __builtin_nontemporal_store(o, out + row * vpr + v);
+  }
+  }   // row loop
 }

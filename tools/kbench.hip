@@ -175,6 +175,11 @@ int main(int argc, char** argv) {
   add("dual fp4 U1", [&] { launch_fast16<true, 1>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st); });
   add("dual fp4 U2", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st); });
   add("dual fp4 U4", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st); });
+  add("dual fp4 U2 cap4096", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st, 4096); });
+  add("dual fp4 U2 cap8192", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st, 8192); });
+  add("dual fp4 U2 cap16384", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st, 16384); });
+  add("dual fp4 U4 cap8192", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st, 8192); });
+  add("sym e2m1 U2 cap16384", [&] { launch_fast16<false, 2>(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_E2M1, st, 16384); });
   static uint32_t* dflag = nullptr; if (!dflag) CK(hipMalloc(&dflag, 4));
   add("dual fp4 U2 +nanflag", [&] { fpq_quant_rows_dual(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, FPQ_F16, FPQ_F16, nullptr, 1.f, dflag, st); });
   add("fast dualfp6 U4 (fill)", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st); });

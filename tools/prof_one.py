@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Run ONE kernel a few times (for rocprofv3 --pmc passes).  usage: prof_one.py {adaln|rotate|dual|sym}"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from fpqvar_amd import ops, quant_utils as qu, rotation as rot  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "sym"
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+C = 1920
+if which == "adaln":
+    B, L = 100, 655
+    x = torch.randn(B, L, C, device=dev).half()
+    scale = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+    shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+    s = torch.rand(C, device=dev) + 0.5
+    fn = lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s)
+elif which == "rotate":
+    x = torch.randn(65536, C, device=dev).half()
+    fn = lambda: rot.rotate_quant(x, "e2m1")
+elif which == "dual":
+    x = torch.nn.functional.gelu(torch.randn(65536, C, device=dev)).half()
+    fn = lambda: ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", 128, None)
+else:
+    x = torch.randn(65536, C, device=dev).half()
+    fn = lambda: qu.fp_quant_e2_per_group_cuda(x, 4, 128)
+for _ in range(5):
+    fn()
+torch.cuda.synchronize()
