@@ -121,10 +121,20 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
       s1 = n1 ? sf_n : sf_p;  i1 = n1 ? inv_n : inv_p;
       sc = (n0 ? (s16x2_n & 0xFFFFu) : (s16x2_p & 0xFFFFu)) | (n1 ? (s16x2_n & 0xFFFF0000u) : (s16x2_p & 0xFFFF0000u));
     }
+#if defined(FPQ_PKDIV) && FPQ_PKDIV
+    // the two elements of the word go through the packed fp32 ALU together
+    typedef float f2q_t __attribute__((ext_vector_type(2)));
+    const f2q_t xx = {x0, x1}, ii = {i0, i1}, ss = {s0, s1};
+    const f2q_t yy = xx * ii;
+    const f2q_t ee = __builtin_elementwise_fma(-yy, ss, xx);
+    const f2q_t rr = __builtin_elementwise_fma(ee, ii, yy);
+    uint32_t rb = f2h(rr.x) | (f2h(rr.y) << 16);
+#else
     float y0 = x0 * i0, y1 = x1 * i1;
     float e0 = __builtin_fmaf(-y0, s0, x0), e1 = __builtin_fmaf(-y1, s1, x1);
     float r0 = __builtin_fmaf(e0, i0, y0), r1 = __builtin_fmaf(e1, i1, y1);
     uint32_t rb = f2h(r0) | (f2h(r1) << 16);
+#endif
     uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
     uint32_t q0 = lut[(u & 0xFFFFu) >> shift];
     uint32_t q1 = lut[u >> (16 + shift)];
@@ -383,30 +393,43 @@ __device__ __forceinline__ float xlane_xor2(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
-// FWHT over the 128 values held by 16 lanes x 8 registers; natural (Sylvester) order
+// FWHT over the 128 values held by 16 lanes x 8 registers; natural (Sylvester) order.
+// The values travel as 4 float pairs (t[j], t[j+4]) so that the butterflies map onto the
+// packed fp32 ALU (v_pk_add_f32 / v_pk_fma_f32: two results per issue slot).
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2_t xlane2(f2_t v, int which) {
+  f2_t r;
+  if (which == 1) { r.x = xlane_xor1(v.x); r.y = xlane_xor1(v.y); }
+  else if (which == 2) { r.x = xlane_xor2(v.x); r.y = xlane_xor2(v.y); }
+  else if (which == 4) { r.x = xlane_xor4(v.x); r.y = xlane_xor4(v.y); }
+  else { r.x = xlane_xor8(v.x); r.y = xlane_xor8(v.y); }
+  return r;
+}
+
 __device__ __forceinline__ void fwht128(float (&t)[8], int lane_in_group) {
+  f2_t p[4];
 #pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
+  for (int j = 0; j < 4; ++j) p[j] = f2_t{t[j], t[j + 4]};
+  // index bit 0 and bit 1: whole pairs against whole pairs
+  { f2_t a = p[0], b = p[1]; p[0] = a + b; p[1] = a - b; a = p[2]; b = p[3]; p[2] = a + b; p[3] = a - b; }
+  { f2_t a = p[0], b = p[2]; p[0] = a + b; p[2] = a - b; a = p[1]; b = p[3]; p[1] = a + b; p[3] = a - b; }
+  // index bit 2: inside each pair
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if ((i & m) == 0) {
-        float a = t[i], b = t[i | m];
-        t[i] = a + b;
-        t[i | m] = a - b;
-      }
-    }
-  }
+  for (int j = 0; j < 4; ++j) p[j] = f2_t{p[j].x + p[j].y, p[j].x - p[j].y};
+  // index bits 3..6 live in the lane number: partner + sign*mine (lower lane a+b, upper lane a-b)
   const float s1 = (lane_in_group & 1) ? -1.0f : 1.0f, s2 = (lane_in_group & 2) ? -1.0f : 1.0f;
   const float s4 = (lane_in_group & 4) ? -1.0f : 1.0f, s8 = (lane_in_group & 8) ? -1.0f : 1.0f;
-  // partner + sign*mine: the lower lane gets a+b, the upper lane a-b (both exact as a sum of two terms)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s1, xlane_xor1(t[i]));
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], f2_t{s1, s1}, xlane2(p[j], 1));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s2, xlane_xor2(t[i]));
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], f2_t{s2, s2}, xlane2(p[j], 2));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s4, xlane_xor4(t[i]));
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], f2_t{s4, s4}, xlane2(p[j], 4));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = __builtin_fmaf(t[i], s8, xlane_xor8(t[i]));
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], f2_t{s8, s8}, xlane2(p[j], 8));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { t[j] = p[j].x; t[j + 4] = p[j].y; }
 }
 
 template <typename Tin, bool EMIT, int U>
