@@ -66,6 +66,29 @@ __device__ __forceinline__ uint32_t pk_mul_f16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, r);
 }
 
+// two fp32 values -> packed fp16 pair with ONE v_cvt_pk_f16_f32 (round to nearest even).  The
+// asm barrier keeps both values as rounded fp32 numbers first (see f2h in fpq_kernels.hip).
+__device__ __forceinline__ uint32_t f2h2(float lo, float hi) {
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  typedef float f2c_t __attribute__((ext_vector_type(2)));
+  h2_t r = __builtin_convertvector(f2c_t{lo, hi}, h2_t);
+  return __builtin_bit_cast(uint32_t, r);
+}
+
+// (float)half_lo(w) * b and (float)half_hi(w) * b in one v_fma_mix_f32 each: the fp16 -> fp32
+// widening rides on the multiply.  The addend is +0, which only differs from a plain product
+// when the product is -0 (x = -0.0); every use below maps +-0 to the same table bucket.
+__device__ __forceinline__ float mul_h_lo(uint32_t w, float b) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float mul_h_hi(uint32_t w, float b) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b));
+  return d;
+}
+
 // max over the LPR lanes that own a row; LPR lanes are contiguous and LPR-aligned
 template <int LPR>
 __device__ __forceinline__ uint32_t row_max_dpp(uint32_t v) {
@@ -130,10 +153,10 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
     const f2q_t rr = __builtin_elementwise_fma(ee, ii, yy);
     uint32_t rb = f2h(rr.x) | (f2h(rr.y) << 16);
 #else
-    float y0 = x0 * i0, y1 = x1 * i1;
+    float y0 = mul_h_lo(wk, i0), y1 = mul_h_hi(wk, i1);
     float e0 = __builtin_fmaf(-y0, s0, x0), e1 = __builtin_fmaf(-y1, s1, x1);
     float r0 = __builtin_fmaf(e0, i0, y0), r1 = __builtin_fmaf(e1, i1, y1);
-    uint32_t rb = f2h(r0) | (f2h(r1) << 16);
+    uint32_t rb = f2h2(r0, r1);
 #endif
     uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
     uint32_t q0 = lut[(u & 0xFFFFu) >> shift];
@@ -496,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __re
       fwht128(t, lg);
       u32x4 y;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = f2h(t[2 * k] * r.c_h) | (f2h(t[2 * k + 1] * r.c_h) << 16);
+      for (int k = 0; k < 4; ++k) y[k] = f2h2(t[2 * k] * r.c_h, t[2 * k + 1] * r.c_h);
       if (EMIT && live[u]) __builtin_nontemporal_store(y, rot_out + v0 + u * kBlock);
       uint32_t m = row_max_dpp<16>(vec_absmax16(y));
       RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
@@ -686,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
     }
     u32x4 hw;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hw[k] = f2h(t[2 * k]) | (f2h(t[2 * k + 1]) << 16);
+    for (int k = 0; k < 4; ++k) hw[k] = f2h2(t[2 * k], t[2 * k + 1]);
     if (h_out && live && row_live) __builtin_nontemporal_store(hw, h_out + row * vpr + v);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -697,7 +720,7 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
     fwht128(t, lg);
     u32x4 y;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) y[k] = f2h(t[2 * k] * r.c_h) | (f2h(t[2 * k + 1] * r.c_h) << 16);
+    for (int k = 0; k < 4; ++k) y[k] = f2h2(t[2 * k] * r.c_h, t[2 * k + 1] * r.c_h);
     if (y_out && live && row_live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
     uint32_t m = row_max_dpp<16>(vec_absmax16(y));
     RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
