@@ -295,6 +295,59 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
   }
 }
 
+// Same rows, but LPR lanes own a row of 2*LPR vectors (two 16-byte vectors per lane, LPR*16 bytes
+// apart): the per-row work - cross-lane max, scale, reciprocal - is paid once per 16 elements of a
+// lane instead of once per 8.  Every load / store instruction still touches whole 128-byte lines
+// (LPR = 8: eight lanes x 16 B).  Used for the 128-element groups.
+template <int LPR, bool DUAL, bool TAB_ARG>
+__global__ __launch_bounds__(kBlock) void rows16_lut_pair_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
+                                                                int64_t n_vec, Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  constexpr int64_t kTile = (int64_t)kBlock * 2;
+  const int64_t tiles = (n_vec + kTile - 1) / kTile;
+  const int in_row = threadIdx.x % LPR, row_in_tile = threadIdx.x / LPR;
+  bool first = true;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t va = tile * kTile + (int64_t)row_in_tile * (2 * LPR) + in_row;
+    const int64_t vb = va + LPR;
+    const bool live = va < n_vec;   // n_vec is a multiple of 2*LPR: both vectors live or both dead
+    u32x4 ra = live ? __builtin_nontemporal_load(x + va) : u32x4{0, 0, 0, 0};
+    u32x4 rb = live ? __builtin_nontemporal_load(x + vb) : u32x4{0, 0, 0, 0};
+    if (first) {
+      if (TAB_ARG) {
+        const int n = 1 << (16 - a.shift);
+        for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+      } else {
+        lut16_fill(lut, a);
+      }
+      __syncthreads();
+      first = false;
+    }
+    u32x4 oa, ob;
+    if (DUAL) {
+      uint32_t mn, mp, mn2, mp2;
+      const uint32_t nan_any = vec_absmax16_dual(ra, mn, mp) | vec_absmax16_dual(rb, mn2, mp2);
+      if (nan_any && a.nan_flag) atomicOr(a.nan_flag, 1u);
+      mn = row_max_dpp<LPR>(mn > mn2 ? mn : mn2);
+      mp = row_max_dpp<LPR>(mp > mp2 ? mp : mp2);
+      RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
+      dual_poison(sn, sp);
+      oa = quant_vec16<true>(ra, lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+      ob = quant_vec16<true>(rb, lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+    } else {
+      const uint32_t m1 = vec_absmax16(ra), m2 = vec_absmax16(rb);
+      const uint32_t m = row_max_dpp<LPR>(m1 > m2 ? m1 : m2);
+      RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      oa = quant_vec16<false>(ra, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      ob = quant_vec16<false>(rb, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+    }
+    if (live) {
+      __builtin_nontemporal_store(oa, out + va);
+      __builtin_nontemporal_store(ob, out + vb);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // long fp16 rows (per-token 1920 / 7680 / 2304 / 9216, per-channel weights in fp16):
 // one workgroup walks a contiguous run of rows; a row's vectors stay in registers

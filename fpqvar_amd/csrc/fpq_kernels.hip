@@ -954,6 +954,24 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
 }
 
 template <bool DUAL>
+int launch_fast16_pair8(const void* x, void* out, int64_t rows, int neg_id, int pos_id, hipStream_t st,
+                        uint32_t* nan_flag = nullptr) {
+  const Lut16Host& h = lut16_host(neg_id, pos_id);
+  Lut16Args args = h.args;
+  args.nan_flag = nan_flag;
+  const int64_t n_vec = rows * 16;   // rows of 128 halves
+  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const int64_t tiles = (n_vec + (int64_t)kBlock * 2 - 1) / ((int64_t)kBlock * 2);
+  if (h.tab_valid)
+    hipLaunchKernelGGL((rows16_lut_pair_kernel<8, DUAL, true>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st,
+                       (const u32x4*)x, (u32x4*)out, n_vec, args, h.tab);
+  else
+    hipLaunchKernelGGL((rows16_lut_pair_kernel<8, DUAL, false>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st,
+                       (const u32x4*)x, (u32x4*)out, n_vec, args, h.tab);
+  return check_launch();
+}
+
+template <bool DUAL>
 int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id,
                         hipStream_t st, uint32_t* nan_flag = nullptr) {
   const Lut16Host& h = lut16_host(neg_id, pos_id);
@@ -1103,7 +1121,12 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   if (flag && hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return FPQ_ERR_LAUNCH;
   int rc;
   if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
-    rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag);
+    // int_neg/e2m3_pos needs a 2048-entry table (too big for the kernel arguments): every workgroup
+    // evaluates it once, so give each workgroup many tiles (measured: 88 us vs 127 us with a full grid)
+    if (lut16_host(neg_table, pos_table).tab_valid)
+      rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag);
+    else
+      rc = launch_fast16<true, 4>(x, out, rows, cols, neg_table, pos_table, st, 4096, flag);
   } else if (!clip_absmax && fast16_block_eligible(x, out, cols, in_dtype, out_dtype)) {
     rc = launch_fast16_block<true>(x, out, rows, cols, neg_table, pos_table, st, flag);
   } else {

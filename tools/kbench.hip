@@ -180,6 +180,14 @@ int main(int argc, char** argv) {
   add("dual fp4 U2 cap16384", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st, 16384); });
   add("dual fp4 U4 cap8192", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st, 8192); });
   add("sym e2m1 U2 cap16384", [&] { launch_fast16<false, 2>(X(), O(), n / 128, 128, FPQ_E2M1, FPQ_E2M1, st, 16384); });
+  add("dualfp6 U2 cap2048", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st, 2048); });
+  add("dualfp6 U2 cap4096", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st, 4096); });
+  add("dualfp6 U4 cap4096", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st, 4096); });
+  add("dualfp6 U2 cap8192", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st, 8192); });
+  add("dualfp6 U2 full", [&] { launch_fast16<true, 2>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st); });
+  add("PAIR8 sym e2m1", [&] { launch_fast16_pair8<false>(X(), O(), n / 128, FPQ_E2M1, FPQ_E2M1, st); });
+  add("PAIR8 dual fp4", [&] { launch_fast16_pair8<true>(X(), O(), n / 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, st); });
+  add("PAIR8 dual fp6 (fill)", [&] { launch_fast16_pair8<true>(X(), O(), n / 128, FPQ_INT_NEG, FPQ_E2M3_POS, st); });
   static uint32_t* dflag = nullptr; if (!dflag) CK(hipMalloc(&dflag, 4));
   add("dual fp4 U2 +nanflag", [&] { fpq_quant_rows_dual(X(), O(), n / 128, 128, FPQ_E1M2_NEG, FPQ_E2M1_POS, FPQ_F16, FPQ_F16, nullptr, 1.f, dflag, st); });
   add("fast dualfp6 U4 (fill)", [&] { launch_fast16<true, 4>(X(), O(), n / 128, 128, FPQ_INT_NEG, FPQ_E2M3_POS, st); });
