@@ -430,6 +430,72 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
   }
 }
 
+// Medium rows (<= 64*MAXC vectors, e.g. per-token 1920 = 240 vectors): one WAVEFRONT per row, the
+// row max by DPP/shuffles only - no LDS, no barrier in the row loop.
+template <bool DUAL, int MAXC, bool TAB_ARG>
+__global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t* __restrict__ x,
+                                                                uint16_t* __restrict__ out, int64_t rows, int64_t cols,
+                                                                Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  if (TAB_ARG) {
+    const int n = 1 << (16 - a.shift);
+    for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+  } else {
+    lut16_fill(lut, a);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t vpr = cols >> 3;
+  constexpr int R = kBlock / 64;
+  for (int64_t base = (int64_t)blockIdx.x * R; base < rows; base += (int64_t)gridDim.x * R) {
+    const int64_t row = base + (threadIdx.x >> 6);
+    if (row >= rows) continue;   // whole wavefront skips
+    const u32x4* xr = (const u32x4*)(x + row * cols);
+    u32x4* orow = (u32x4*)(out + row * cols);
+    u32x4 raw[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t v = (int64_t)c * 64 + lane;
+      raw[c] = (v < vpr) ? __builtin_nontemporal_load(xr + v) : u32x4{0, 0, 0, 0};
+    }
+    RowScale16 sn, sp;
+    if (DUAL) {
+      uint32_t mn = 0, mp = 0, nan_any = 0;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        uint32_t a1, b1;
+        nan_any |= vec_absmax16_dual(raw[c], a1, b1);
+        mn = mn > a1 ? mn : a1;
+        mp = mp > b1 ? mp : b1;
+      }
+      if (nan_any && a.nan_flag) atomicOr(a.nan_flag, 1u);
+      mn = row_max_dpp<64>(mn);
+      mp = row_max_dpp<64>(mp);
+      sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg);
+      sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
+      dual_poison(sn, sp);
+    } else {
+      uint32_t m = 0;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        uint32_t t = vec_absmax16(raw[c]);
+        m = m > t ? m : t;
+      }
+      m = row_max_dpp<64>(m);
+      sn = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      sp = sn;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t v = (int64_t)c * 64 + lane;
+      if (v < vpr) {
+        u32x4 o = quant_vec16<DUAL>(raw[c], lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+        __builtin_nontemporal_store(o, orow + v);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // F1: the online rotate fused in front of the per-group quant.
 //

@@ -979,9 +979,26 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   args.nan_flag = nan_flag;
   const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
   const int64_t vec_per_row = cols / 8;
+  if (vec_per_row <= 64 * 5 && !getenv("FPQ_NO_WAVE_ROWS")) {
+    // one wavefront per row: 4 rows per workgroup pass, enough workgroups to keep every CU busy while the
+    // table staging stays amortised
+    const int mc = (int)((vec_per_row + 63) / 64);
+    int64_t g = (rows + 3) / 4;
+    const int64_t capw = h.tab_valid ? 16384 : 2048;
+    if (g > capw) g = capw;
+#define FPQ_WAVE(M) do { if (h.tab_valid) hipLaunchKernelGGL((rows16_lut_wave_kernel<DUAL, M, true>), dim3((unsigned)g), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out, rows, cols, args, h.tab); \
+                         else hipLaunchKernelGGL((rows16_lut_wave_kernel<DUAL, M, false>), dim3((unsigned)g), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out, rows, cols, args, h.tab); } while (0)
+    if (mc <= 1) FPQ_WAVE(1);
+    else if (mc <= 2) FPQ_WAVE(2);
+    else if (mc <= 4) FPQ_WAVE(4);
+    else FPQ_WAVE(5);
+#undef FPQ_WAVE
+    return check_launch();
+  }
   const int maxc = (int)((vec_per_row + kBlock - 1) / kBlock);
   // enough workgroups to fill the chip several times over, each walking consecutive rows
-  int64_t rpb = (rows + 16383) / 16384;
+  const int64_t target_wgs = h.tab_valid ? 16384 : 2048;   // table evaluated per workgroup when it is not an argument
+  int64_t rpb = (rows + target_wgs - 1) / target_wgs;
   if (rpb < 1) rpb = 1;
   const int64_t grid = (rows + rpb - 1) / rpb;
   auto go = [&](auto kern_tab, auto kern_fill) {
