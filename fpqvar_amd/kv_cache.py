@@ -41,3 +41,46 @@ def update_kv_cache(cached_k: Optional[torch.Tensor], cached_v: Optional[torch.T
             assert not torch.isnan(v).any(), "Tensor contains NaN values!"
             assert not torch.isinf(v).any(), "Tensor contains inf values!"
     return torch.cat((cached_k, k), dim=dim_cat), torch.cat((cached_v, v), dim=dim_cat)
+
+
+class IncrementalKVCache:
+    """F3: the same K / V the reference's re-quantize-everything loop produces,
+    with every cache entry quantized exactly ONCE.
+
+    Why this is exact: re-quantizing an already fake-quantized row returns it unchanged (same scale,
+    same levels) whenever the row's fp16 scale is a normal number, i.e. max|row| >= ~4e-4 - proven by
+    exhaustion over every fp16 row maximum and every level in tests/test_kv_idempotence.py.  The
+    reference quantizes the cache BEFORE appending the new k / v (tr/basic_var.py:192-209), so at
+    step t the entries of step t-1 are quantized for the first time and all older ones are
+    re-quantized to themselves; here only the former happens.  Rows below that magnitude (not seen
+    with unit-norm keys / O(1) values) may differ in their last bits.
+
+    Layout: flash layout [B, L, H, c] (`dim_cat` = 1), as the reference's published KV runs use; with
+    kv_bit 4 a 128-group then never straddles tokens as long as H*c is a multiple of 128.
+    Buffers are allocated once for `max_len` tokens; `append` returns views of the filled prefix.
+    """
+
+    def __init__(self, batch: int, max_len: int, heads: int, head_dim: int, kv_bit: int,
+                 dtype=torch.float16, device="cuda"):
+        assert kv_bit in (4, 6)
+        assert kv_bit == 6 or (heads * head_dim) % 128 == 0
+        self.kv_bit = kv_bit
+        self.k = torch.empty(batch, max_len, heads, head_dim, dtype=dtype, device=device)
+        self.v = torch.empty_like(self.k)
+        self.len = 0
+        self._pending = None        # (start, stop, quantized k, quantized v) of the previous step's entries
+
+    @torch.no_grad()
+    def append(self, k: torch.Tensor, v: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        n = k.shape[1]
+        assert self.len + n <= self.k.shape[1], "IncrementalKVCache: max_len exceeded"
+        if self._pending is not None:             # what the reference's quantize-the-cache does NEW work on
+            a, b, qk, qv = self._pending
+            self.k[:, a:b].copy_(qk)
+            self.v[:, a:b].copy_(qv)
+        self.k[:, self.len:self.len + n].copy_(k)
+        self.v[:, self.len:self.len + n].copy_(v)
+        kc, vc = k.contiguous(), v.contiguous()
+        self._pending = (self.len, self.len + n, quantize_kv(kc, self.kv_bit), quantize_kv(vc, self.kv_bit))
+        self.len += n
+        return self.k[:, :self.len], self.v[:, :self.len]

@@ -645,3 +645,22 @@ def test_adaln_rotate_quant_fused(dev, C, L, x_dtype):
     o3, h3, _ = rot.adaln_rotate_quant(x, scale.float(), shift.float(), "e2m3", return_intermediates=True)
     h3_ref = ln.mul(scale.float().add(1)).add_(shift.float()).half()
     assert float((_ulp_diff_f16(h3.cpu(), h3_ref.cpu()) > 0).float().mean()) < 2e-3
+
+
+@pytest.mark.parametrize("kv_bit", (6, 4))
+def test_incremental_kv_equals_requantize_everything(dev, kv_bit):
+    """10 scale steps of VAR's KV cache: quantizing each entry once (IncrementalKVCache) reproduces the
+    reference's re-quantize-the-whole-cache loop bit for bit (see tests/test_kv_idempotence.py)."""
+    from fpqvar_amd import kv_cache as kv
+    g = torch.Generator().manual_seed(91)
+    B, H, c = 6, 30, 64
+    patch = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
+    inc = kv.IncrementalKVCache(B, sum(p * p for p in patch), H, c, kv_bit, device=dev)
+    ck = cv = None
+    for pn in patch:
+        k = torch.nn.functional.normalize(torch.randn(B, pn * pn, H, c, generator=g), dim=-1).half().to(dev)
+        v = torch.randn(B, pn * pn, H, c, generator=g).half().to(dev)
+        ck, cv = kv.update_kv_cache(ck, cv, k, v, True, kv_bit, 1)       # the reference's O(L^2) loop
+        ik, iv = inc.append(k, v)
+        assert_bits_equal(ik.contiguous(), ck, f"K step pn={pn}")
+        assert_bits_equal(iv.contiguous(), cv, f"V step pn={pn}")
