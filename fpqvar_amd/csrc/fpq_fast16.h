@@ -403,8 +403,20 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
         mn = mn > a1 ? mn : a1;
         mp = mp > b1 ? mp : b1;
       }
-      mn = block_max16(mn, sh);
-      mp = block_max16(mp, sh);
+      // both maxima through one LDS exchange (one barrier pair instead of two)
+      mn = row_max_dpp<64>(mn);
+      mp = row_max_dpp<64>(mp);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (mn << 16) | mp;
+      __syncthreads();
+      mn = 0;
+      mp = 0;
+#pragma unroll
+      for (int i = 0; i < kBlock / 64; ++i) {
+        const uint32_t w = sh[i];
+        mn = mn > (w >> 16) ? mn : (w >> 16);
+        mp = mp > (w & 0xFFFFu) ? mp : (w & 0xFFFFu);
+      }
       sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg);
       sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
       dual_poison(sn, sp);
