@@ -44,6 +44,10 @@ _SIGS = {
     "fpq_absmax": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "fpq_quant_rows_codes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                          _c.c_int, _c.c_int, _c.c_void_p]),
+    "fpq_quant_rows_codes_mx": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                            _c.c_void_p]),
+    "fpq_gemm_fp4_mx": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                    _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p]),
     "fpq_dequant_rows_codes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                            _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }

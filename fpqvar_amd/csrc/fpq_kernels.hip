@@ -509,6 +509,7 @@ __global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restri
 }
 
 #include "fpq_fast16.h"
+#include "fpq_gemm_fp4.h"
 
 // ---------------------------------------------------------------------------------
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void rows_codes_kernel(const Tin* __restric
 
 // Vectorised codes for rows of exactly 128 elements (per-group): LPR lanes own a row, 16-byte
 // loads, one packed store per lane (FP4: V nibbles, FP6: V bytes), lane 0 of the row writes the scale.
-template <typename Tin, bool PACK>
+template <typename Tin, bool PACK, bool HW = false>
 __global__ __launch_bounds__(kBlock) void codes128_kernel(const u32x4* __restrict__ x, uint8_t* __restrict__ codes,
                                                          Tin* __restrict__ scales, int64_t n_vec, Fmt fs) {
   constexpr int V = DT<Tin>::kVec;
@@ -670,7 +671,8 @@ __global__ __launch_bounds__(kBlock) void codes128_kernel(const u32x4* __restric
       uint32_t neg = (xn < 0.0f) ? 1u : 0u;
       float qm = quant_mag(fabsf(xn), neg, fs);
       int li = level_index(qm, fs);
-      c[i] = (uint32_t)(neg ? fs.zero_code - li : fs.zero_code + li);
+      if constexpr (HW) c[i] = (uint32_t)li | ((neg && li != 0) ? 8u : 0u);   // OCP sign-magnitude nibble
+      else c[i] = (uint32_t)(neg ? fs.zero_code - li : fs.zero_code + li);
     }
     if constexpr (PACK && V == 8) {
       uint32_t w = 0;
@@ -1017,6 +1019,27 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   return go(rows16_lut_block_kernel<DUAL, 8, true>, rows16_lut_block_kernel<DUAL, 8, false>);
 }
 
+// ---- F2: hardware-nibble codes + FP4 MFMA GEMM ---------------------------------------
+inline const Lut16Tab& lut16_mx_codes_e2m1() {
+  static const Lut16Tab* tab = [] {
+    auto* t = new Lut16Tab;
+    const Lut16Host& h = lut16_host(FPQ_E2M1, FPQ_E2M1);
+    const int n = 1 << (16 - h.args.shift);
+    for (int i = 0; i < kLutArgEntries; ++i) t->e[i] = 0;
+    for (int i = 0; i < n; ++i) {
+      uint32_t u = (uint32_t)i << h.args.shift;
+      bool neg = (u >> 15) != 0;
+      float qm = quant_mag(h2f(u & 0x7FFFu), 0u, h.args.fpos);
+      // level -> magnitude index 0..7 (host twin of level_index)
+      int li = (qm >= h.args.fpos.kmin) ? (int)((fbits(qm) >> h.args.fpos.mshift) - h.args.fpos.kmin_code_base)
+                                        : (int)(qm * h.args.fpos.inv_step0);
+      t->e[i] = (uint16_t)(li | ((neg && li != 0) ? 8 : 0));
+    }
+    return t;
+  }();
+  return *tab;
+}
+
 }  // namespace
 
 // =================================================================================
@@ -1213,6 +1236,52 @@ int fpq_adaln_rotate_quant_rows(const void* x, void* out, void* h_out, void* rot
   if (mod_dtype == FPQ_F16) FPQ_GO(float, _Float16);
   FPQ_GO(float, float);
 #undef FPQ_GO
+}
+
+int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                            fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (cols % 128 != 0) return FPQ_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !codes || !scales) return FPQ_ERR_ARG;
+  if ((((uintptr_t)x | (uintptr_t)codes | (uintptr_t)scales) & 15) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == FPQ_F16) {
+    const Lut16Host& h = lut16_host(FPQ_E2M1, FPQ_E2M1);
+    const int64_t n_vec = rows * (cols / 8);
+    const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+    hipLaunchKernelGGL(rows16_codes_mx_kernel, dim3(grid_for((n_vec + kBlock - 1) / kBlock, 16384)), dim3(kBlock), lds, st,
+                       (const u32x4*)x, (uint32_t*)codes, (uint16_t*)scales, n_vec, h.args, lut16_mx_codes_e2m1());
+  } else {
+    const int64_t n_vec = rows * (cols / 4);
+    hipLaunchKernelGGL((codes128_kernel<float, true, true>), dim3(grid_for((n_vec + kBlock - 1) / kBlock, 1 << 20)),
+                       dim3(kBlock), 0, st, (const u32x4*)x, codes, (float*)scales, n_vec, make_fmt(FPQ_E2M1));
+  }
+  return check_launch();
+}
+
+int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                    int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                    fpq_stream_t stream) {
+  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (k % 128 != 0 || k > 128 * 64 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if (tokens == 0 || outs == 0) return FPQ_OK;
+  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  const int G = (int)(k / 128);
+  size_t lds = 16384 + (size_t)G * 128 * 4 * 2;
+  if (lds < 4 * 64 * 72 * 2) lds = 4 * 64 * 72 * 2;
+  const dim3 grid((unsigned)((outs + kGemmBN - 1) / kGemmBN), (unsigned)((tokens + kGemmBM - 1) / kGemmBM));
+  hipStream_t st = (hipStream_t)stream;
+  if (w_scale_dtype == FPQ_F16)
+    hipLaunchKernelGGL(gemm_fp4_kernel<_Float16>, grid, dim3(256), lds, st, a_codes, (const _Float16*)a_scales, w_codes,
+                       (const _Float16*)w_scales, (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);
+  else
+    hipLaunchKernelGGL(gemm_fp4_kernel<float>, grid, dim3(256), lds, st, a_codes, (const _Float16*)a_scales, w_codes,
+                       (const float*)w_scales, (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);
+  return check_launch();
 }
 
 int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream) {

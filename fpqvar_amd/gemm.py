@@ -1,0 +1,57 @@
+"""F2: real FP4 arithmetic for the W4A4 per-group E2M1 configuration.
+
+The reference only *simulates* FP4: it de-quantizes and runs an fp16 GEMM
+(tr/quant_utils.py:765-767).  Here the quantizer emits hardware E2M1 nibbles + per-group scales and
+the product runs on MI355X's block-scaled FP4 matrix cores (`fpq_gemm_fp4_mx`).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, dtype_id, lib, require_gpu, stream_ptr
+
+E2M1_LEVELS = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
+
+
+def quantize_mx(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [..., K] fp16/fp32 (K % 128 == 0) -> (codes uint8 [rows, K/2], scales [rows, K/128] in x.dtype)."""
+    require_gpu(x, "quantize_mx")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quantize_mx: x must be float16 or float32, got {x.dtype}")
+    k = x.shape[-1]
+    if k % 128 != 0:
+        raise RuntimeError("quantize_mx: the last dimension must be a multiple of 128")
+    xc = x.contiguous()
+    rows = xc.numel() // k
+    codes = torch.empty((rows, k // 2), dtype=torch.uint8, device=x.device)
+    scales = torch.empty((rows, k // 128), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows_codes_mx(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
+                                            dtype_id(x.dtype), stream_ptr(x.device)), "fpq_quant_rows_codes_mx")
+    return codes, scales
+
+
+def dequantize_mx(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """Reference decoder in torch ops (tests / debugging): fp32 [rows, K]."""
+    lv = torch.tensor(E2M1_LEVELS + tuple(-v for v in E2M1_LEVELS), dtype=torch.float32, device=codes.device)
+    lo, hi = (codes & 0xF).long(), (codes >> 4).long()
+    q = torch.stack((lv[lo], lv[hi]), dim=-1).reshape(codes.shape[0], -1)
+    return (q.view(codes.shape[0], -1, 128) * scales.float().unsqueeze(-1)).reshape(codes.shape[0], -1)
+
+
+def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
+               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores."""
+    require_gpu(a_codes, "linear_fp4")
+    tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
+    if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16:
+        raise RuntimeError("linear_fp4: operand shapes / activation scale dtype mismatch")
+    out = torch.empty((tokens, outs), dtype=torch.float16, device=a_codes.device)
+    b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
+    with torch.cuda.device(a_codes.device):
+        check(lib().fpq_gemm_fp4_mx(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
+                                    dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
+                                    tokens, outs, k, stream_ptr(a_codes.device)), "fpq_gemm_fp4_mx")
+    return out

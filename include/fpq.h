@@ -180,6 +180,27 @@ int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stre
 int fpq_quant_rows_codes(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols,
                          int table_id, int in_dtype, int pack_nibbles, fpq_stream_t stream);
 
+/* ---- F2: a real FP4 consumer --------------------------------------------
+ * Per-group(128) FP4-E2M1 quantization straight to HARDWARE codes: one OCP E2M1 nibble per element
+ * (bit 3 sign, bits 2:0 index into {0,.5,1,1.5,2,3,4,6}; element 2i in the low nibble of byte i) and
+ * one scale per group in x's dtype.  Same scale / normalise / rounding arithmetic as fpq_quant_rows,
+ * i.e. level * scale reproduces fp_quant_e2_per_group_cuda exactly.  x: [rows, cols] F16 or F32,
+ * cols % 128 == 0; codes: [rows, cols/2]; scales: [rows, cols/128]. */
+int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols,
+                            int in_dtype, fpq_stream_t stream);
+
+/* out[t, o] = bias[o] + sum_g a_scale[t,g] * w_scale[o,g] * dot_128(levels(a)[t,g,:], levels(w)[o,g,:])
+ * on the gfx950 block-scaled FP4 matrix cores (one 16x16x128 MFMA per group and 16x16 output tile,
+ * exact products, fp32 accumulation); replaces F.linear(act_quant(x), W_q, b) of
+ * tr/quant_utils.py:765-767 for the W4A4 per-group E2M1 configuration.  a_codes [tokens, k/2],
+ * a_scales fp16 [tokens, k/128], w_codes [outs, k/2], w_scales [outs, k/128] in w_scale_dtype,
+ * bias fp16 [outs] or NULL, out fp16 [tokens, outs]; k % 128 == 0, outs % 8 == 0.
+ * Numerics: does NOT round the de-quantized operands to fp16 first as the reference's fp16 GEMM does;
+ * agreement with it is to fp16-GEMM tolerance, not bit-exact. */
+int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                    int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                    fpq_stream_t stream);
+
 /* Inverse of fpq_quant_rows_codes: out = (Tout)((float)table_dedup[code] * (float)scale). */
 int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, int64_t rows,
                            int64_t cols, int table_id, int scale_dtype, int out_dtype,

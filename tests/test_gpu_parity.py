@@ -664,3 +664,45 @@ def test_incremental_kv_equals_requantize_everything(dev, kv_bit):
         ik, iv = inc.append(k, v)
         assert_bits_equal(ik.contiguous(), ck, f"K step pn={pn}")
         assert_bits_equal(iv.contiguous(), cv, f"V step pn={pn}")
+
+
+# ------------------------------------------------------------------ F2: hardware FP4 codes + MFMA GEMM
+def test_mx_codes_reproduce_fake_quant(dev, qu):
+    from fpqvar_amd import gemm
+    g = torch.Generator().manual_seed(101)
+    x = (torch.randn(300, 1920, generator=g) * torch.exp(0.5 * torch.randn(300, 1920, generator=g))).half()
+    x[3, :128] = 0
+    codes, scales = gemm.quantize_mx(x.to(dev))
+    assert codes.shape == (300, 960) and scales.shape == (300, 15) and scales.dtype == torch.float16
+    deq = gemm.dequantize_mx(codes, scales).half()           # level * scale, product exact in fp32, one rounding
+    assert_bits_equal(deq.view(300, 1920), orc.per_group_kernel_sem(x, "e2m1", 128), "fp16 activations")
+    w = torch.randn(384, 1920, generator=g) * 0.02
+    wc, ws = gemm.quantize_mx(w.to(dev))
+    assert ws.dtype == torch.float32
+    assert_bits_equal(gemm.dequantize_mx(wc, ws).view(384, 1920), orc.per_group_kernel_sem(w, "e2m1", 128), "fp32 weights")
+
+
+@pytest.mark.parametrize("T,O,K", ((256, 256, 1920), (1000, 5760, 1920), (130, 1928, 256), (64, 128, 7680)))
+def test_fp4_gemm(dev, T, O, K):
+    from fpqvar_amd import gemm
+    import fpqvar_amd.quant_utils as qu
+    g = torch.Generator().manual_seed(102 + T)
+    x = (torch.randn(T, K, generator=g) * torch.exp(0.3 * torch.randn(T, K, generator=g))).half().to(dev)
+    w = (torch.randn(O, K, generator=g) * 0.02).to(dev)
+    bias = (torch.randn(O, generator=g) * 0.1).half().to(dev)
+    ac, asc = gemm.quantize_mx(x)
+    wc, wsc = gemm.quantize_mx(w)
+    y = gemm.linear_fp4(ac, asc, wc, wsc, bias)
+    assert y.shape == (T, O) and y.dtype == torch.float16
+    # exact reference from the decoded operands in float64
+    a64 = gemm.dequantize_mx(ac, asc).double()
+    w64 = gemm.dequantize_mx(wc, wsc).double()
+    ref = a64 @ w64.t() + bias.double()
+    err = (y.double() - ref).abs()
+    tol = 2.0 ** -10 * ref.abs() + 1e-5 * (a64.abs() @ w64.abs().t()) + 1e-6     # fp16 output rounding + fp32 accumulation
+    assert bool((err <= tol).all()), float((err / tol).max())
+    # and the reference's own path: fp16 GEMM on the fake-quantized tensors (tr/quant_utils.py:765-767)
+    wq16 = qu.fp_quant_e2_per_group_cuda(w, 4, 128).half()
+    y_ref = torch.nn.functional.linear(qu.fp_quant_e2_per_group_cuda(x, 4, 128), wq16, bias)
+    torch.testing.assert_close(y.float(), y_ref.float(), rtol=2e-2, atol=2e-2 * float(ref.abs().mean()))
+    assert gemm.linear_fp4(ac, asc, wc, wsc.half(), None).shape == (T, O)        # fp16 weight scales, no bias
