@@ -26,9 +26,16 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 constexpr int kGemmBM = 128, kGemmBN = 128;   // workgroup tile (tokens x outputs), 4 wavefronts as 2 x 2
 constexpr int kGemmMT = 4, kGemmNT = 4;       // 16x16 MFMA tiles per wavefront: 64 x 64
 
-// byte offset of (row, 16-byte chunk c) in a [128 rows][64 B] LDS image, XOR-swizzled so that the 16
-// rows one ds_read_b128 touches fall into 16 different bank groups
-__device__ __forceinline__ int gemm_lds_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// Byte offset of (row, 16-byte chunk kb) in the 8 KiB LDS image of a 128-row operand tile.
+// ds_read_b128 serves a wavefront in four fixed 16-lane groups - {0-3,12-15,20-27}, {4-11,16-19,28-31} and
+// the same +32 (MI355X_MICROARCH.md, LDS) - and with lane = (kb << 4) | row each group mixes two k-blocks.
+// Layout: per 16 rows one 1 KiB block = 4 planes (one per kb) of 16 slots; row r sits in slot
+// (r&3)*4 + (r>>2) of its plane, planes 2 and 3 rotated by two slots.  Every read group then covers 16
+// distinct 16-byte slots (conflict-free); the staging writes (4 lanes per row) are 2-way.
+__device__ __forceinline__ int gemm_lds_off(int row, int kb) {
+  const int r = row & 15;
+  return ((row >> 4) << 10) + (kb << 8) + (((((r & 3) << 2) + (r >> 2) + ((kb >> 1) << 1)) & 15) << 4);
+}
 
 template <typename Tsw>
 __global__ __launch_bounds__(256) void gemm_fp4_kernel(const uint8_t* __restrict__ A, const _Float16* __restrict__ sa,
@@ -37,13 +44,22 @@ __global__ __launch_bounds__(256) void gemm_fp4_kernel(const uint8_t* __restrict
                                                       int T, int O, int C) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int G = C >> 7, row_bytes = C >> 1;
-  uint8_t* lA = smem;                         // 8 KiB
-  uint8_t* lB = smem + 8192;                  // 8 KiB
-  float* lsa = (float*)(smem + 16384);        // [G][128]
+  // two operand buffers (A 8 KiB + B 8 KiB each): group g+1 is written while group g is multiplied,
+  // one barrier per group
+  uint8_t* lAB = smem;                        // [2][A 8 KiB | B 8 KiB]
+  float* lsa = (float*)(smem + 32768);        // [G][128]
   float* lsw = lsa + G * 128;                 // [G][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int t0 = blockIdx.y * kGemmBM, o0 = blockIdx.x * kGemmBN;
+  // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2):
+  // XCD k owns a contiguous band of `cpx` column tiles and walks all row tiles of that band, so its
+  // slice of W (cpx * 128 rows) stays L2-resident and an A tile is re-used by cpx consecutive workgroups.
+  const int n_col = (O + kGemmBN - 1) / kGemmBN, n_row = (T + kGemmBM - 1) / kGemmBM;
+  const int cpx = (n_col + 7) >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int col_blk = xcd * cpx + local % cpx, row_blk = local / cpx;
+  if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
+  const int t0 = row_blk * kGemmBM, o0 = col_blk * kGemmBN;
 
   // scales of this tile, transposed to [g][row] and widened to fp32
   for (int i = tid; i < G * 128; i += 256) {
@@ -59,25 +75,60 @@ __global__ __launch_bounds__(256) void gemm_fp4_kernel(const uint8_t* __restrict
 #pragma unroll
     for (int n = 0; n < kGemmNT; ++n) acc[m][n] = v4f_t{0, 0, 0, 0};
 
-  // staging assignment: 512 chunks of 16 B per operand tile, 2 per thread
+  // staging assignment: 512 chunks of 16 B per operand tile, 2 per thread.  Software pipeline: the
+  // global loads of group g+1 are in flight while group g is multiplied out of LDS.
   const int sr0 = tid >> 2, sc = tid & 3;     // rows sr0 and sr0 + 64, chunk sc
+  const uint8_t* pa[2];
+  const uint8_t* pb[2];
+  bool va[2], vb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = sr0 + 64 * h;
+    va[h] = t0 + r < T;
+    vb[h] = o0 + r < O;
+    pa[h] = A + (int64_t)(va[h] ? t0 + r : 0) * row_bytes + sc * 16;
+    pb[h] = W + (int64_t)(vb[h] ? o0 + r : 0) * row_bytes + sc * 16;
+  }
+  u32x4 ga[2], gb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    ga[h] = va[h] ? *(const u32x4*)(pa[h]) : u32x4{0, 0, 0, 0};
+    gb[h] = vb[h] ? *(const u32x4*)(pb[h]) : u32x4{0, 0, 0, 0};
+  }
+  // prologue: group 0 into buffer 0, group 1 into the registers
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = sr0 + 64 * h;
+    *(u32x4*)(lAB + gemm_lds_off(r, sc)) = ga[h];
+    *(u32x4*)(lAB + 8192 + gemm_lds_off(r, sc)) = gb[h];
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ga[h] = va[h] ? *(const u32x4*)(pa[h] + 64) : u32x4{0, 0, 0, 0};
+      gb[h] = vb[h] ? *(const u32x4*)(pb[h] + 64) : u32x4{0, 0, 0, 0};
+    }
+  }
+  __syncthreads();   // buffer 0 and the scale tiles are visible
   for (int g = 0; g < G; ++g) {
-    u32x4 ga[2], gb[2];
+    const uint8_t* lA = lAB + (g & 1) * 16384;
+    const uint8_t* lB = lA + 8192;
+    if (g + 1 < G) {   // stage group g+1 into the other buffer (last read in iteration g-1, barrier since)
+      uint8_t* nA = lAB + ((g + 1) & 1) * 16384;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = sr0 + 64 * h;
-      const int t = t0 + r, o = o0 + r;
-      ga[h] = (t < T) ? *(const u32x4*)(A + (int64_t)t * row_bytes + g * 64 + sc * 16) : u32x4{0, 0, 0, 0};
-      gb[h] = (o < O) ? *(const u32x4*)(W + (int64_t)o * row_bytes + g * 64 + sc * 16) : u32x4{0, 0, 0, 0};
-    }
-    __syncthreads();   // the previous group's fragments have been read
+      for (int h = 0; h < 2; ++h) {
+        const int r = sr0 + 64 * h;
+        *(u32x4*)(nA + gemm_lds_off(r, sc)) = ga[h];
+        *(u32x4*)(nA + 8192 + gemm_lds_off(r, sc)) = gb[h];
+      }
+      if (g + 2 < G) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = sr0 + 64 * h;
-      *(u32x4*)(lA + gemm_lds_off(r, sc)) = ga[h];
-      *(u32x4*)(lB + gemm_lds_off(r, sc)) = gb[h];
+        for (int h = 0; h < 2; ++h) {
+          ga[h] = va[h] ? *(const u32x4*)(pa[h] + (g + 2) * 64) : u32x4{0, 0, 0, 0};
+          gb[h] = vb[h] ? *(const u32x4*)(pb[h] + (g + 2) * 64) : u32x4{0, 0, 0, 0};
+        }
+      }
     }
-    __syncthreads();
     v8i_t af[kGemmMT], bf[kGemmNT];
 #pragma unroll
     for (int m = 0; m < kGemmMT; ++m) {
@@ -95,19 +146,24 @@ __global__ __launch_bounds__(256) void gemm_fp4_kernel(const uint8_t* __restrict
     for (int m = 0; m < kGemmMT; ++m) sa4[m] = *(const v4f_t*)(lsa + g * 128 + wm * 64 + m * 16 + 4 * (lane >> 4));
 #pragma unroll
     for (int n = 0; n < kGemmNT; ++n) sw1[n] = lsw[g * 128 + wn * 64 + n * 16 + (lane & 15)];
+    // four independent MFMAs per tile row, then their scale-and-accumulate in the packed-fp32 VALU:
+    // the matrix pipe works on row m+1 while the VALU finishes row m
 #pragma unroll
-    for (int m = 0; m < kGemmMT; ++m)
+    for (int m = 0; m < kGemmMT; ++m) {
+      v4f_t d[kGemmNT];
+#pragma unroll
+      for (int n = 0; n < kGemmNT; ++n)
+        d[n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[m], bf[n], v4f_t{0, 0, 0, 0}, 4, 4, 0, 127, 0, 127);
 #pragma unroll
       for (int n = 0; n < kGemmNT; ++n) {
-        const v4f_t d = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[m], bf[n], v4f_t{0, 0, 0, 0}, 4, 4, 0, 127, 0,
-                                                                          127);
         const v4f_t p = sa4[m] * sw1[n];
-        acc[m][n] = __builtin_elementwise_fma(d, p, acc[m][n]);
+        acc[m][n] = __builtin_elementwise_fma(d[n], p, acc[m][n]);
       }
+    }
+    __syncthreads();   // group g consumed, group g+1 staged
   }
 
   // epilogue: bias, fp16, transpose each 64x64 wavefront tile through LDS for 16-byte row stores
-  __syncthreads();
   _Float16* lo = (_Float16*)smem + wave * (64 * 72);   // 64 rows x (64 + 8 pad) halves = 9216 B per wavefront
 #pragma unroll
   for (int m = 0; m < kGemmMT; ++m)

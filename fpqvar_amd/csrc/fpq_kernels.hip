@@ -1271,9 +1271,12 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
   if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
   const int G = (int)(k / 128);
-  size_t lds = 16384 + (size_t)G * 128 * 4 * 2;
+  size_t lds = 32768 + (size_t)G * 128 * 4 * 2;
   if (lds < 4 * 64 * 72 * 2) lds = 4 * 64 * 72 * 2;
-  const dim3 grid((unsigned)((outs + kGemmBN - 1) / kGemmBN), (unsigned)((tokens + kGemmBM - 1) / kGemmBM));
+  const int64_t n_col = (outs + kGemmBN - 1) / kGemmBN, n_row = (tokens + kGemmBM - 1) / kGemmBM;
+  const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;   // see the XCD-aware tile order in gemm_fp4_kernel
+  if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  const dim3 grid((unsigned)n_wg);
   hipStream_t st = (hipStream_t)stream;
   if (w_scale_dtype == FPQ_F16)
     hipLaunchKernelGGL(gemm_fp4_kernel<_Float16>, grid, dim3(256), lds, st, a_codes, (const _Float16*)a_scales, w_codes,

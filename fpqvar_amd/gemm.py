@@ -55,3 +55,33 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
                                     dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
                                     tokens, outs, k, stream_ptr(a_codes.device)), "fpq_gemm_fp4_mx")
     return out
+
+
+class FP4Linear(torch.nn.Module):
+    """Drop-in for QuantizedLinear in the W4A4 per-group `fp_e2` configuration that runs on the FP4
+    matrix cores instead of simulating FP4 in fp16: weights are stored as hardware E2M1 codes + one
+    fp32 scale per 128 input channels (4.25 bits per weight instead of 16), the
+    activation is quantized to codes on the fly, the product is `fpq_gemm_fp4_mx`.
+    Same quantization decisions as the reference (codes * scale == its fake-quantized tensors bit for
+    bit); the GEMM itself is more exact than the reference's fp16 GEMM (tolerance-level agreement)."""
+
+    def __init__(self, w_codes, w_scales, bias, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.register_buffer("w_codes", w_codes)
+        self.register_buffer("w_scales", w_scales)
+        self.register_buffer("bias", bias)
+
+    @classmethod
+    def from_float(cls, module: torch.nn.Linear):
+        assert isinstance(module, torch.nn.Linear) and module.in_features % 128 == 0 and module.out_features % 8 == 0
+        codes, scales = quantize_mx(module.weight.detach().float())
+        bias = None if module.bias is None else module.bias.detach().to(torch.float16)
+        return cls(codes, scales, bias, module.in_features, module.out_features)
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features))
+        y = linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)
+        return y.view(*lead, self.out_features)

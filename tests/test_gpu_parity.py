@@ -706,3 +706,24 @@ def test_fp4_gemm(dev, T, O, K):
     y_ref = torch.nn.functional.linear(qu.fp_quant_e2_per_group_cuda(x, 4, 128), wq16, bias)
     torch.testing.assert_close(y.float(), y_ref.float(), rtol=2e-2, atol=2e-2 * float(ref.abs().mean()))
     assert gemm.linear_fp4(ac, asc, wc, wsc.half(), None).shape == (T, O)        # fp16 weight scales, no bias
+
+
+def test_fp4_linear_module(dev, golden):
+    """FP4Linear vs the reference-path QuantizedLinear (fake-quant + fp16 GEMM) on the golden toy layer."""
+    from fpqvar_amd import gemm
+    from fpqvar_amd.quant_linear import QuantizedLinear
+    lin = torch.nn.Linear(128, 384, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(from_bits(golden["ql/w0/attn.mat_qkv"]))
+    lin = lin.to(dev)
+    x = torch.randn(3, 50, 128, device=dev).half()
+    real = gemm.FP4Linear.from_float(lin)
+    fake = QuantizedLinear.from_float(lin, weight_quant="per_group", act_quant="per_group", w_bit=4, a_bit=4,
+                                      activation_fp_quant=True, weight_fp_quant=True, act_fp_type="fp_e2",
+                                      weight_fp_type="fp_e2")
+    # same quantization decisions: decoded weights == the fake-quantized weights, bit for bit
+    assert_bits_equal(gemm.dequantize_mx(real.w_codes, real.w_scales).view(384, 128), fake.weight, "weights")
+    fake.weight = fake.weight.half()
+    y_real, y_fake = real(x), fake(x)
+    assert y_real.shape == (3, 50, 384)
+    torch.testing.assert_close(y_real.float(), y_fake.float(), rtol=2e-2, atol=2e-3)

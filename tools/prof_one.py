@@ -19,6 +19,13 @@ if which == "adaln":
     shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
     s = torch.rand(C, device=dev) + 0.5
     fn = lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s)
+elif which == "gemm":
+    from fpqvar_amd import gemm
+    x = torch.randn(65536, C, device=dev).half()
+    w = torch.randn(5760, C, device=dev) * 0.02
+    ac, asc = gemm.quantize_mx(x)
+    wc, wsc = gemm.quantize_mx(w)
+    fn = lambda: gemm.linear_fp4(ac, asc, wc, wsc)
 elif which == "rotate":
     x = torch.randn(65536, C, device=dev).half()
     fn = lambda: rot.rotate_quant(x, "e2m1")
