@@ -1271,19 +1271,30 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
   if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
   const int G = (int)(k / 128);
-  size_t lds = 32768 + (size_t)G * 128 * 4 * 2;
-  if (lds < 4 * 64 * 72 * 2) lds = 4 * 64 * 72 * 2;
-  const int64_t n_col = (outs + kGemmBN - 1) / kGemmBN, n_row = (tokens + kGemmBM - 1) / kGemmBM;
-  const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;   // see the XCD-aware tile order in gemm_fp4_kernel
-  if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-  const dim3 grid((unsigned)n_wg);
   hipStream_t st = (hipStream_t)stream;
-  if (w_scale_dtype == FPQ_F16)
-    hipLaunchKernelGGL(gemm_fp4_kernel<_Float16>, grid, dim3(256), lds, st, a_codes, (const _Float16*)a_scales, w_codes,
-                       (const _Float16*)w_scales, (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);
-  else
-    hipLaunchKernelGGL(gemm_fp4_kernel<float>, grid, dim3(256), lds, st, a_codes, (const _Float16*)a_scales, w_codes,
-                       (const float*)w_scales, (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);
+  // tile configuration: FPQ_GEMM_CFG = 0 (4 waves, 128x128, 64x64 per wave), 1 (8 waves, 128x128, 32x64),
+  // 2 (8 waves, 128x256, 64x64 per wave)
+  const char* env = getenv("FPQ_GEMM_CFG");
+  const int cfg = env ? atoi(env) : 0;
+#define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
+  do {                                                                                                               \
+    using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
+    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
+    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
+    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
+    if (w_scale_dtype == FPQ_F16)                                                                                    \
+      hipLaunchKernelGGL((gemm_fp4_kernel<_Float16, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),        \
+                         Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,   \
+                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((gemm_fp4_kernel<float, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),           \
+                         Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,      \
+                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                     \
+  } while (0)
+  if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
+  else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
+  else FPQ_GEMM_LAUNCH(4, 4, 2, 2);
+#undef FPQ_GEMM_LAUNCH
   return check_launch();
 }
 
