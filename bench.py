@@ -108,7 +108,8 @@ def other_kernels(dev):
     out = {}
 
     def timed(fn, iters=20):
-        fn()
+        for _ in range(10):      # reach steady clocks first: the first launches after an idle gap read ~20 % slow
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
