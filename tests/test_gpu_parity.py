@@ -727,3 +727,27 @@ def test_fp4_linear_module(dev, golden):
     y_real, y_fake = real(x), fake(x)
     assert y_real.shape == (3, 50, 384)
     torch.testing.assert_close(y_real.float(), y_fake.float(), rtol=2e-2, atol=2e-3)
+
+
+def test_more_than_2_31_elements(dev, qu):
+    """64-bit indexing: a tensor with more than 2^31 elements (4.3 GB of fp16), checked on slices from
+    both ends and across the 2^31 boundary."""
+    rows, cols = 1_120_000, 1920                      # 2.15e9 elements
+    assert rows * cols > 2 ** 31
+    x = torch.empty(rows, cols, dtype=torch.float16, device=dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    chunk = 100_000
+    for r in range(0, rows, chunk):
+        x[r:r + chunk].normal_(generator=g)
+    out = qu.fp_quant_e2_per_group_cuda(x, 4, 128)
+    boundary = 2 ** 31 // cols
+    for r0 in (0, boundary - 2, rows - 64):
+        sl = slice(r0, r0 + 64)
+        assert_bits_equal(out[sl], orc.per_group_kernel_sem(x[sl].cpu(), "e2m1", 128), f"rows {r0}..")
+    del out
+    out = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, 4, 128)
+    assert_bits_equal(out[rows - 64:], orc.dual_per_group_kernel_sem(x[rows - 64:].cpu(), "e1m2_neg", "e2m1_pos", 128, 1.0),
+                      "dual, last rows")
+    del out
+    out = qu.fp6_quant_e2m3_per_token_cuda(x, 6)
+    assert_bits_equal(out[rows - 64:], orc.per_token_kernel_sem(x[rows - 64:].cpu(), "e2m3"), "per-token, last rows")
