@@ -36,6 +36,8 @@ _SIGS = {
                                           _c.c_void_p]),
     "fpq_quant_rows_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_float, _c.c_void_p, _c.c_void_p]),
+    "fpq_quant_rows_neg_reverse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                               _c.c_void_p]),
     "fpq_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                           _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),
     "fpq_adaln_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,

@@ -508,6 +508,120 @@ __global__ __launch_bounds__(kBlock) void rows_scalar_kernel(const Tin* __restri
   if (DUAL && saw_nan && dual.nan_flag) atomicOr(dual.nan_flag, 1u);
 }
 
+// ---------------------------------------------------------------------------------
+// "neg reverse" rows (models_fp_quant/quant_utils.py:454-495): the non-positive half is
+// shifted up by m = |row min| before it is quantized and shifted back afterwards.
+// Three row reductions (min, max|shifted|, max positive), all on data held in registers.
+// ---------------------------------------------------------------------------------
+// key whose MAX is the row MIN with torch.min's NaN propagation (NaN -> 0xFFFFFFFF)
+__device__ __forceinline__ uint32_t min_key(float e) {
+  uint32_t b = fbits(e);
+  uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // increasing in e
+  return (e != e) ? 0xFFFFFFFFu : ~ord;
+}
+__device__ __forceinline__ float abs_from_min_key(uint32_t k) {
+  uint32_t ord = ~k;
+  uint32_t b = (ord & 0x80000000u) ? (ord & 0x7FFFFFFFu) : ~ord;
+  return (k == 0xFFFFFFFFu) ? __builtin_nanf("") : fabsf(u2f(b));
+}
+
+template <typename T>
+__device__ __forceinline__ float negrev_shifted(float xf, float m) {
+  return DT<T>::round(((xf <= 0.0f) ? xf : 0.0f) + m);
+}
+
+template <typename T>
+__device__ __forceinline__ float quant_negrev(float xf, float xnr, float m, float snr, float sp, const Fmt& f) {
+  float a = DT<T>::round(xnr / snr);
+  float b = DT<T>::round(((xf > 0.0f) ? xf : 0.0f) / sp);
+  uint32_t na = (a < 0.0f) ? 1u : 0u;
+  float qa = quant_mag(fabsf(a), na, f);
+  qa = (na && qa != 0.0f) ? -qa : qa;
+  float qb = quant_mag(b, 0u, f);  // b >= 0 or NaN
+  float t = qa * snr;
+  t = t - m;
+  float u = qb * sp;
+  return t + u;
+}
+
+template <typename T, int LPR, int UNROLL>
+__global__ __launch_bounds__(kBlock) void rows_negrev_subwave_kernel(const u32x4* __restrict__ x,
+                                                                    u32x4* __restrict__ out, int64_t n_vec,
+                                                                    Fmt fs) {
+  constexpr int V = DT<T>::kVec;
+  const int64_t tile_vecs = (int64_t)kBlock * UNROLL;
+  const int64_t tiles = (n_vec + tile_vecs - 1) / tile_vecs;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t v0 = tile * tile_vecs + threadIdx.x;
+    u32x4 raw[UNROLL];
+    bool live[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      int64_t v = v0 + (int64_t)u * kBlock;
+      live[u] = v < n_vec;
+      raw[u] = live[u] ? __builtin_nontemporal_load(x + v) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      float xf[V], xnr[V];
+      uint32_t kmin = 0, mpos = 0, mnr = 0;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float e = DT<T>::get(raw[u], i);
+        xf[i] = e;
+        uint32_t k = min_key(e), bp = (e > 0.0f) ? DT<T>::absbits(e) : 0u;
+        kmin = kmin > k ? kmin : k;
+        mpos = mpos > bp ? mpos : bp;
+      }
+      kmin = lanes_max<LPR>(kmin);
+      mpos = lanes_max<LPR>(mpos);
+      const float m = abs_from_min_key(kmin);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        xnr[i] = negrev_shifted<T>(xf[i], m);
+        uint32_t ab = DT<T>::absbits(xnr[i]);
+        mnr = mnr > ab ? mnr : ab;
+      }
+      mnr = lanes_max<LPR>(mnr);
+      if (!live[u]) continue;
+      const float snr = scale_of<T>(mnr, fs.gmax), sp = scale_of<T>(mpos, fs.gmax);
+      u32x4 o = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < V; ++i) DT<T>::put(o, i, quant_negrev<T>(xf[i], xnr[i], m, snr, sp, fs));
+      __builtin_nontemporal_store(o, out + v0 + (int64_t)u * kBlock);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                                   int64_t rows, int64_t cols, Fmt fs) {
+  __shared__ uint32_t sh[kBlock / 64];
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const T* xr = x + row * cols;
+    uint32_t kmin = 0, mpos = 0, mnr = 0;
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      float e = load_scalar<T>(xr + c);
+      uint32_t k = min_key(e), bp = (e > 0.0f) ? DT<T>::absbits(e) : 0u;
+      kmin = kmin > k ? kmin : k;
+      mpos = mpos > bp ? mpos : bp;
+    }
+    kmin = block_max(kmin, sh);
+    mpos = block_max(mpos, sh);
+    const float m = abs_from_min_key(kmin);
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      uint32_t ab = DT<T>::absbits(negrev_shifted<T>(load_scalar<T>(xr + c), m));
+      mnr = mnr > ab ? mnr : ab;
+    }
+    mnr = block_max(mnr, sh);
+    const float snr = scale_of<T>(mnr, fs.gmax), sp = scale_of<T>(mpos, fs.gmax);
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      float e = load_scalar<T>(xr + c);
+      store_scalar<T>(out + row * cols + c, quant_negrev<T>(e, negrev_shifted<T>(e, m), m, snr, sp, fs));
+    }
+  }
+}
+
 #include "fpq_fast16.h"
 #include "fpq_gemm_fp4.h"
 
@@ -1045,6 +1159,35 @@ inline const Lut16Tab& lut16_mx_codes_e2m1() {
 // =================================================================================
 // C ABI
 // =================================================================================
+template <typename T>
+int launch_negrev(const void* x, void* out, int64_t rows, int64_t cols, const Fmt& fs, hipStream_t st) {
+  constexpr int V = DT<T>::kVec;
+  constexpr int U = 2;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+  const int64_t lpr = cols / V;
+  if (aligned && cols % V == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0) {
+    const int64_t n_vec = rows * lpr;
+    auto go = [&](auto kern) {
+      int64_t blocks = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+      hipLaunchKernelGGL(kern, dim3(grid_for(blocks, 1 << 20)), dim3(kBlock), 0, st, (const u32x4*)x, (u32x4*)out,
+                         n_vec, fs);
+      return check_launch();
+    };
+    switch ((int)lpr) {
+      case 1: return go(rows_negrev_subwave_kernel<T, 1, U>);
+      case 2: return go(rows_negrev_subwave_kernel<T, 2, U>);
+      case 4: return go(rows_negrev_subwave_kernel<T, 4, U>);
+      case 8: return go(rows_negrev_subwave_kernel<T, 8, U>);
+      case 16: return go(rows_negrev_subwave_kernel<T, 16, U>);
+      case 32: return go(rows_negrev_subwave_kernel<T, 32, U>);
+      case 64: return go(rows_negrev_subwave_kernel<T, 64, U>);
+    }
+  }
+  hipLaunchKernelGGL((rows_negrev_scalar_kernel<T>), dim3(grid_for(rows, 65535)), dim3(kBlock), 0, st, (const T*)x,
+                     (T*)out, rows, cols, fs);
+  return check_launch();
+}
+
 extern "C" {
 
 int fpq_version(void) { return FPQ_VERSION; }
@@ -1183,6 +1326,17 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   hipLaunchKernelGGL(zero_if_flag_kernel, dim3(grid_for((n_bytes / 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                      (uint8_t*)out, n_bytes, flag);
   return check_launch();
+}
+
+int fpq_quant_rows_neg_reverse(const void* x, void* out, int64_t rows, int64_t cols, int table_id, int dtype,
+                               fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (dtype != FPQ_F16 && dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !out) return FPQ_ERR_ARG;
+  if (dtype == FPQ_F16) return launch_negrev<_Float16>(x, out, rows, cols, make_fmt(table_id), (hipStream_t)stream);
+  return launch_negrev<float>(x, out, rows, cols, make_fmt(table_id), (hipStream_t)stream);
 }
 
 int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols, int in_dtype,

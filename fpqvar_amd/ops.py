@@ -85,6 +85,23 @@ def quant_rows_argmin(x: torch.Tensor, table: str, cols: int, clamp3: bool) -> t
     return out
 
 
+def quant_rows_neg_reverse(x: torch.Tensor, table: str, cols: int) -> torch.Tensor:
+    """Shift-by-|row min| quantizer for the non-positive half (fpq_quant_rows_neg_reverse); x.dtype result."""
+    require_gpu(x, "quant_rows_neg_reverse")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_rows_neg_reverse: x must be float16 or float32, got {x.dtype}")
+    n = x.numel()
+    if cols <= 0 or n % cols != 0:
+        raise RuntimeError(f"quant_rows_neg_reverse: numel {n} is not a multiple of the row length {cols}")
+    xc = _contig(x)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows_neg_reverse(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[table],
+                                               dtype_id(x.dtype), stream_ptr(x.device)),
+              "fpq_quant_rows_neg_reverse")
+    return out
+
+
 def absmax(x: torch.Tensor) -> torch.Tensor:
     """0-dim max|x| in x's dtype (NaN-propagating)."""
     require_gpu(x, "absmax")

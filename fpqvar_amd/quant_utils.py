@@ -109,6 +109,13 @@ def fp4_afpq_per_group_cuda(x, n_bits, group_size=128, clipping_strength=1.0):
     return ops.quant_rows_dual(x, "e2m1_neg", "e2m1_pos", group_size, clipping_strength)
 
 
+def fp_neg_reverse_quant_per_group_cuda(x, n_bits, group_size=128):
+    """models_fp_quant/quant_utils.py:454-495: x <= 0 is shifted up by |group min|, quantized on E2M1
+    and shifted back; x > 0 is quantized on E2M1 as usual."""
+    assert n_bits == 4
+    return ops.quant_rows_neg_reverse(x, "e2m1", group_size)
+
+
 # ---- FP6 (tr/quant_utils.py:503-574): output is float16 whatever the input dtype ----
 
 def fp6_quant_e2m3_per_token_cuda(x, n_bits):

@@ -133,6 +133,15 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
                         int pos_table, int in_dtype, int out_dtype, const void* clip_absmax,
                         float clip_strength, void* nan_flag, fpq_stream_t stream);
 
+/* "Neg reverse" rows: out = (T)( (q(x_nr / s_nr) * s_nr - m) + q(x_pos / s_pos) * s_pos ) with
+ * m = |min(row)|, x_nr = (T)(min(x, 0) + m), both scales (T)(absmax / max|table|); products,
+ * the subtraction and the sum in fp32.  `dtype` is the type of both x and out.
+ *   replaces fp_neg_reverse_quant_per_group_cuda   models_fp_quant/quant_utils.py:454-495
+ *   (the reference uses FPQ_E2M1 and cols = 128; any symmetric table and row length work).
+ * A NaN in a row makes m NaN, hence the whole row NaN, as torch.min does. */
+int fpq_quant_rows_neg_reverse(const void* x, void* out, int64_t rows, int64_t cols, int table_id,
+                               int dtype, fpq_stream_t stream);
+
 /* Online rotate fused in front of the per-group(128) quantizer.
  * Replaces, for the block-diagonal randomized-Hadamard rotation
  * (rotate_utils/rotation_utils.py:69-104: every 128x128 block = diag(D).H128/sqrt(128)),

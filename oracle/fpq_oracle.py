@@ -212,6 +212,26 @@ def dual_per_group_kernel_sem(x, neg_name="e1m2_neg", pos_name="e2m1_pos", group
     return y.view(x.shape).to(x.dtype)
 
 
+def neg_reverse_per_group_kernel_sem(x, table_name="e2m1", group_size=128) -> torch.Tensor:
+    """fp_neg_reverse_quant_per_group_cuda (models_fp_quant/quant_utils.py:454-495): the
+    non-positive half is shifted up by |row min| and quantized on the symmetric table, shifted
+    back after de-quantization; the positive half is quantized as usual.  The shift, both scales
+    and both quotients live in x.dtype; products, the subtraction and the sum are fp32."""
+    table = TABLES[table_name]
+    xs = x.reshape(-1, group_size)
+    m = xs.min(dim=-1, keepdim=True)[0].abs()
+    zeros = torch.zeros_like(xs)
+    x_neg = torch.where(xs <= 0, xs, zeros)
+    x_pos = torch.where(xs > 0, xs, zeros)
+    x_nr = x_neg + m
+    s_nr = x_nr.abs().max(dim=-1, keepdim=True)[0] / table.abs().max()
+    s_pos = x_pos.abs().max(dim=-1, keepdim=True)[0] / table.abs().max()
+    q_nr = nearest_kernel((x_nr / s_nr).reshape(-1).to(torch.float32), table).view(xs.shape)
+    q_pos = nearest_kernel((x_pos / s_pos).reshape(-1).to(torch.float32), table).view(xs.shape)
+    y = (q_nr * s_nr - m) + q_pos * s_pos
+    return y.view(x.shape).to(x.dtype)
+
+
 def dual_per_token_kernel_sem(x, neg_name="int_neg", pos_name="e2m3_pos") -> torch.Tensor:
     """fp6_quant_int_neg_e2m3_pos_per_token_cuda (tr/quant_utils.py:614-646)."""
     y = _dual_rows_kernel_sem(x.reshape(-1, x.shape[-1]), neg_name, pos_name)

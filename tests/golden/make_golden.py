@@ -145,6 +145,8 @@ def main():
                           qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(x.clone(), 6)))
             cases.append((f"dual_group_cuda/e2m1_neg+e2m1_pos/{kind}_{dn}",
                           fqu.fp4_afpq_per_group_cuda(x.clone(), P, 128)))
+            cases.append((f"neg_reverse_group_cuda/e2m1/{kind}_{dn}",
+                          fqu.fp_neg_reverse_quant_per_group_cuda(x.clone(), P, 128)))
             # the pure-torch CPU path (A9)
             cases.append((f"per_group_argmin/e2m1/{kind}_{dn}", qu.fp_quant_e2_per_group(x.clone(), P, 128)))
             cases.append((f"per_group_argmin/e1m2/{kind}_{dn}", qu.fp_quant_e1_per_group(x.clone(), P, 128)))

@@ -127,6 +127,8 @@ def _run_named(qu, key, x):
         return qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, 4, 128, 0.9)
     if fam == "dual_token_cuda":
         return qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(x, 6)
+    if fam == "neg_reverse_group_cuda":
+        return qu.fp_neg_reverse_quant_per_group_cuda(x, 4, 128)
     raise KeyError(key)
 
 
@@ -136,8 +138,8 @@ def test_golden_vectors(dev, qu, golden, kind, dn):
     x = from_bits(golden[f"in/{kind}_{dn}"]).to(dev)
     keys = [k[4:] for k in golden.files if k.startswith("out/") and k.endswith(f"/{kind}_{dn}")
             and k.split("/")[1] in ("per_group_cuda", "per_token_cuda", "dual_group_cuda",
-                                    "dual_group_cuda_clip0.9", "dual_token_cuda")]
-    assert len(keys) == 12
+                                    "dual_group_cuda_clip0.9", "dual_token_cuda", "neg_reverse_group_cuda")]
+    assert len(keys) == 13
     for key in keys:
         want = from_bits(golden[f"out/{key}"])
         x_before = x.clone()
@@ -229,6 +231,29 @@ def test_dual_per_group_vs_oracle(dev, qu, kind, dtype):
                       orc.dual_per_group_kernel_sem(x, "e1m2_neg", "e2m1_pos", 128, 0.8), f"dual fp4 clip {kind}")
     assert_bits_equal(qu.fp6_quant_int_neg_e2m3_pos_per_group_cuda(xd, 6, 128),
                       orc.dual_per_group_kernel_sem(x, "int_neg", "e2m3_pos", 128, None), f"dual fp6 {kind}")
+
+
+@pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("kind", ("gelu", "gauss", "heavy"))
+def test_neg_reverse_vs_oracle(dev, qu, kind, dtype):
+    """fp_neg_reverse_quant_per_group_cuda (models_fp_quant/quant_utils.py:454-495), vector kernel at
+    g=128 and other power-of-two groups, scalar kernel at ragged group sizes."""
+    from fpqvar_amd import ops
+    x = _inputs(kind, (256, 7680), dtype, 29)
+    x[1, :128] = x[1, :128].abs() + 0.1     # min > 0: the shift is the smallest positive value
+    x[2, :128] = -x[2, :128].abs() - 0.1    # no positives
+    x[3, :128] = 0
+    x[4, 5] = float("inf")
+    x[5, 5] = float("-inf")
+    x[6, 5] = float("nan")
+    xd = x.to(dev)
+    assert_bits_equal(qu.fp_neg_reverse_quant_per_group_cuda(xd, 4, 128),
+                      orc.neg_reverse_per_group_kernel_sem(x, "e2m1", 128), f"neg reverse {kind}")
+    for g in (32, 512 if dtype == torch.float16 else 256, 60, 7680, 3):
+        assert_bits_equal(ops.quant_rows_neg_reverse(xd, "e2m1", g),
+                          orc.neg_reverse_per_group_kernel_sem(x, "e2m1", g), f"neg reverse {kind} g={g}")
+    assert_bits_equal(ops.quant_rows_neg_reverse(xd, "e2m3", 128),
+                      orc.neg_reverse_per_group_kernel_sem(x, "e2m3", 128), f"neg reverse e2m3 {kind}")
 
 
 def test_exhaustive_fp16_scale_pairs(dev, qu):

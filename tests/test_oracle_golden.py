@@ -106,6 +106,14 @@ def test_dual_kernel_sem(golden, kind, dn):
 
 @pytest.mark.parametrize("dn", DTYPES)
 @pytest.mark.parametrize("kind", KINDS)
+def test_neg_reverse_kernel_sem(golden, kind, dn):
+    x = _in(golden, kind, dn)
+    want = from_bits(golden[f"out/neg_reverse_group_cuda/e2m1/{kind}_{dn}"])
+    assert_bits_equal(orc.neg_reverse_per_group_kernel_sem(x, "e2m1", 128), want, "neg reverse")
+
+
+@pytest.mark.parametrize("dn", DTYPES)
+@pytest.mark.parametrize("kind", KINDS)
 def test_argmin_cpu_path(golden, kind, dn):
     x = _in(golden, kind, dn)
     for name, clamp3 in (("e2m1", False), ("e1m2", True), ("e3m0", True)):
