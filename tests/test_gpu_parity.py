@@ -776,3 +776,40 @@ def test_more_than_2_31_elements(dev, qu):
     del out
     out = qu.fp6_quant_e2m3_per_token_cuda(x, 6)
     assert_bits_equal(out[rows - 64:], orc.per_token_kernel_sem(x[rows - 64:].cpu(), "e2m3"), "per-token, last rows")
+
+
+# ------------------------------------------------------------------ F4: packed on-disk format
+def test_packed_file_reproduces_calibration(dev, qu, tmp_path):
+    """pack -> save -> load -> dequantize == the tensor the reference keeps after from_float + .half()
+    (oracle on CPU), for per-group FP4, per-channel FP6, and a smoothed + rotated layer; the FP4 layer's
+    hardware operands give the same GEMM result as quantizing the weight directly."""
+    from fpqvar_amd import gemm, packed, rotation as rot
+    g = torch.Generator().manual_seed(77)
+    w1 = torch.randn(384, 1920, generator=g) * 0.02
+    w2 = torch.randn(256, 768, generator=g) * 0.02
+    s = torch.rand(1920, generator=g) + 0.5
+    layers = {
+        "a.fp4": packed.pack_weight(w1.to(dev), "e2m1", 128, bias=torch.randn(384, generator=g).to(dev)),
+        "b.fp6": packed.pack_weight(w2.to(dev), "e2m3", 768),
+        "c.fp6g": packed.pack_weight(w2.to(dev), "e3m2", 128),
+        "d.rot": packed.pack_weight(w1.to(dev), "e2m1", 128, smooth=s.to(dev), rotate_block=128, rotate_seed=42),
+    }
+    path = str(tmp_path / "m.safetensors")
+    nbytes = packed.save_packed(path, layers)
+    fp16_bytes = 2 * (2 * w1.numel() + 2 * w2.numel())
+    assert nbytes < 0.45 * fp16_bytes
+    got = packed.load_packed(path, dev)
+    assert_bits_equal(got["a.fp4"].dequantize(), orc.per_group_kernel_sem(w1, "e2m1", 128).half(), "packed fp4")
+    assert_bits_equal(got["b.fp6"].dequantize(), orc.per_token_kernel_sem(w2, "e2m3"), "packed fp6 per-channel")
+    assert_bits_equal(got["c.fp6g"].dequantize(), orc.per_group_kernel_sem(w2, "e3m2", 128, out_dtype=torch.float16),
+                      "packed fp6 per-group")
+    qd = rot.block_random_hadamard_matrix(1920, 128, dev, 42)
+    wt = rot.rotate_weight(rot.transform_weight(w1.to(dev), s.to(dev)), qd).cpu()
+    assert_bits_equal(got["d.rot"].dequantize(), orc.per_group_kernel_sem(wt, "e2m1", 128).half(), "packed rotated")
+    assert got["d.rot"].rotate_block == 128 and torch.equal(got["d.rot"].smooth.cpu(), s)
+    # hardware operands
+    x = torch.randn(256, 1920, generator=g).half().to(dev)
+    ac, asc = gemm.quantize_mx(x)
+    wc, wsc = got["a.fp4"].fp4_operands()
+    direct = gemm.linear_fp4(ac, asc, *gemm.quantize_mx(w1.to(dev)), bias=got["a.fp4"].bias)
+    assert_bits_equal(gemm.linear_fp4(ac, asc, wc, wsc, bias=got["a.fp4"].bias), direct, "fp4 operands from the file")
