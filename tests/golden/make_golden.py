@@ -240,6 +240,33 @@ def main():
             off[i * 128:(i + 1) * 128, i * 128:(i + 1) * 128] = 0
         out["rot/offdiag_zero_1920"] = np.array(bool((off == 0).all()))
 
+    # ---- 5. GALT objective and its STE gradient (learnable_transformation/*.py) --------------------
+    import learnable_transformation.learnable_transformation_mat_qkv_fp4 as g4   # noqa: E402
+    import learnable_transformation.learnable_transformation_mat_qkv_fp6 as g6   # noqa: E402
+    gg = torch.Generator().manual_seed(91)
+    gx_ = torch.randn(64, 256, generator=gg) * torch.exp(0.5 * torch.randn(64, 256, generator=gg))
+    gw_ = torch.randn(48, 256, generator=gg) * 0.05
+    gs_ = torch.rand(256, generator=gg) + 0.5
+    gq_ = ru.block_random_hadamard_matrix(256, 128, "cpu", 42).to(torch.float32)
+    out["galt/x_f32"], out["galt/w_f32"], out["galt/s_f32"], out["galt/q_f32"] = bits(gx_), bits(gw_), bits(gs_), bits(gq_)
+    for tag, mod in (("fp4", g4), ("fp6", g6)):
+        sp = torch.nn.Parameter(gs_.clone())
+        loss = mod.compute_quant_error_v1(gx_, gw_, sp, gq_)
+        loss.backward()
+        out[f"galt/{tag}/loss"] = bits(loss.detach().float().reshape(1))
+        out[f"galt/{tag}/grad_s"] = bits(sp.grad.float())
+        # the quantizers' forward on the exact transformed operands (bit-level parity target)
+        x2 = torch.matmul(gx_ * gs_, gq_)
+        w2 = torch.matmul(gw_ / gs_, gq_)
+        out[f"galt/{tag}/x2_f32"], out[f"galt/{tag}/w2_f32"] = bits(x2), bits(w2)
+        if tag == "fp4":
+            out["galt/fp4/x2_quant"] = bits(mod.FPQuant.apply(x2))
+            out["galt/fp4/w2_quant"] = bits(mod.FPQuant.apply(w2))
+        else:
+            out["galt/fp6/x2_quant"] = bits(mod.FP6Quant_activation_per_token.apply(x2))
+            out["galt/fp6/w2_quant"] = bits(mod.FP6Quant_weight.apply(w2))
+            out["galt/fp6/x2_quant_group"] = bits(mod.FP6Quant_activation.apply(x2))
+
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), len(out), "arrays")
 

@@ -813,3 +813,53 @@ def test_packed_file_reproduces_calibration(dev, qu, tmp_path):
     wc, wsc = got["a.fp4"].fp4_operands()
     direct = gemm.linear_fp4(ac, asc, *gemm.quantize_mx(w1.to(dev)), bias=got["a.fp4"].bias)
     assert_bits_equal(gemm.linear_fp4(ac, asc, wc, wsc, bias=got["a.fp4"].bias), direct, "fp4 operands from the file")
+
+
+# ------------------------------------------------------------------ F4: GALT on the fused kernels
+def test_galt_quantizers_and_objective(dev, golden):
+    """The STE quantizers' forwards are bit-equal to the reference's classes on the reference's transformed
+    operands; the objective and its gradient (matmuls now on the GPU) agree to GEMM-rounding tolerance."""
+    from fpqvar_amd import galt
+    x2, w2 = from_bits(golden["galt/fp4/x2_f32"]).to(dev), from_bits(golden["galt/fp4/w2_f32"]).to(dev)
+    assert_bits_equal(galt.FPQuant(x2), from_bits(golden["galt/fp4/x2_quant"]), "FPQuant(x2)")
+    assert_bits_equal(galt.FPQuant(w2), from_bits(golden["galt/fp4/w2_quant"]), "FPQuant(w2)")
+    x2, w2 = from_bits(golden["galt/fp6/x2_f32"]).to(dev), from_bits(golden["galt/fp6/w2_f32"]).to(dev)
+    assert_bits_equal(galt.FP6Quant_activation_per_token(x2), from_bits(golden["galt/fp6/x2_quant"]), "fp6 act")
+    assert_bits_equal(galt.FP6Quant_weight(w2), from_bits(golden["galt/fp6/w2_quant"]), "fp6 weight")
+    assert_bits_equal(galt.FP6Quant_activation(x2), from_bits(golden["galt/fp6/x2_quant_group"]), "fp6 act group")
+    x, w, s, q = (from_bits(golden[f"galt/{k}_f32"]).to(dev) for k in ("x", "w", "s", "q"))
+    for tag, tol in (("fp4", 2e-3), ("fp6", 2e-2)):
+        sp = torch.nn.Parameter(s.clone())
+        loss = galt.compute_quant_error(x, w, sp, q, tag)
+        loss.backward()
+        want_loss = float(from_bits(golden[f"galt/{tag}/loss"]))
+        want_grad = from_bits(golden[f"galt/{tag}/grad_s"])
+        assert abs(float(loss.detach()) - want_loss) <= tol * want_loss, (tag, float(loss.detach()), want_loss)
+        cos = torch.nn.functional.cosine_similarity(sp.grad.cpu().float(), want_grad, dim=0)
+        assert float(cos) > 0.99, (tag, float(cos))
+
+
+def test_galt_loop_equals_torch_argmin_loop(dev, golden):
+    """Same loop, same GPU, same matmuls: the fused argmin kernel vs the reference's distance-tensor lookup
+    written in torch ops.  Forward values are bit-equal, so the whole AdamW trajectory is identical."""
+    from fpqvar_amd import galt
+    x, w, _, q = (from_bits(golden[f"galt/{k}_f32"]).to(dev) for k in ("x", "w", "s", "q"))
+    grid = orc.TABLES["e2m1"].to(dev)
+
+    def torch_fpquant(t):
+        def fwd(v):
+            shape = v.shape
+            v = v.reshape(-1, 128)
+            scale = v.abs().max(dim=-1, keepdim=True)[0] / grid.abs().max()
+            v = v / scale
+            idx = torch.argmin(torch.abs(v.unsqueeze(-1) - grid), dim=-1)
+            return (grid[idx] * scale).view(shape)
+        return galt._STE.apply(t, fwd)
+
+    acts = [x[:32], x[32:]]
+    la, lb = [], []
+    sa = galt.learn_s(acts, w, q, epochs=4, fmt="fp4", log=la)
+    sb = galt.learn_s(acts, w, q, epochs=4, fmt="fp4", log=lb, act_quant=torch_fpquant, weight_quant=torch_fpquant)
+    assert la == lb
+    assert_bits_equal(sa, sb, "learned s")
+    assert la[-1] < la[0]
