@@ -530,10 +530,25 @@ __device__ __forceinline__ float negrev_shifted(float xf, float m) {
   return DT<T>::round(((xf <= 0.0f) ? xf : 0.0f) + m);
 }
 
+// (T)(x / s).  fp16: x and s carry 11-bit significands, so one residual step on x*rcp(s) lands on the
+// correctly rounded quotient (fpq_fast16.h, "exact fp16 division"); where it differs from IEEE
+// (s = 0 or non-finite: 0 / NaN instead of inf / 0) the quantizer maps both to level 0.
+template <typename T>
+__device__ __forceinline__ float div_round(float x, float s) {
+  if constexpr (sizeof(T) == 2) {
+    float inv = (s == 0.0f) ? 0.0f : __builtin_amdgcn_rcpf(s);
+    float y = x * inv;
+    float e = __builtin_fmaf(-y, s, x);
+    return DT<T>::round(__builtin_fmaf(e, inv, y));
+  } else {
+    return x / s;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ float quant_negrev(float xf, float xnr, float m, float snr, float sp, const Fmt& f) {
-  float a = DT<T>::round(xnr / snr);
-  float b = DT<T>::round(((xf > 0.0f) ? xf : 0.0f) / sp);
+  float a = div_round<T>(xnr, snr);
+  float b = div_round<T>((xf > 0.0f) ? xf : 0.0f, sp);
   uint32_t na = (a < 0.0f) ? 1u : 0u;
   float qa = quant_mag(fabsf(a), na, f);
   qa = (na && qa != 0.0f) ? -qa : qa;
