@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_fp4_kernel(const uint8_t* _
       v4f_t d[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        d[n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[m], bf[n], v4f_t{0, 0, 0, 0}, 4, 4, 0, 127, 0, 127);
+        d[n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[m], bf[n], v4f_t{0, 0, 0, 0}, 4, 4, 0, 0, 0, 0);   // literal zero scales select the unscaled instruction (x1.0, probed)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const v4f_t p = sa4[m] * sw1[n];
@@ -190,6 +190,220 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_fp4_kernel(const uint8_t* _
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Second-generation kernel: operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging
+// registers, no ds_write), wavefront tile 16*MT x 16*NT (128 x 64) so that one pair of fragment reads
+// feeds more matrix work, two waves per SIMD.  What the measurements in tools/probe/ say about this chip:
+//   * v_mfma_f32_16x16x128_f8f6f4 (FP4) issues every ~8.5 ns per SIMD (7.9 PFLOP/s chip-wide);
+//   * VALU work does not hide behind it (mfma + 8 v_fma = 18.5 ns vs 8.5 + 12.1 separately), and
+//     v_pk_fma_f32 costs as much as two v_fma_f32;
+//   * the scaled form (v_mfma_scale_*) pays an extra VALU slot for its scale operands.
+// So the per-group scale-and-accumulate (2 multiplies + 1 fma per output element and group) is the real
+// bound of this formulation (~19 ns per MFMA, ~3.5 PFLOP/s), and everything else has to stay out of its way.
+//
+// LDS image of a 16-row x 64-byte block (1 KiB, written by ONE LDS-DMA instruction, lane j -> bytes 16j):
+// lane j = 4*q + c fetches row q, 16-byte chunk c ^ pi[q >> 2], pi = (0,2,3,1): four consecutive lanes read
+// one row's 64 contiguous bytes from memory, and the fragment reads (lane l: row l & 15, chunk l >> 4,
+// ds_read_b128 served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) touch 16 distinct
+// 16-byte slots per group (checked exhaustively offline): conflict-free on both sides.
+__device__ __forceinline__ int glds_chunk_perm(int q) { return (0x78 >> ((q >> 2) << 1)) & 3; }   // pi = 0,2,3,1
+
+// Copy a [rows_valid x G] row-major scale tile (contiguous in memory, 16-byte aligned) into LDS as fp32 [G][rows]
+// (rows >= rows_valid; the tail rows are left untouched: their outputs are never stored).
+template <typename Ts, int NTHR>
+__device__ __forceinline__ void load_scale_tile(const Ts* __restrict__ src, float* __restrict__ dst, int rows, int rows_valid,
+                                                int G, int tid) {
+  constexpr int E = 16 / (int)sizeof(Ts);   // elements per 16-byte vector
+  const int n_valid = rows_valid * G;
+  const int n_vec = (n_valid + E - 1) / E;
+  for (int base = 0; base < n_vec; base += NTHR * 4) {
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = base + j * NTHR + tid;
+      v[j] = u32x4{0, 0, 0, 0};
+      if ((idx + 1) * E <= n_valid) {
+        v[j] = *(const u32x4*)(src + (int64_t)idx * E);
+      } else if (idx * E < n_valid) {   // the ragged last vector of the last row tile
+        Ts tmp[E];
+        for (int e = 0; e < E; ++e) tmp[e] = (idx * E + e < n_valid) ? src[(int64_t)idx * E + e] : (Ts)0;
+        __builtin_memcpy(&v[j], tmp, 16);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = base + j * NTHR + tid;
+      if (idx < n_vec) {
+        Ts tmp[E];
+        __builtin_memcpy(tmp, &v[j], 16);
+        int r = (idx * E) / G, g = idx * E - r * G;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (r < rows_valid) dst[g * rows + r] = (float)tmp[e];
+          if (++g == G) { g = 0; ++r; }
+        }
+      }
+    }
+  }
+}
+
+template <typename Tsw, int MT, int NT>
+__global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_kernel(const uint8_t* __restrict__ A,
+                                                              const _Float16* __restrict__ sa,
+                                                              const uint8_t* __restrict__ W, const Tsw* __restrict__ sw,
+                                                              const _Float16* __restrict__ bias,
+                                                              _Float16* __restrict__ out, int T, int O, int C) {
+  constexpr int WR = 2, WC = 2, BM = 16 * MT * WR, BN = 16 * NT * WC, NTHR = 256;
+  constexpr int ABLK = BM / 16, BBLK = BN / 16, NBLK = ABLK + BBLK, STAGE = NBLK * 1024;
+  static_assert(NBLK % 4 == 0, "blocks are dealt round-robin to the four wavefronts");
+  constexpr int PIECES = NBLK / 4;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int G = C >> 7, row_bytes = C >> 1;
+  float* lsa = (float*)(smem + 2 * STAGE);   // [G][BM]
+  float* lsw = lsa + G * BM;                 // [G][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_col = (O + BN - 1) / BN, n_row = (T + BM - 1) / BM;
+  const int cpx = (n_col + 7) >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int col_blk = xcd * cpx + local % cpx, row_blk = local / cpx;
+  if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
+  const int t0 = row_blk * BM, o0 = col_blk * BN;
+
+  // LDS-DMA sources of this wavefront's pieces (block = wave + 4*i of the stage), group 0
+  const uint8_t* src[PIECES];
+  {
+    const int q = lane >> 2, kb = (lane & 3) ^ glds_chunk_perm(q);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int blk = wave + 4 * i;
+      if (blk < ABLK) {
+        const int t = t0 + blk * 16 + q;
+        src[i] = A + (int64_t)(t < T ? t : T - 1) * row_bytes + kb * 16;
+      } else {
+        const int o = o0 + (blk - ABLK) * 16 + q;
+        src[i] = W + (int64_t)(o < O ? o : O - 1) * row_bytes + kb * 16;
+      }
+    }
+  }
+  auto issue = [&](int g, int buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + g * 64),
+                                       (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (wave + 4 * i) * 1024),
+                                       16, 0, 0);
+  };
+  issue(0, 0);
+
+  // Scale tiles -> LDS, transposed to [g][row] and widened to fp32.  The tile's scales are ONE contiguous run
+  // in memory (rows t0.. x G values), so they come in as independent 16-byte loads, four in flight per thread.
+  load_scale_tile<_Float16, NTHR>(sa + (int64_t)t0 * G, lsa, BM, (T - t0 < BM ? T - t0 : BM), G, tid);
+  load_scale_tile<Tsw, NTHR>(sw + (int64_t)o0 * G, lsw, BN, (O - o0 < BN ? O - o0 : BN), G, tid);
+
+  v4f_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = v4f_t{0, 0, 0, 0};
+
+  // fragment read offset inside a block: row lane & 15, chunk lane >> 4
+  const int frag_off = ((lane & 15) << 6) + ((((lane >> 4) ^ glds_chunk_perm(lane & 15)) & 3) << 4);
+  const int a_off = wm * MT * 1024 + frag_off, b_off = (ABLK + wn * NT) * 1024 + frag_off;
+  const int sa_off = wm * MT * 16 + 4 * (lane >> 4), sw_off = wn * NT * 16 + (lane & 15);
+
+  for (int g = 0; g < G; ++g) {
+    __syncthreads();   // stage g has landed (the fence drains the LDS-DMA queue); stage g^1's readers are done
+    if (g + 1 < G) issue(g + 1, (g + 1) & 1);
+    const uint8_t* st = smem + (g & 1) * STAGE;
+    // Fragment and scale reads run one tile row ahead of the matrix work (the compiler would otherwise
+    // issue each row's ds_reads right before their first use and expose the LDS latency eight times per
+    // group); sched_barrier keeps that order.
+    u32x4 bq[NT];
+    float sw1[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      bq[n] = *(const u32x4*)(st + b_off + n * 1024);
+      sw1[n] = lsw[g * BN + sw_off + n * 16];
+    }
+    u32x4 aq = *(const u32x4*)(st + a_off);
+    v4f_t sa4 = *(const v4f_t*)(lsa + g * BM + sa_off);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      u32x4 aq_n = aq;
+      v4f_t sa4_n = sa4;
+      if (m + 1 < MT) {
+        aq_n = *(const u32x4*)(st + a_off + (m + 1) * 1024);
+        sa4_n = *(const v4f_t*)(lsa + g * BM + sa_off + (m + 1) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const v8i_t af = v8i_t{(int)aq[0], (int)aq[1], (int)aq[2], (int)aq[3], 0, 0, 0, 0};
+      v4f_t d[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const v8i_t bf = v8i_t{(int)bq[n][0], (int)bq[n][1], (int)bq[n][2], (int)bq[n][3], 0, 0, 0, 0};
+        d[n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, v4f_t{0, 0, 0, 0}, 4, 4, 0, 0, 0, 0);
+      }
+      {
+        // scalar fp32 ops on purpose: beside MFMAs the packed forms cost more than two scalar ones
+        // (tools/probe/valu_mfma_overlap.hip; MI355X_MICROARCH.md, cycle constants)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            // the multiply reads an MFMA result: it stays a compiler-generated instruction so that the
+            // hazard recognizer places the wait states; the empty asm only stops the SLP packer
+            float t = d[n][i] * sa4[i];
+            asm("" : "+v"(t));
+            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[m][n][i]) : "v"(t), "v"(sw1[n]));
+          }
+      }
+      aq = aq_n;
+      sa4 = sa4_n;
+    }
+  }
+  __syncthreads();   // every wavefront is done with the staging buffers: the epilogue reuses them
+
+  // epilogue: bias, fp16, transpose each wavefront tile through LDS for 16-byte row stores
+  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT, LDW = WCOLS + 8;
+  _Float16* lo = (_Float16*)smem + wave * (WROWS * LDW);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n * 16 + (lane & 15);
+      const int o = o0 + wn * WCOLS + col;
+      const float b = (bias && o < O) ? (float)bias[o] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lo[(m * 16 + 4 * (lane >> 4) + i) * LDW + col] = (_Float16)(acc[m][n][i] + b);
+    }
+  __syncthreads();
+  constexpr int EP = WROWS * (WCOLS / 8);
+#pragma unroll
+  for (int pass = 0; pass < (EP + 63) / 64; ++pass) {
+    const int piece = pass * 64 + lane;
+    if (piece < EP) {
+      const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
+      const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
+      if (t < T && o + 8 <= O) {
+        *(u32x4*)(out + (int64_t)t * O + o) = *(const u32x4*)(lo + r * LDW + cpc * 8);
+      } else if (t < T) {
+        for (int e = 0; e < 8; ++e)
+          if (o + e < O) out[(int64_t)t * O + o + e] = lo[r * LDW + cpc * 8 + e];
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+struct GemmGldsCfg {
+  static constexpr int BM = 32 * MT, BN = 32 * NT;
+  static size_t lds(int G) {
+    size_t main = 2 * (size_t)(BM + BN) * 64 + (size_t)G * (BM + BN) * 4;
+    size_t epi = (size_t)4 * (16 * MT) * (16 * NT + 8) * 2;
+    return main > epi ? main : epi;
+  }
+};
 
 template <int MT, int NT, int WR, int WC>
 struct GemmCfg {

@@ -1441,10 +1441,11 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
   const int G = (int)(k / 128);
   hipStream_t st = (hipStream_t)stream;
-  // tile configuration: FPQ_GEMM_CFG = 0 (4 waves, 128x128, 64x64 per wave), 1 (8 waves, 128x128, 32x64),
-  // 2 (8 waves, 128x256, 64x64 per wave)
+  // Default: the LDS-DMA kernel with 128 x 128 tiles (three workgroups per CU); the register-staged kernel
+  // when its LDS image does not fit (very long K) or the scale arrays are not 16-byte aligned.
+  // FPQ_GEMM_CFG (experiments): 0..2 register-staged tilings, 10 / 20 LDS-DMA tilings (256x128, 128x128).
   const char* env = getenv("FPQ_GEMM_CFG");
-  const int cfg = env ? atoi(env) : 0;
+  const int cfg = env ? atoi(env) : 20;
 #define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
   do {                                                                                                               \
     using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
@@ -1460,6 +1461,28 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
                          Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,      \
                          (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                     \
   } while (0)
+#define FPQ_GEMM_GLDS(MT, NT)                                                                                        \
+  do {                                                                                                               \
+    using Cfg = GemmGldsCfg<MT, NT>;                                                                                 \
+    const size_t lds = Cfg::lds(G);                                                                                  \
+    if (lds <= 160 * 1024 && (((uintptr_t)a_scales | (uintptr_t)w_scales) & 15) == 0) {                              \
+      const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                \
+      const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                            \
+      if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                   \
+      if (w_scale_dtype == FPQ_F16)                                                                                  \
+        hipLaunchKernelGGL((gemm_fp4_glds_kernel<_Float16, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,      \
+                           a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,                   \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                   \
+      else                                                                                                           \
+        hipLaunchKernelGGL((gemm_fp4_glds_kernel<float, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,         \
+                           a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,                      \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                   \
+      return check_launch();                                                                                         \
+    }                                                                                                                \
+  } while (0)
+  if (cfg == 10) FPQ_GEMM_GLDS(8, 4);
+  if (cfg == 20) FPQ_GEMM_GLDS(4, 4);
+#undef FPQ_GEMM_GLDS
   if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
   else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
   else FPQ_GEMM_LAUNCH(4, 4, 2, 2);

@@ -8,6 +8,16 @@
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+__global__ void probe_unscaled(const uint32_t* a, const uint32_t* b, float* d) {
+  int l = threadIdx.x;
+  v8i av = {0, 0, 0, 0, 0, 0, 0, 0}, bv = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) { av[i] = (int)a[l * 4 + i]; bv[i] = (int)b[l * 4 + i]; }
+  v4f c = {0, 0, 0, 0};
+  // literal zero scales: the compiler selects v_mfma_f32_16x16x128_f8f6f4 (no v_mfma_ld_scale_b32 prefix)
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 4, 4, 0, 0, 0, 0);
+  for (int i = 0; i < 4; ++i) d[l * 4 + i] = c[i];
+}
+
 __global__ void probe(const uint32_t* a, const uint32_t* b, float* d, int scale_a, int scale_b) {
   int l = threadIdx.x;
   v8i av = {0, 0, 0, 0, 0, 0, 0, 0}, bv = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -35,9 +45,10 @@ int main() {
   uint32_t *da, *db; float* dd;
   hipMalloc(&da, sizeof(ha)); hipMalloc(&db, sizeof(hb)); hipMalloc(&dd, 64 * 4 * 4);
   hipMemcpy(da, ha, sizeof(ha), hipMemcpyHostToDevice); hipMemcpy(db, hb, sizeof(hb), hipMemcpyHostToDevice);
-  for (int sc = 0; sc < 2; ++sc) {
-    int sa = sc ? 128 : 127, sb = sc ? 126 : 127;   // 2^1 and 2^-1 in the second run
-    hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, da, db, dd, sa, sb);
+  for (int sc = 0; sc < 3; ++sc) {
+    int sa = sc ? 128 : 127, sb = sc ? 126 : 127;   // 2^1 and 2^-1 in the second run; third run: unscaled instruction
+    if (sc < 2) hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, da, db, dd, sa, sb);
+    else hipLaunchKernelGGL(probe_unscaled, dim3(1), dim3(64), 0, 0, da, db, dd);
     float hd[256];
     hipMemcpy(hd, dd, sizeof(hd), hipMemcpyDeviceToHost);
     int bad = 0;
