@@ -207,6 +207,22 @@ def test_per_group_vs_oracle(dev, qu, kind, dtype):
 
 
 @pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("group", (64, 32, 256))
+def test_other_group_sizes_vs_oracle(dev, qu, group, dtype):
+    """BASELINE.json names group_size 64/128; every reference function takes group_size as an argument."""
+    x = _inputs("heavy", (300, 1920), dtype, 40 + group)
+    x[7, :group] = 0
+    xd = x.to(dev)
+    assert_bits_equal(qu.fp_quant_e2_per_group_cuda(xd, 4, group), orc.per_group_kernel_sem(x, "e2m1", group), f"e2m1 g={group}")
+    assert_bits_equal(qu.fp6_quant_e3m2_per_group_cuda(xd, 6, group),
+                      orc.per_group_kernel_sem(x, "e3m2", group, out_dtype=torch.float16), f"e3m2 g={group}")
+    assert_bits_equal(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(xd, 4, group),
+                      orc.dual_per_group_kernel_sem(x, "e1m2_neg", "e2m1_pos", group, 1.0), f"dual fp4 g={group}")
+    assert_bits_equal(qu.fp6_quant_int_neg_e2m3_pos_per_group_cuda(xd, 6, group),
+                      orc.dual_per_group_kernel_sem(x, "int_neg", "e2m3_pos", group, None), f"dual fp6 g={group}")
+
+
+@pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
 @pytest.mark.parametrize("cols", (64, 1920, 2304, 7680, 9216, 1000, 8, 3))
 def test_per_token_vs_oracle(dev, qu, cols, dtype):
     x = _inputs("heavy", (37, cols), dtype, 22 + cols)
