@@ -40,6 +40,11 @@ _SIGS = {
                                                _c.c_void_p]),
     "fpq_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                           _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),
+    "fpq_rotate_quant_rows_codes_mx": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                                   _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_void_p]),
+    "fpq_adaln_rotate_quant_rows_codes_mx": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                                         _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
+                                                         _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_void_p]),
     "fpq_adaln_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
                                                 _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float,
                                                 _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),

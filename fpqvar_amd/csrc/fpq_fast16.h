@@ -166,6 +166,25 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
   return o;
 }
 
+// Same normalisation and bucketing as quant_vec16, but the table holds 4-bit hardware codes (OCP E2M1
+// nibbles, fpq_gemm_fp4.h): returns the 8 codes of the vector packed low nibble first.
+__device__ __forceinline__ uint32_t codes_vec16(const u32x4& w, const uint16_t* lut, int shift, float sf, float inv) {
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t wk = w[k];
+    const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
+    const float y0 = mul_h_lo(wk, inv), y1 = mul_h_hi(wk, inv);
+    const float e0 = __builtin_fmaf(-y0, sf, x0), e1 = __builtin_fmaf(-y1, sf, x1);
+    const float r0 = __builtin_fmaf(e0, inv, y0), r1 = __builtin_fmaf(e1, inv, y1);
+    const uint32_t rb = f2h2(r0, r1);
+    const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+    const uint32_t c0 = lut[(u & 0xFFFFu) >> shift], c1 = lut[u >> (16 + shift)];
+    packed |= (c0 | (c1 << 4)) << (8 * k);
+  }
+  return packed;
+}
+
 // |x| patterns of one vector reduced to a per-lane maximum (symmetric tables)
 __device__ __forceinline__ uint32_t vec_absmax16(const u32x4& w) {
   uint32_t m = pk_max_u16(pk_max_u16(w[0] & 0x7FFF7FFFu, w[1] & 0x7FFF7FFFu),
@@ -532,6 +551,9 @@ struct RotArgs {
   uint32_t sign[4];      // bit j set <=> D[j] = -1, j = 0..127
   float c_h;             // (float)half(float32(1/sqrt(128)))
   int64_t vec_per_row;   // cols / 8
+  uint16_t* code_scales; // nullptr: `out` receives fake-quantized fp16 values.  Otherwise `out` receives packed
+                         // hardware E2M1 codes (4 bytes per 8 elements), this array one fp16 scale per 128-group,
+                         // and the staged table is the code table (fpq_gemm_fp4.h)
 };
 
 __device__ __forceinline__ float xlane_xor4(float v) {
@@ -654,8 +676,17 @@ __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __re
       if (EMIT && live[u]) __builtin_nontemporal_store(y, rot_out + v0 + u * kBlock);
       uint32_t m = row_max_dpp<16>(vec_absmax16(y));
       RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
-      if (live[u]) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
+      if (r.code_scales) {
+        const uint32_t c = codes_vec16(y, lut, a.shift, s.sf, s.inv);
+        if (live[u]) {
+          const int64_t v = v0 + u * kBlock;
+          ((uint32_t*)out)[v] = c;
+          if (lg == 0) r.code_scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
+        }
+      } else {
+        u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+        if (live[u]) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
+      }
     }
   }
 }
@@ -855,8 +886,16 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
     if (y_out && live && row_live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
     uint32_t m = row_max_dpp<16>(vec_absmax16(y));
     RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-    u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
-    if (live && row_live) __builtin_nontemporal_store(o, out + row * vpr + v);
+    if (r.code_scales) {
+      const uint32_t cd = codes_vec16(y, lut, a.shift, s.sf, s.inv);
+      if (live && row_live) {
+        ((uint32_t*)out)[row * vpr + v] = cd;
+        if (lg == 0) r.code_scales[(row * vpr + v) >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
+      }
+    } else {
+      u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      if (live && row_live) __builtin_nontemporal_store(o, out + row * vpr + v);
+    }
   }
   }   // row loop
 }

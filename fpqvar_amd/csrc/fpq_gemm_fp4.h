@@ -431,19 +431,7 @@ __global__ __launch_bounds__(kBlock) void rows16_codes_mx_kernel(const u32x4* __
     const uint32_t m = row_max_dpp<16>(vec_absmax16(w));
     const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
     if ((threadIdx.x & 15) == 0) scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
-    uint32_t packed = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t wk = w[k];
-      const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
-      const float y0 = mul_h_lo(wk, s.inv), y1 = mul_h_hi(wk, s.inv);
-      const float e0 = __builtin_fmaf(-y0, s.sf, x0), e1 = __builtin_fmaf(-y1, s.sf, x1);
-      const float r0 = __builtin_fmaf(e0, s.inv, y0), r1 = __builtin_fmaf(e1, s.inv, y1);
-      const uint32_t rb = f2h2(r0, r1);
-      const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
-      const uint32_t c0 = lut[(u & 0xFFFFu) >> a.shift], c1 = lut[u >> (16 + a.shift)];
-      packed |= (c0 | (c1 << 4)) << (8 * k);
-    }
+    const uint32_t packed = codes_vec16(w, lut, a.shift, s.sf, s.inv);
     codes[v] = packed;
   }
 }

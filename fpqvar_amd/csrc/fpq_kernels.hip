@@ -1028,12 +1028,16 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   return FPQ_ERR_SHAPE;
 }
 
+inline const Lut16Tab& lut16_mx_codes_e2m1();
+
 template <typename Tin>
 int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, int64_t cols, const float* smooth,
-                        const uint32_t sign[4], int table_id, hipStream_t st) {
+                        const uint32_t sign[4], int table_id, hipStream_t st, uint16_t* code_scales = nullptr) {
   const Lut16Host& h = lut16_host(table_id, table_id);
   if (!h.tab_valid) return FPQ_ERR_TABLE;
+  const Lut16Tab& tab = code_scales ? lut16_mx_codes_e2m1() : h.tab;
   RotArgs r;
+  r.code_scales = code_scales;
   r.smooth = smooth;
   for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));   // torch.tensor(128).sqrt() is float32; autocast makes Q fp16
@@ -1044,20 +1048,22 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   if (rot_out)
     hipLaunchKernelGGL((rotate_quant16_kernel<Tin, true, U>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st, x,
-                       (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, h.tab);
+                       (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, tab);
   else
     hipLaunchKernelGGL((rotate_quant16_kernel<Tin, false, U>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st,
-                       x, (u32x4*)out, (u32x4*)nullptr, n_vec, r, h.args, h.tab);
+                       x, (u32x4*)out, (u32x4*)nullptr, n_vec, r, h.args, tab);
   return check_launch();
 }
 
 template <typename Tin, typename Tmod>
 int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out, int64_t rows, int64_t cols,
                               const AdaLnArgs& ad, const float* smooth, const uint32_t sign[4], int table_id,
-                              hipStream_t st, int lanes_per_row) {
+                              hipStream_t st, int lanes_per_row, uint16_t* code_scales = nullptr) {
   const Lut16Host& h = lut16_host(table_id, table_id);
   if (!h.tab_valid) return FPQ_ERR_TABLE;
+  const Lut16Tab& tab = code_scales ? lut16_mx_codes_e2m1() : h.tab;
   RotArgs r;
+  r.code_scales = code_scales;
   r.smooth = smooth;
   for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));
@@ -1071,7 +1077,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   const dim3 g((unsigned)g64);
   const int maxc = (int)((r.vec_per_row + lanes_per_row - 1) / lanes_per_row);
 #define FPQ_ADALN(L, M) hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, L, M>), g, dim3(kBlock), lds, st, x, \
-                                           (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, h.tab)
+                                           (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab)
   if (lanes_per_row == 256) {
     if (maxc <= 1) FPQ_ADALN(256, 1);
     else FPQ_ADALN(256, 2);
@@ -1354,8 +1360,9 @@ int fpq_quant_rows_neg_reverse(const void* x, void* out, int64_t rows, int64_t c
   return launch_negrev<float>(x, out, rows, cols, make_fmt(table_id), (hipStream_t)stream);
 }
 
-int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols, int in_dtype,
-                          const float* smooth, const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+static int rotate_quant_impl(const void* x, void* out, void* rotated_out, void* code_scales, int64_t rows, int64_t cols,
+                             int in_dtype, const float* smooth, const uint32_t* sign_mask_host, int table_id,
+                             fpq_stream_t stream) {
   if (rows < 0 || cols < 0 || !sign_mask_host) return FPQ_ERR_ARG;
   if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
   if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
@@ -1365,15 +1372,26 @@ int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t r
   if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)rotated_out | (uintptr_t)smooth) & 15) != 0) return FPQ_ERR_ARG;
   if (in_dtype == FPQ_F16)
     return launch_rotate_quant<_Float16>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
-                                         (hipStream_t)stream);
+                                         (hipStream_t)stream, (uint16_t*)code_scales);
   return launch_rotate_quant<float>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, (uint16_t*)code_scales);
 }
 
-int fpq_adaln_rotate_quant_rows(const void* x, void* out, void* h_out, void* rotated_out, int64_t rows, int64_t cols,
-                                int in_dtype, const void* scale, const void* shift, int mod_dtype,
-                                int64_t rows_per_batch, float eps, const float* smooth,
-                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols, int in_dtype,
+                          const float* smooth, const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  return rotate_quant_impl(x, out, rotated_out, nullptr, rows, cols, in_dtype, smooth, sign_mask_host, table_id, stream);
+}
+
+int fpq_rotate_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                                   const float* smooth, const uint32_t* sign_mask_host, fpq_stream_t stream) {
+  if (rows > 0 && cols > 0 && !scales) return FPQ_ERR_ARG;
+  return rotate_quant_impl(x, codes, nullptr, scales, rows, cols, in_dtype, smooth, sign_mask_host, FPQ_E2M1, stream);
+}
+
+static int adaln_rotate_quant_impl(const void* x, void* out, void* h_out, void* rotated_out, void* code_scales,
+                                   int64_t rows, int64_t cols, int in_dtype, const void* scale, const void* shift,
+                                   int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
+                                   const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
   if (rows < 0 || cols < 0 || rows_per_batch <= 0 || !sign_mask_host) return FPQ_ERR_ARG;
   if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
   if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (mod_dtype != FPQ_F16 && mod_dtype != FPQ_F32))
@@ -1399,12 +1417,29 @@ int fpq_adaln_rotate_quant_rows(const void* x, void* out, void* h_out, void* rot
   const int lpr = (lanes == 64) ? 64 : 256;
   hipStream_t st = (hipStream_t)stream;
 #define FPQ_GO(TI, TM) return launch_adaln_rotate_quant<TI, TM>(x, out, h_out, rotated_out, rows, cols, ad, smooth, \
-                                                              sign_mask_host, table_id, st, lpr)
+                                                              sign_mask_host, table_id, st, lpr, (uint16_t*)code_scales)
   if (in_dtype == FPQ_F16 && mod_dtype == FPQ_F16) FPQ_GO(_Float16, _Float16);
   if (in_dtype == FPQ_F16) FPQ_GO(_Float16, float);
   if (mod_dtype == FPQ_F16) FPQ_GO(float, _Float16);
   FPQ_GO(float, float);
 #undef FPQ_GO
+}
+
+int fpq_adaln_rotate_quant_rows(const void* x, void* out, void* h_out, void* rotated_out, int64_t rows, int64_t cols,
+                                int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                int64_t rows_per_batch, float eps, const float* smooth,
+                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  return adaln_rotate_quant_impl(x, out, h_out, rotated_out, nullptr, rows, cols, in_dtype, scale, shift, mod_dtype,
+                                 rows_per_batch, eps, smooth, sign_mask_host, table_id, stream);
+}
+
+int fpq_adaln_rotate_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols,
+                                         int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                         int64_t rows_per_batch, float eps, const float* smooth,
+                                         const uint32_t* sign_mask_host, fpq_stream_t stream) {
+  if (rows > 0 && cols > 0 && !scales) return FPQ_ERR_ARG;
+  return adaln_rotate_quant_impl(x, codes, nullptr, nullptr, scales, rows, cols, in_dtype, scale, shift, mod_dtype,
+                                 rows_per_batch, eps, smooth, sign_mask_host, FPQ_E2M1, stream);
 }
 
 int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int in_dtype,

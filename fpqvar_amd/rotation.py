@@ -98,6 +98,66 @@ def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor]
     return (out, rot) if return_rotated else out
 
 
+def _smooth_ptr(smooth, c, device):
+    if smooth is None:
+        return None, None
+    sm = smooth.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    if sm.numel() == 1:
+        sm = sm.expand(c).contiguous()
+    if sm.numel() != c:
+        raise RuntimeError("smooth must have one entry per channel")
+    return sm, sm.data_ptr()
+
+
+def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rotate_quant(x, "e2m1") emitting the FP4 GEMM's operands instead of values:
+    (codes uint8 [rows, C/2], scales fp16 [rows, C/128]); level(code) * scale == rotate_quant(x) bit for bit."""
+    require_gpu(x, "rotate_quant_mx")
+    if x.dtype not in (torch.float16, torch.float32) or x.shape[-1] % 128 != 0:
+        raise RuntimeError("rotate_quant_mx: x must be float16/float32 with a last dimension that is a multiple of 128")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    d = sign_vector(128, 42) if d is None else d
+    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    xc = x if x.is_contiguous() else x.contiguous()
+    sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
+    codes = torch.empty((rows, c // 2), dtype=torch.uint8, device=x.device)
+    scales = torch.empty((rows, c // 128), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_rotate_quant_rows_codes_mx(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c,
+                                                   dtype_id(x.dtype), sm_ptr, mask, stream_ptr(x.device)),
+              "fpq_rotate_quant_rows_codes_mx")
+    return codes, scales
+
+
+def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, d: Optional[torch.Tensor] = None,
+                          smooth: Optional[torch.Tensor] = None, eps: float = 1e-6) -> Tuple[torch.Tensor, torch.Tensor]:
+    """adaln_rotate_quant(x, scale, shift, "e2m1") emitting (codes uint8 [B*L, C/2], scales fp16 [B*L, C/128])."""
+    require_gpu(x, "adaln_rotate_quant_mx")
+    if x.dim() != 3:
+        raise RuntimeError("adaln_rotate_quant_mx: x must be [B, L, C]")
+    bsz, seq, c = x.shape
+    if c % 128 != 0 or c > 4096:
+        raise RuntimeError("adaln_rotate_quant_mx: C must be a multiple of 128 and at most 4096")
+    if scale.dtype != shift.dtype or scale.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("adaln_rotate_quant_mx: scale and shift must both be float16 or both float32")
+    sc = scale.reshape(bsz, c).contiguous()
+    sh = shift.reshape(bsz, c).contiguous()
+    d = sign_vector(128, 42) if d is None else d
+    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    xc = x if x.is_contiguous() else x.contiguous()
+    sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
+    codes = torch.empty((bsz * seq, c // 2), dtype=torch.uint8, device=x.device)
+    scales = torch.empty((bsz * seq, c // 128), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_adaln_rotate_quant_rows_codes_mx(
+            xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), bsz * seq, c, dtype_id(x.dtype), sc.data_ptr(),
+            sh.data_ptr(), dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, stream_ptr(x.device)),
+            "fpq_adaln_rotate_quant_rows_codes_mx")
+    return codes, scales
+
+
 def adaln_rotate_quant(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, table: str = "e2m1",
                        d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None, eps: float = 1e-6,
                        return_intermediates: bool = False):

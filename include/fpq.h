@@ -198,6 +198,19 @@ int fpq_quant_rows_codes(const void* x, uint8_t* codes, void* scales, int64_t ro
 int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols,
                             int in_dtype, fpq_stream_t stream);
 
+/* The fused producers of F1 emitting the FP4 GEMM's operand format directly (hardware E2M1 codes + one fp16
+ * scale per 128-group) instead of fake-quantized values: same arguments and the same arithmetic as
+ * fpq_rotate_quant_rows / fpq_adaln_rotate_quant_rows with table FPQ_E2M1, i.e. level(code) * scale is bit-equal
+ * to their `out`.  codes: [rows, cols/2]; scales: fp16 [rows, cols/128].  With these the activation never exists
+ * in HBM as fp16 between the block's LayerNorm and its matrix product (2 B read + 0.53 B written per element). */
+int fpq_rotate_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols,
+                                   int in_dtype, const float* smooth, const uint32_t* sign_mask_host,
+                                   fpq_stream_t stream);
+int fpq_adaln_rotate_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols,
+                                         int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                         int64_t rows_per_batch, float eps, const float* smooth,
+                                         const uint32_t* sign_mask_host, fpq_stream_t stream);
+
 /* out[t, o] = bias[o] + sum_g a_scale[t,g] * w_scale[o,g] * dot_128(levels(a)[t,g,:], levels(w)[o,g,:])
  * on the gfx950 block-scaled FP4 matrix cores (one 16x16x128 MFMA per group and 16x16 output tile,
  * exact products, fp32 accumulation); replaces F.linear(act_quant(x), W_q, b) of

@@ -879,3 +879,38 @@ def test_galt_loop_equals_torch_argmin_loop(dev, golden):
     assert la == lb
     assert_bits_equal(sa, sb, "learned s")
     assert la[-1] < la[0]
+
+
+# ------------------------------------------------------------------ F1 -> F2: producers emitting GEMM operands
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+def test_fused_producers_emit_fp4_operands(dev, x_dtype):
+    """rotate_quant_mx / adaln_rotate_quant_mx: level(code) * scale is bit-equal to the value-emitting kernels,
+    and the codes feed linear_fp4 with the same result as quantizing the rotated tensor separately."""
+    from fpqvar_amd import gemm, rotation as rot
+    g = torch.Generator().manual_seed(91)
+    B, L, C = 3, 50, 1920
+    x = (torch.randn(B, L, C, generator=g) * 2 + 0.3).to(x_dtype).to(dev)
+    x[1, 7, 256:384] = 0                      # one all-zero group after LayerNorm? no - but one in the plain rotate case
+    s = (torch.rand(C, generator=g) * 1.5 + 0.25).to(dev)
+    scale = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    shift = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    # plain rotate
+    x2 = x.reshape(B * L, C)
+    want = rot.rotate_quant(x2, "e2m1", smooth=s)
+    codes, scales = rot.rotate_quant_mx(x2, smooth=s)
+    assert codes.shape == (B * L, C // 2) and scales.shape == (B * L, C // 128) and scales.dtype == torch.float16
+    assert_bits_equal(gemm.dequantize_mx(codes, scales).half(), want, "rotate_quant_mx decode")
+    # whole producer
+    want, _, y = rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s, return_intermediates=True)
+    codes, scales = rot.adaln_rotate_quant_mx(x, scale, shift, smooth=s)
+    assert_bits_equal(gemm.dequantize_mx(codes, scales).half().view(B, L, C), want, "adaln_rotate_quant_mx decode")
+    c2, s2 = gemm.quantize_mx(y.reshape(B * L, C))
+    assert_bits_equal(gemm.dequantize_mx(c2, s2), gemm.dequantize_mx(codes, scales), "same operands as quantize_mx(rotated)")
+    assert torch.equal(s2, scales)
+    w = (torch.randn(256, C, generator=g) * 0.02).to(dev)
+    wc, ws = gemm.quantize_mx(w)
+    assert_bits_equal(gemm.linear_fp4(codes, scales, wc, ws), gemm.linear_fp4(c2, s2, wc, ws), "GEMM on the emitted codes")
+    # a group that rotates to all zeros: scale 0, codes 0
+    z = torch.zeros(4, 256, dtype=x_dtype, device=dev)
+    cz, sz = rot.rotate_quant_mx(z)
+    assert not cz.any() and not sz.any()

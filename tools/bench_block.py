@@ -113,12 +113,12 @@ def main():
         return gemm.linear_fp4(ac, asc, *fp4[name]).view(*y.shape[:-1], -1)
 
     def block_fp4(x):
-        _, _, y1 = rot.adaln_rotate_quant(x, scale1, shift1, "e2m1", smooth=s_qkv, return_intermediates=True)
-        a = attention(fp4_linear(y1, "qkv"))
+        ac, asc = rot.adaln_rotate_quant_mx(x, scale1, shift1, smooth=s_qkv)      # producer -> GEMM operands, one launch
+        a = attention(gemm.linear_fp4(ac, asc, *fp4["qkv"]).view(B, L, 3 * C))
         a = fp4_linear(a, "proj")
         x = x + a.mul(gamma1)
-        _, _, y2 = rot.adaln_rotate_quant(x, scale2, shift2, "e2m1", smooth=s_fc1, return_intermediates=True)
-        h = Fn.gelu(fp4_linear(y2, "fc1"), approximate="tanh")
+        ac, asc = rot.adaln_rotate_quant_mx(x, scale2, shift2, smooth=s_fc1)
+        h = Fn.gelu(gemm.linear_fp4(ac, asc, *fp4["fc1"]).view(B, L, HID), approximate="tanh")
         f = Fn.linear(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128), wq["fc2"])
         return x + f.mul(gamma2)
 
