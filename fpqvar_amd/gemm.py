@@ -85,3 +85,9 @@ class FP4Linear(torch.nn.Module):
         a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features))
         y = linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)
         return y.view(*lead, self.out_features)
+
+    @torch.no_grad()
+    def forward_operands(self, a_codes: torch.Tensor, a_scales: torch.Tensor) -> torch.Tensor:
+        """The same product for an activation that already is in operand form - what the fused producers
+        `rotation.rotate_quant_mx` / `rotation.adaln_rotate_quant_mx` emit: fp16 [tokens, out_features]."""
+        return linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)

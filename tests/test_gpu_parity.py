@@ -723,7 +723,8 @@ def test_mx_codes_reproduce_fake_quant(dev, qu):
     assert_bits_equal(gemm.dequantize_mx(wc, ws).view(384, 1920), orc.per_group_kernel_sem(w, "e2m1", 128), "fp32 weights")
 
 
-@pytest.mark.parametrize("T,O,K", ((256, 256, 1920), (1000, 5760, 1920), (130, 1928, 256), (64, 128, 7680)))
+@pytest.mark.parametrize("T,O,K", ((256, 256, 1920), (1000, 5760, 1920), (130, 1928, 256), (64, 128, 7680),
+                                   (20, 6912, 2304), (323, 9216, 2304), (1, 8, 128)))
 def test_fp4_gemm(dev, T, O, K):
     from fpqvar_amd import gemm
     import fpqvar_amd.quant_utils as qu
