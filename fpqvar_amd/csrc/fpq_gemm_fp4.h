@@ -207,49 +207,42 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_fp4_kernel(const uint8_t* _
 // one row's 64 contiguous bytes from memory, and the fragment reads (lane l: row l & 15, chunk l >> 4,
 // ds_read_b128 served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) touch 16 distinct
 // 16-byte slots per group (checked exhaustively offline): conflict-free on both sides.
-__device__ __forceinline__ int glds_chunk_perm(int q) { return (0x78 >> ((q >> 2) << 1)) & 3; }   // pi = 0,2,3,1
+#define FPQ_NOPK __attribute__((target("no-packed-fp32-ops")))   // callees must carry the kernel's target features to be inlined
+// __syncthreads() spelled out (the header's inline function does not carry the attribute and would become a call)
+#define FPQ_SYNC()                                             \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
+    __builtin_amdgcn_s_barrier();                              \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     \
+  } while (0)
+FPQ_NOPK __device__ __forceinline__ int glds_chunk_perm(int q) { return (0x78 >> ((q >> 2) << 1)) & 3; }   // pi = 0,2,3,1
 
-// Copy a [rows_valid x G] row-major scale tile (contiguous in memory, 16-byte aligned) into LDS as fp32 [G][rows]
-// (rows >= rows_valid; the tail rows are left untouched: their outputs are never stored).
-template <typename Ts, int NTHR>
-__device__ __forceinline__ void load_scale_tile(const Ts* __restrict__ src, float* __restrict__ dst, int rows, int rows_valid,
-                                                int G, int tid) {
-  constexpr int E = 16 / (int)sizeof(Ts);   // elements per 16-byte vector
-  const int n_valid = rows_valid * G;
-  const int n_vec = (n_valid + E - 1) / E;
-  for (int base = 0; base < n_vec; base += NTHR * 4) {
-    u32x4 v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = base + j * NTHR + tid;
-      v[j] = u32x4{0, 0, 0, 0};
-      if ((idx + 1) * E <= n_valid) {
-        v[j] = *(const u32x4*)(src + (int64_t)idx * E);
-      } else if (idx * E < n_valid) {   // the ragged last vector of the last row tile
-        Ts tmp[E];
-        for (int e = 0; e < E; ++e) tmp[e] = (idx * E + e < n_valid) ? src[(int64_t)idx * E + e] : (Ts)0;
-        __builtin_memcpy(&v[j], tmp, 16);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = base + j * NTHR + tid;
-      if (idx < n_vec) {
-        Ts tmp[E];
-        __builtin_memcpy(tmp, &v[j], 16);
-        int r = (idx * E) / G, g = idx * E - r * G;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          if (r < rows_valid) dst[g * rows + r] = (float)tmp[e];
-          if (++g == G) { g = 0; ++r; }
-        }
-      }
+// Scale tiles -> LDS as fp32 [G][rows]: one thread per tile row (activation rows first, then weight rows) walks
+// that row's G consecutive scales; rows past the end of the tensor read as zero (their outputs are never stored).
+template <typename Tsw, int BM, int BN, int NTHR>
+FPQ_NOPK __device__ __forceinline__ void load_scale_tiles(const _Float16* __restrict__ sa, const Tsw* __restrict__ sw, float* lsa,
+                                                 float* lsw, int t0, int o0, int T, int O, int G, int tid) {
+  for (int r = tid; r < BM + BN; r += NTHR) {
+    if (r < BM) {   // wave-uniform: BM is a multiple of 64
+      const bool ok = t0 + r < T;
+      const _Float16* src = sa + (int64_t)(ok ? t0 + r : 0) * G;
+#pragma unroll 5
+      for (int g = 0; g < G; ++g) lsa[g * BM + r] = ok ? (float)src[g] : 0.0f;
+    } else {
+      const int c = r - BM;
+      const bool ok = o0 + c < O;
+      const Tsw* src = sw + (int64_t)(ok ? o0 + c : 0) * G;
+#pragma unroll 5
+      for (int g = 0; g < G; ++g) lsw[g * BN + c] = ok ? (float)src[g] : 0.0f;
     }
   }
 }
 
+// target("no-packed-fp32-ops"): beside MFMAs a packed fp32 op costs as much as two scalar ones and blocks the issue
+// port twice as long (tools/probe/valu_mfma_overlap.hip); with the feature off the compiler emits scalar
+// v_mul_f32 / v_fma_f32 and schedules them - and the MFMA hazard wait states - itself.
 template <typename Tsw, int MT, int NT>
-__global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_kernel(const uint8_t* __restrict__ A,
+__global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4_glds_kernel(const uint8_t* __restrict__ A,
                                                               const _Float16* __restrict__ sa,
                                                               const uint8_t* __restrict__ W, const Tsw* __restrict__ sw,
                                                               const _Float16* __restrict__ bias,
@@ -287,19 +280,15 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_ker
       }
     }
   }
-  auto issue = [&](int g, int buf) {
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + g * 64),
-                                       (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (wave + 4 * i) * 1024),
-                                       16, 0, 0);
-  };
-  issue(0, 0);
+#define FPQ_GLDS_ISSUE(g, buf)                                                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < PIECES; ++i_)                                                             \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i_] + (g) * 64),        \
+                                       (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +            \
+                                                                                 (wave + 4 * i_) * 1024),           \
+                                       16, 0, 0)
+  FPQ_GLDS_ISSUE(0, 0);
 
-  // Scale tiles -> LDS, transposed to [g][row] and widened to fp32.  The tile's scales are ONE contiguous run
-  // in memory (rows t0.. x G values), so they come in as independent 16-byte loads, four in flight per thread.
-  load_scale_tile<_Float16, NTHR>(sa + (int64_t)t0 * G, lsa, BM, (T - t0 < BM ? T - t0 : BM), G, tid);
-  load_scale_tile<Tsw, NTHR>(sw + (int64_t)o0 * G, lsw, BN, (O - o0 < BN ? O - o0 : BN), G, tid);
+  load_scale_tiles<Tsw, BM, BN, NTHR>(sa, sw, lsa, lsw, t0, o0, T, O, G, tid);
 
   v4f_t acc[MT][NT];
 #pragma unroll
@@ -313,12 +302,14 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_ker
   const int sa_off = wm * MT * 16 + 4 * (lane >> 4), sw_off = wn * NT * 16 + (lane & 15);
 
   for (int g = 0; g < G; ++g) {
-    __syncthreads();   // stage g has landed (the fence drains the LDS-DMA queue); stage g^1's readers are done
-    if (g + 1 < G) issue(g + 1, (g + 1) & 1);
+    FPQ_SYNC();   // stage g has landed (the fence drains the LDS-DMA queue); stage g^1's readers are done
+    if (g + 1 < G) { FPQ_GLDS_ISSUE(g + 1, (g + 1) & 1); }
     const uint8_t* st = smem + (g & 1) * STAGE;
-    // Fragment and scale reads run one tile row ahead of the matrix work (the compiler would otherwise
-    // issue each row's ds_reads right before their first use and expose the LDS latency eight times per
-    // group); sched_barrier keeps that order.
+    // Software pipeline over the tile rows: the ds_reads of row m+1 are issued first, then the NT MFMAs of row m,
+    // then the scale-and-accumulate of row m-1 - VALU work that does not depend on the MFMAs in flight, so no
+    // hazard wait states are needed and 8 of each MFMA's 16 cycles of vector issue are hidden behind it.
+    // (Left to itself the compiler issues each row's reads right before their use and the VALU right behind its
+    // own MFMAs, with s_nops in between.)
     u32x4 bq[NT];
     float sw1[NT];
 #pragma unroll
@@ -328,8 +319,11 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_ker
     }
     u32x4 aq = *(const u32x4*)(st + a_off);
     v4f_t sa4 = *(const v4f_t*)(lsa + g * BM + sa_off);
+    v4f_t d_prev[NT], sa4_prev = sa4;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int n = 0; n < NT; ++n) d_prev[n] = v4f_t{0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m <= MT; ++m) {
       u32x4 aq_n = aq;
       v4f_t sa4_n = sa4;
       if (m + 1 < MT) {
@@ -337,32 +331,45 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_ker
         sa4_n = *(const v4f_t*)(lsa + g * BM + sa_off + (m + 1) * 16);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const v8i_t af = v8i_t{(int)aq[0], (int)aq[1], (int)aq[2], (int)aq[3], 0, 0, 0, 0};
       v4f_t d[NT];
+      if (m < MT) {
+        const v8i_t af = v8i_t{(int)aq[0], (int)aq[1], (int)aq[2], (int)aq[3], 0, 0, 0, 0};
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const v8i_t bf = v8i_t{(int)bq[n][0], (int)bq[n][1], (int)bq[n][2], (int)bq[n][3], 0, 0, 0, 0};
-        d[n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, v4f_t{0, 0, 0, 0}, 4, 4, 0, 0, 0, 0);
+        for (int n = 0; n < NT; ++n) {
+          const v8i_t bf = v8i_t{(int)bq[n][0], (int)bq[n][1], (int)bq[n][2], (int)bq[n][3], 0, 0, 0, 0};
+          // literal zero scale operands select the unscaled instruction (x 1.0; tools/probe/mfma_fp4_probe.hip)
+          d[n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, v4f_t{0, 0, 0, 0}, 4, 4, 0, 0, 0, 0);
+        }
       }
-      {
-        // scalar fp32 ops on purpose: beside MFMAs the packed forms cost more than two scalar ones
-        // (tools/probe/valu_mfma_overlap.hip; MI355X_MICROARCH.md, cycle constants)
+      if (m > 0) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            // the multiply reads an MFMA result: it stays a compiler-generated instruction so that the
-            // hazard recognizer places the wait states; the empty asm only stops the SLP packer
-            float t = d[n][i] * sa4[i];
-            asm("" : "+v"(t));
-            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[m][n][i]) : "v"(t), "v"(sw1[n]));
+            const float t = d_prev[n][i] * sa4_prev[i];
+            acc[m - 1][n][i] = __builtin_fmaf(t, sw1[n], acc[m - 1][n][i]);
           }
+      }
+      if (m > 0 && m < MT) {
+        // issue order inside the row: one MFMA, then the 8 VALU ops of one finished tile, NT times - an in-order
+        // wavefront that issues its MFMAs back to back just waits for the matrix pipe with its VALU idle
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < MT) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) d_prev[n] = d[n];
+        sa4_prev = sa4;
       }
       aq = aq_n;
       sa4 = sa4_n;
     }
   }
-  __syncthreads();   // every wavefront is done with the staging buffers: the epilogue reuses them
+  FPQ_SYNC();   // every wavefront is done with the staging buffers: the epilogue reuses them
 
   // epilogue: bias, fp16, transpose each wavefront tile through LDS for 16-byte row stores
   constexpr int WROWS = 16 * MT, WCOLS = 16 * NT, LDW = WCOLS + 8;
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_ker
 #pragma unroll
       for (int i = 0; i < 4; ++i) lo[(m * 16 + 4 * (lane >> 4) + i) * LDW + col] = (_Float16)(acc[m][n][i] + b);
     }
-  __syncthreads();
+  FPQ_SYNC();
   constexpr int EP = WROWS * (WCOLS / 8);
 #pragma unroll
   for (int pass = 0; pass < (EP + 63) / 64; ++pass) {
@@ -394,6 +401,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) void gemm_fp4_glds_ker
     }
   }
 }
+
+#undef FPQ_GLDS_ISSUE
 
 template <int MT, int NT>
 struct GemmGldsCfg {

@@ -1477,7 +1477,7 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
   const int G = (int)(k / 128);
   hipStream_t st = (hipStream_t)stream;
   // Default: the LDS-DMA kernel with 128 x 128 tiles (three workgroups per CU); the register-staged kernel
-  // when its LDS image does not fit (very long K) or the scale arrays are not 16-byte aligned.
+  // when its LDS image does not fit (very long K).
   // FPQ_GEMM_CFG (experiments): 0..2 register-staged tilings, 10 / 20 LDS-DMA tilings (256x128, 128x128).
   const char* env = getenv("FPQ_GEMM_CFG");
   const int cfg = env ? atoi(env) : 20;
@@ -1500,7 +1500,7 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
   do {                                                                                                               \
     using Cfg = GemmGldsCfg<MT, NT>;                                                                                 \
     const size_t lds = Cfg::lds(G);                                                                                  \
-    if (lds <= 160 * 1024 && (((uintptr_t)a_scales | (uintptr_t)w_scales) & 15) == 0) {                              \
+    if (lds <= 160 * 1024) {                                                                                         \
       const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                \
       const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                            \
       if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                   \

@@ -22,14 +22,16 @@ for cfg in (sys.argv[1:] or ["0", "3", "4", "5"]):
     if ref is None:
         ref = y
     same = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
-    for _ in range(5):
-        gemm.linear_fp4(ac, asc, wc, wsc)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
     for _ in range(20):
         gemm.linear_fp4(ac, asc, wc, wsc)
-    e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
+    ms = float("inf")
+    for _ in range(3):          # best of three bursts (the clock state of the box moves single bursts by 5-10 %)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            gemm.linear_fp4(ac, asc, wc, wsc)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = min(ms, e0.elapsed_time(e1) / 20)
     print(f"cfg {cfg}: {ms:.4f} ms  {2.0 * T * K * O / ms / 1e9:.0f} TFLOP/s  max_rel_diff_vs_first={same:.2e}", flush=True)
