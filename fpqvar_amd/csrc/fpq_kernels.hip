@@ -644,14 +644,83 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
 // The table index is wave-uniform, so table[j] is a scalar load (SGPR broadcast).
 // ---------------------------------------------------------------------------------
+// One element through the closed form of a built-in table (side: 0 symmetric, 1 values <= 0 only, 2 values >= 0 only)
+__device__ __forceinline__ float nearest_closed(float xv, const Fmt& f, int side) {
+  if (side == 0) {
+    uint32_t neg = xv < 0.0f ? 1u : 0u;
+    float qm = quant_mag(fabsf(xv), neg, f);
+    return (neg && qm != 0.0f) ? -qm : qm;
+  }
+  if (side == 1) {
+    // table holds only values <= 0: positive inputs fall on 0 (if within reach)
+    // (0.0 is also what "nothing within reach" yields, so no reach test is needed here)
+    float qm = (xv <= 0.0f) ? quant_mag(fabsf(xv), 1u, f) : 0.0f;
+    return (qm != 0.0f) ? -qm : 0.0f;
+  }
+  return (xv > 0.0f) ? quant_mag(xv, 0u, f) : 0.0f;
+}
+
+// The value tables this library knows in closed form, as the reference spells them (sorted, FP6 with two zeros).
+// Handed to the scan kernel by value: every workgroup compares the caller's table with them (bit for bit) once,
+// and a recognised table takes the closed form (~20 VALU ops per element) instead of the K-step scan
+// (3 ops per entry: 45 for K = 15, 190 for K = 64).  Same function of (x, table) either way - the closed form is
+// checked against the scan on every fp16 value, the neighbourhoods of every entry / midpoint / reach limit and
+// 2^26 random fp32 patterns per table (tests/test_gpu_parity.py).
+struct KnownTables {
+  float v[272];                 // all tables back to back (262 entries)
+  Fmt fmt[FPQ_NUM_TABLES];
+  int16_t off[FPQ_NUM_TABLES], k[FPQ_NUM_TABLES];
+  int8_t side[FPQ_NUM_TABLES];
+};
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void nearest_scan_kernel(const T* __restrict__ x,
                                                              const float* __restrict__ table,
-                                                             T* __restrict__ z, int64_t n, int k) {
+                                                             T* __restrict__ z, int64_t n, int k,
+                                                             KnownTables known) {
   __shared__ float tab[256];
+  __shared__ int match;
   if ((int)threadIdx.x < k) tab[threadIdx.x] = table[threadIdx.x];
+  if (threadIdx.x == 0) match = -1;
   __syncthreads();
+  if ((int)threadIdx.x < FPQ_NUM_TABLES && known.k[threadIdx.x] == k) {
+    bool same = true;
+    const float* kv = known.v + known.off[threadIdx.x];
+    for (int j = 0; j < k; ++j) same &= fbits(tab[j]) == fbits(kv[j]);
+    if (same) match = (int)threadIdx.x;   // the built-in tables are pairwise different: at most one writer
+  }
+  __syncthreads();
+  const int id = match;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (id >= 0) {
+    const Fmt f = known.fmt[id];
+    const int side = known.side[id];
+    if constexpr (sizeof(T) == 4) {
+      if ((((uintptr_t)x | (uintptr_t)z) & 15) == 0) {   // 16 bytes per lane, two vectors in flight
+        const int64_t n_vec = n >> 2;
+        const u32x4* xv = (const u32x4*)x;
+        u32x4* zv = (u32x4*)z;
+        for (int64_t v = (int64_t)blockIdx.x * (2 * kBlock) + threadIdx.x; v < n_vec; v += 2 * stride) {
+          const bool two = v + kBlock < n_vec;
+          u32x4 a = __builtin_nontemporal_load(xv + v);
+          u32x4 b = two ? __builtin_nontemporal_load(xv + v + kBlock) : u32x4{0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = fbits(nearest_closed(u2f(a[e]), f, side));
+            b[e] = fbits(nearest_closed(u2f(b[e]), f, side));
+          }
+          __builtin_nontemporal_store(a, zv + v);
+          if (two) __builtin_nontemporal_store(b, zv + v + kBlock);
+        }
+        for (int64_t i = (n_vec << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+          z[i] = (T)nearest_closed((float)x[i], f, side);
+        return;
+      }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+      z[i] = (T)nearest_closed((float)x[i], f, side);
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     float xv = (float)x[i];
     float best = 102400.0f, zv = 0.0f;
@@ -667,26 +736,12 @@ __global__ __launch_bounds__(kBlock) void nearest_scan_kernel(const T* __restric
   }
 }
 
-// closed form against a built-in table (signed input)
 __global__ __launch_bounds__(kBlock) void nearest_builtin_kernel(const float* __restrict__ x,
                                                                 float* __restrict__ z, int64_t n, Fmt f,
                                                                 int side /*0 sym, 1 neg-only, 2 pos-only*/) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    float xv = x[i];
-    float q;
-    if (side == 0) {
-      uint32_t neg = xv < 0.0f ? 1u : 0u;
-      float qm = quant_mag(fabsf(xv), neg, f);
-      q = (neg && qm != 0.0f) ? -qm : qm;
-    } else if (side == 1) {
-      // table holds only values <= 0: positive inputs fall on 0 (if within reach)
-      // (0.0 is also what "nothing within reach" yields, so no reach test is needed here)
-      float qm = (xv <= 0.0f) ? quant_mag(fabsf(xv), 1u, f) : 0.0f;
-      q = (qm != 0.0f) ? -qm : 0.0f;
-    } else {
-      q = (xv > 0.0f) ? quant_mag(xv, 0u, f) : 0.0f;
-    }
+    const float q = nearest_closed(x[i], f, side);
     z[i] = q;
   }
 }
@@ -1248,6 +1303,22 @@ int fpq_table_values(int table_id, float* host_out) {
   return n;
 }
 
+static const KnownTables& known_tables() {
+  static const KnownTables* kt = [] {
+    auto* t = new KnownTables();
+    int off = 0;
+    for (int id = 0; id < FPQ_NUM_TABLES; ++id) {
+      t->off[id] = (int16_t)off;
+      t->k[id] = (int16_t)fpq_table_values(id, t->v + off);
+      off += t->k[id];
+      t->fmt[id] = make_fmt(id);
+      t->side[id] = kTables[id].symmetric ? 0 : ((id == FPQ_E2M1_POS || id == FPQ_E2M3_POS) ? 2 : 1);
+    }
+    return t;
+  }();
+  return *kt;
+}
+
 int fpq_quant_nearest(const void* x, const float* table, void* z, int64_t n, int k, int dtype,
                       fpq_stream_t stream) {
   if (n < 0) return FPQ_ERR_ARG;
@@ -1258,11 +1329,11 @@ int fpq_quant_nearest(const void* x, const float* table, void* z, int64_t n, int
   hipStream_t st = (hipStream_t)stream;
   int g = grid_for((n + kBlock - 1) / kBlock);
   if (dtype == FPQ_F32)
-    hipLaunchKernelGGL(nearest_scan_kernel<float>, dim3(g), dim3(kBlock), 0, st, (const float*)x, table, (float*)z,
-                       n, k);
+    hipLaunchKernelGGL(nearest_scan_kernel<float>, dim3(grid_for((n / 4 + 2 * kBlock - 1) / (2 * kBlock) + 1, 4096)),
+                       dim3(kBlock), 0, st, (const float*)x, table, (float*)z, n, k, known_tables());
   else
     hipLaunchKernelGGL(nearest_scan_kernel<double>, dim3(g), dim3(kBlock), 0, st, (const double*)x, table,
-                       (double*)z, n, k);
+                       (double*)z, n, k, known_tables());
   return check_launch();
 }
 

@@ -81,8 +81,14 @@ def test_scan_kernel_vs_oracle(dev, name):
     x = torch.cat([all_fp16_as_f32(), neighbourhoods(tab),
                    (torch.rand(300000, generator=g) * 2 - 1) * float(tab.abs().max()) * 1.3,
                    torch.randn(1000, generator=g) * 1e5])
-    got = ops.quant_nearest(x.to(dev), tab.to(dev))
+    got = ops.quant_nearest(x.to(dev), tab.to(dev))          # a table the kernel recognises: closed-form path
+    assert_bits_equal(got, orc.nearest_kernel(x, tab), f"recognised table {name}")
+    dup = torch.cat([tab, tab[-1:]])                         # same function, one entry more: the literal scan runs
+    got = ops.quant_nearest(x.to(dev), dup.to(dev))
     assert_bits_equal(got, orc.nearest_kernel(x, tab), f"scan {name}")
+    x64 = x[:70000].double()
+    assert_bits_equal(ops.quant_nearest(x64.to(dev), tab.double().to(dev)), orc.nearest_kernel(x[:70000], tab).double(),
+                      f"recognised table, float64 {name}")
     # unsorted / arbitrary table: the literal scan must still agree
     perm = tab[torch.randperm(tab.numel(), generator=g)]
     got = ops.quant_nearest(x.to(dev), perm.to(dev))
@@ -102,8 +108,9 @@ def test_closed_form_vs_oracle_and_scan(dev, name):
     bits = torch.randint(-2**31, 2**31 - 1, (1 << 26,), dtype=torch.int64, device=dev).to(torch.int32)
     xr = bits.view(torch.float32)
     a = ops.quant_nearest_builtin(xr, name)
-    b = ops.quant_nearest(xr, tab.to(dev))
+    b = ops.quant_nearest(xr, torch.cat([tab, tab[-1:]]).to(dev))     # unrecognised spelling of the same table: scan
     assert_bits_equal(a, b, f"closed form vs scan, random bit patterns, {name}")
+    assert_bits_equal(ops.quant_nearest(xr, tab.to(dev)), b, f"recognised-table path vs scan, {name}")
 
 
 # ------------------------------------------------------------------ golden vectors
