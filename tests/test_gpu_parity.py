@@ -296,6 +296,49 @@ def test_exhaustive_fp16_scale_pairs(dev, qu):
                       orc.dual_per_group_kernel_sem(x, "e1m2_neg", "e2m1_pos", 128, 1.0), "scale sweep dual")
 
 
+@pytest.mark.parametrize("table", ("e2m1", "e1m2", "e3m0", "e2m3", "e3m2", "e1m2_neg+e2m1_pos", "int_neg+e2m3_pos"))
+def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table):
+    """EVERY (group maximum, element) pair of finite fp16 values - 1.0e9 per table, both signs - through the fast
+    fp16 kernel (3-op division, LUT rounding, packed fp16 multiply) and through the generic kernel (IEEE fp32
+    division, closed form, fp32 product; selected by asking for a float32 result), which the tests above pin to the
+    oracle.  The division trick of fpq_fast16.h is argued on paper; this is the same statement checked on hardware.
+    Dual formats: the group holds +max and -max, so both sides' scales sweep every magnitude too."""
+    from fpqvar_amd import ops
+    dual = "+" in table
+    lead = 2 if dual else 1
+    per = 128 - lead
+    total = 0
+    step = 512
+    distinct_out = set()
+    for lo in range(0, 0x7C00, step):
+        p = torch.arange(lo, min(lo + step, 0x7C00), device=dev, dtype=torch.int64)          # maxima, as bit patterns
+        n_val = 2 * (p + 1)                                                                  # signed candidates <= max
+        n_grp = (n_val + per - 1) // per
+        gm = torch.repeat_interleave(p, n_grp)                                               # max pattern of every group
+        first = torch.cumsum(n_grp, 0) - n_grp
+        start = (torch.arange(gm.numel(), device=dev) - torch.repeat_interleave(first, n_grp)) * per
+        idx = start[:, None] + torch.arange(per, device=dev)[None, :]                        # candidate index per slot
+        ok = idx < (2 * (gm + 1))[:, None]
+        pat = torch.where(ok, (idx >> 1) | ((idx & 1) << 15), torch.zeros_like(idx))
+        head = [gm[:, None]] + ([gm[:, None] | 0x8000] if dual else [])
+        x = torch.cat(head + [pat], dim=1).to(torch.int32).to(torch.int16).view(torch.float16)
+        assert int((x.view(torch.int16).to(torch.int32) & 0x7FFF).max()) == min(lo + step, 0x7C00) - 1
+        if dual:
+            neg, pos = table.split("+")
+            fast = ops.quant_rows_dual(x, neg, pos, 128, None)
+            ieee = ops.quant_rows_dual(x, neg, pos, 128, None, out_dtype=torch.float32).half()
+        else:
+            fast = ops.quant_rows(x, table, 128, torch.float16)
+            ieee = ops.quant_rows(x, table, 128, torch.float32).half()
+        bad = fast.view(torch.int16) != ieee.view(torch.int16)
+        assert not bool(bad.any()), (table, lo, x[bad][:4].tolist(), fast[bad][:4].tolist(), ieee[bad][:4].tolist())
+        total += int(ok.sum())
+        if lo % (step * 8) == 0:
+            distinct_out.update(torch.unique(fast.view(torch.int16)).tolist()[:4096])
+    assert total == sum(2 * (q + 1) for q in range(0x7C00)) == 1_007_713_280
+    assert len(distinct_out) > 1000                                   # the sweep really produced a spread of results
+
+
 # ------------------------------------------------------------------ shapes, raggedness, errors
 def test_edge_shapes_and_errors(dev, qu):
     from fpqvar_amd import ops
