@@ -301,7 +301,8 @@ def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table):
     """EVERY (group maximum, element) pair of finite fp16 values - 1.0e9 per table, both signs - through the fast
     fp16 kernel (3-op division, LUT rounding, packed fp16 multiply) and through the generic kernel (IEEE fp32
     division, closed form, fp32 product; selected by asking for a float32 result), which the tests above pin to the
-    oracle.  The division trick of fpq_fast16.h is argued on paper; this is the same statement checked on hardware.
+    oracle, and through the reference's own ~11-op torch sequence on this GPU around the literal scan kernel.
+    The division trick of fpq_fast16.h is argued on paper; this is the same statement checked on hardware.
     Dual formats: the group holds +max and -max, so both sides' scales sweep every magnitude too."""
     from fpqvar_amd import ops
     dual = "+" in table
@@ -332,6 +333,25 @@ def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table):
             ieee = ops.quant_rows(x, table, 128, torch.float32).half()
         bad = fast.view(torch.int16) != ieee.view(torch.int16)
         assert not bool(bad.any()), (table, lo, x[bad][:4].tolist(), fast[bad][:4].tolist(), ieee[bad][:4].tolist())
+        # ... and against the reference's own op sequence executed by torch-ROCm in real fp16 arithmetic around the
+        # LITERAL scan (the duplicated last entry keeps the kernel from recognising the table)
+        if dual:
+            tn, tp = orc.TABLES[neg].to(dev), orc.TABLES[pos].to(dev)
+            zeros = torch.zeros_like(x)
+            x_neg, x_pos = torch.where(x <= 0, x, zeros), torch.where(x > 0, x, zeros)
+            s_neg = x_neg.abs().max(dim=-1, keepdim=True)[0] / tn.abs().max()
+            s_pos = x_pos.abs().max(dim=-1, keepdim=True)[0] / tp.abs().max()
+            q_neg = ops.quant_nearest((x_neg / s_neg).view(-1).to(torch.float32), torch.cat([tn, tn[-1:]])).view(x.shape)
+            q_pos = ops.quant_nearest((x_pos / s_pos).view(-1).to(torch.float32), torch.cat([tp, tp[-1:]])).view(x.shape)
+            seq = (q_neg * s_neg + q_pos * s_pos).to(torch.float16)
+        else:
+            tab = orc.TABLES[table].to(dev)
+            scale = x.abs().max(dim=-1, keepdim=True)[0] / tab.abs().max()
+            q = ops.quant_nearest((x / scale).view(-1).to(torch.float32), torch.cat([tab, tab[-1:]])).view(x.shape)
+            seq = (q * scale).to(torch.float16)
+        bad = fast.view(torch.int16) != seq.view(torch.int16)
+        assert not bool(bad.any()), ("vs torch sequence", table, lo, x[bad][:4].tolist(), fast[bad][:4].tolist(),
+                                     seq[bad][:4].tolist())
         total += int(ok.sum())
         if lo % (step * 8) == 0:
             distinct_out.update(torch.unique(fast.view(torch.int16)).tolist()[:4096])
