@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Model-shaped end to end (BASELINE.json config 3): the transformer part of one VAR-d30
+256x256 generation batch - 10 scale steps (patch_nums 1..16, 680 tokens), 30 AdaLN blocks per step, B = 100 rows per
+token (50 images x CFG), W4A4 per-group fp_e2 + fc2 dual format + block rotation + GALT smoothing + KV cache in FP6
+(run.sh line 4) - with random weights (no checkpoints exist offline), every block sharing one set of weight tensors.
+Word embedding, class conditioning, the VQVAE decoder and sampling are not part of the quantized path and are left out.
+
+Three ways to run everything around the attention core:
+  R  Level 0 of INTEGRATION.md: the reference's own op sequence (its ~11 torch ops per quantizer around
+     quant_cuda.quant, dense fp16 GEMM with the block-diagonal Q, fp16 Linears on de-quantized tensors, the whole KV
+     cache re-quantized at every step)
+  F  Level 1 + 1b: one launch per quantizer, fused LayerNorm/modulate/smooth/rotate/quant producer, incremental KV
+  Q  F with mat_qkv / proj / fc1 on the FP4 matrix cores (producers emit the GEMM operands directly)
+Prints the time per batch for each and the speed-ups.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.nn.functional as Fn  # noqa: E402
+
+import quant_cuda  # noqa: E402  (the drop-in module)
+from fpqvar_amd import gemm, kv_cache, quant_utils as qu, rotation as rot  # noqa: E402
+
+PATCH_NUMS = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
+
+
+def ref_sym(x, grid, group=None, out_dtype=None):
+    """fp_quant_e2_per_group_cuda / fp6_quant_e2m3_per_token_cuda as the reference spells them."""
+    shape = x.shape
+    xs = x.reshape(-1, group) if group else x
+    scale = xs.abs().max(dim=-1, keepdim=True)[0] / grid.abs().max()
+    q, _ = quant_cuda.quant((xs / scale).view(-1).to(torch.float32), grid)
+    return (q.view(xs.shape) * scale).view(shape).to(out_dtype or x.dtype)
+
+
+def ref_dual(x, gneg, gpos, group=128):
+    clip = 1.0 * x.abs().max()
+    x = torch.clamp(x, -clip, clip)
+    shape = x.shape
+    xs = x.reshape(-1, group)
+    zeros = torch.zeros_like(xs)
+    xn_, xp_ = torch.where(xs <= 0, xs, zeros), torch.where(xs > 0, xs, zeros)
+    sn = xn_.abs().max(dim=-1, keepdim=True)[0] / gneg.abs().max()
+    sp = xp_.abs().max(dim=-1, keepdim=True)[0] / gpos.abs().max()
+    qa, _ = quant_cuda.quant((xn_ / sn).view(-1).to(torch.float32), gneg)
+    qb, _ = quant_cuda.quant((xp_ / sp).view(-1).to(torch.float32), gpos)
+    return (qa.view(xs.shape) * sn + qb.view(xs.shape) * sp).view(shape).to(x.dtype)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--depth", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=100)
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    C, H, HID, B, depth = 64 * 30, 30, 4 * 64 * 30, args.batch, args.depth
+    hd = C // H
+    s_qkv, s_fc1 = torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5
+    q64 = rot.block_random_hadamard_matrix(C, 128, dev, 42)
+    q32 = q64.float()
+
+    def lin_w(o, i, smooth=None, rotate=False):
+        w = torch.randn(o, i, device=dev) * 0.02
+        if smooth is not None:
+            w = rot.transform_weight(w, smooth)
+        return rot.rotate_weight(w, q64) if rotate else w
+
+    w32 = {"qkv": lin_w(3 * C, C, s_qkv, True), "proj": lin_w(C, C), "fc1": lin_w(HID, C, s_fc1, True), "fc2": lin_w(C, HID)}
+    wq = {n: qu.fp_quant_e2_per_group_cuda(w, 4, 128).half() for n, w in w32.items()}
+    fp4 = {n: gemm.quantize_mx(w32[n]) for n in ("qkv", "proj", "fc1")}
+    mods = [[(torch.randn(B, 1, C, device=dev) * 0.2).half() for _ in range(6)] for _ in range(depth)]
+    e2m1 = qu.fp4_e2m1_grid.to(dev)
+    e2m3 = qu.fp6_e2m3_grid.to(dev)
+    gneg = torch.tensor([-1.75, -1.5, -1.25, -1.0, -0.75, -0.5, -0.25, 0.0], device=dev)
+    gpos = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], device=dev)
+    max_len = sum(p * p for p in PATCH_NUMS)
+
+    def attend(q, kc, vc):                      # q [B,L,H,c]; kc, vc [B,Ltot,H,c] (flash layout, as the KV runs use)
+        o = Fn.scaled_dot_product_attention(q.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2))
+        return o.transpose(1, 2).reshape(q.shape[0], q.shape[1], C)
+
+    def run(path):
+        caches = [None] * depth
+        if path != "R":
+            caches = [kv_cache.IncrementalKVCache(B, max_len, H, hd, 6, device=dev) for _ in range(depth)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for pn in PATCH_NUMS:
+            L = pn * pn
+            x = torch.randn(B, L, C, device=dev).half()
+            for b in range(depth):
+                g1, g2, sc1, sc2, sh1, sh2 = mods[b]
+                if path == "R":
+                    with torch.autocast("cuda", dtype=torch.float16):
+                        x1 = torch.matmul(Fn.layer_norm(x, (C,), eps=1e-6).mul(sc1.add(1)).add_(sh1).mul(s_qkv), q32)
+                        qkv = Fn.linear(ref_sym(x1, e2m1, 128), wq["qkv"]).view(B, L, 3, H, hd)
+                        q, k, v = qkv.unbind(2)
+                        if caches[b] is None:
+                            kc, vc = k, v
+                        else:                                        # tr/basic_var.py:186-209: whole cache, every step
+                            ck, cv = caches[b]
+                            ck = ref_sym(ck.contiguous(), e2m3, None, torch.float16)
+                            cv = ref_sym(cv.contiguous(), e2m3, None, torch.float16)
+                            kc, vc = torch.cat((ck, k), dim=1), torch.cat((cv, v), dim=1)
+                        caches[b] = (kc, vc)
+                        a = Fn.linear(ref_sym(attend(q, kc, vc), e2m1, 128), wq["proj"])
+                        x = x + a.mul(g1)
+                        x2 = torch.matmul(Fn.layer_norm(x, (C,), eps=1e-6).mul(sc2.add(1)).add_(sh2).mul(s_fc1), q32)
+                        h = Fn.gelu(Fn.linear(ref_sym(x2, e2m1, 128), wq["fc1"]), approximate="tanh")
+                        x = x + Fn.linear(ref_dual(h, gneg, gpos), wq["fc2"]).mul(g2)
+                    continue
+                if path == "F":
+                    qkv = Fn.linear(rot.adaln_rotate_quant(x, sc1, sh1, "e2m1", smooth=s_qkv), wq["qkv"])
+                else:
+                    qkv = gemm.linear_fp4(*rot.adaln_rotate_quant_mx(x, sc1, sh1, smooth=s_qkv), *fp4["qkv"])
+                q, k, v = qkv.view(B, L, 3, H, hd).unbind(2)
+                kc, vc = caches[b].append(k, v)
+                a = attend(q, kc, vc)
+                if path == "F":
+                    a = Fn.linear(qu.fp_quant_e2_per_group_cuda(a, 4, 128), wq["proj"])
+                else:
+                    a = gemm.linear_fp4(*gemm.quantize_mx(a.view(B * L, C)), *fp4["proj"]).view(B, L, C)
+                x = x + a.mul(g1)
+                if path == "F":
+                    h = Fn.linear(rot.adaln_rotate_quant(x, sc2, sh2, "e2m1", smooth=s_fc1), wq["fc1"])
+                else:
+                    h = gemm.linear_fp4(*rot.adaln_rotate_quant_mx(x, sc2, sh2, smooth=s_fc1), *fp4["fc1"]).view(B, L, HID)
+                h = Fn.gelu(h, approximate="tanh")
+                x = x + Fn.linear(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128), wq["fc2"]).mul(g2)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    res = {"workload": f"VAR-d30 256x256 transformer part, {depth} blocks x 10 steps, B={B} (CFG), W4A4 + FP6 KV cache, random weights",
+           "depth": depth, "batch_rows": B}
+    for path in ("F", "Q", "R"):
+        run(path)                                   # warm-up (allocator, kernel load)
+        res[f"{path}_ms_per_batch"] = round(min(run(path) for _ in range(args.reps)), 1)
+    res["speedup_F_vs_R"] = round(res["R_ms_per_batch"] / res["F_ms_per_batch"], 2)
+    res["speedup_Q_vs_R"] = round(res["R_ms_per_batch"] / res["Q_ms_per_batch"], 2)
+    res["images_per_s_Q"] = round((B // 2) / (res["Q_ms_per_batch"] / 1e3), 1)
+    res["images_per_s_R"] = round((B // 2) / (res["R_ms_per_batch"] / 1e3), 1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
