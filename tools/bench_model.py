@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--depth", type=int, default=30)
     ap.add_argument("--batch", type=int, default=100)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--paths", default="F,Q,R")
+    ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -86,15 +88,48 @@ def main():
         o = Fn.scaled_dot_product_attention(q.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2))
         return o.transpose(1, 2).reshape(q.shape[0], q.shape[1], C)
 
+    def new_caches(path):
+        if path == "R":
+            return [None] * depth
+        return [kv_cache.IncrementalKVCache(B, max_len, H, hd, 6, device=dev) for _ in range(depth)]
+
     def run(path):
-        caches = [None] * depth
-        if path != "R":
-            caches = [kv_cache.IncrementalKVCache(B, max_len, H, hd, 6, device=dev) for _ in range(depth)]
+        caches = new_caches(path)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for pn in PATCH_NUMS:
-            L = pn * pn
-            x = torch.randn(B, L, C, device=dev).half()
+            x = torch.randn(B, pn * pn, C, device=dev).half()
+            step(path, caches, x)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    def run_graphed(path):
+        """One hipGraph per scale step (static shapes), captured in step order so that the KV-cache bookkeeping on
+        the host advances exactly as in an eager run; a batch is then 10 graph launches."""
+        caches = new_caches(path)
+        pool = torch.cuda.graph_pool_handle()
+        graphs, inputs = [], []
+        for pn in PATCH_NUMS:
+            x = torch.randn(B, pn * pn, C, device=dev).half()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                step(path, caches, x)
+            graphs.append(g)
+            inputs.append(x)
+        best = float("inf")
+        for _ in range(args.reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for g in graphs:
+                g.replay()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) * 1e3)
+        del graphs
+        return best
+
+    def step(path, caches, x):
+        if True:
+            L = x.shape[1]
             for b in range(depth):
                 g1, g2, sc1, sc2, sh1, sh2 = mods[b]
                 if path == "R":
@@ -134,18 +169,28 @@ def main():
                     h = gemm.linear_fp4(*rot.adaln_rotate_quant_mx(x, sc2, sh2, smooth=s_fc1), *fp4["fc1"]).view(B, L, HID)
                 h = Fn.gelu(h, approximate="tanh")
                 x = x + Fn.linear(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128), wq["fc2"]).mul(g2)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) * 1e3
+        return x
 
     res = {"workload": f"VAR-d30 256x256 transformer part, {depth} blocks x 10 steps, B={B} (CFG), W4A4 + FP6 KV cache, random weights",
            "depth": depth, "batch_rows": B}
-    for path in ("F", "Q", "R"):
+    paths = args.paths.split(",")
+    for path in paths:
         run(path)                                   # warm-up (allocator, kernel load)
         res[f"{path}_ms_per_batch"] = round(min(run(path) for _ in range(args.reps)), 1)
-    res["speedup_F_vs_R"] = round(res["R_ms_per_batch"] / res["F_ms_per_batch"], 2)
-    res["speedup_Q_vs_R"] = round(res["R_ms_per_batch"] / res["Q_ms_per_batch"], 2)
-    res["images_per_s_Q"] = round((B // 2) / (res["Q_ms_per_batch"] / 1e3), 1)
-    res["images_per_s_R"] = round((B // 2) / (res["R_ms_per_batch"] / 1e3), 1)
+        torch.cuda.empty_cache()
+        if args.no_graphs:
+            continue
+        try:
+            res[f"{path}_ms_per_batch_hipgraph"] = round(run_graphed(path), 1)
+        except Exception as e:      # extra information only
+            res[f"{path}_ms_per_batch_hipgraph"] = f"error: {str(e)[:120]}"
+        torch.cuda.empty_cache()
+    if "R" in paths:
+        for pth in ("F", "Q"):
+            if pth in paths:
+                res[f"speedup_{pth}_vs_R"] = round(res["R_ms_per_batch"] / res[f"{pth}_ms_per_batch"], 2)
+    for pth in paths:
+        res[f"images_per_s_{pth}"] = round((B // 2) / (res[f"{pth}_ms_per_batch"] / 1e3), 1)
     print(json.dumps(res))
 
 
