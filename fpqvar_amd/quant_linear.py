@@ -148,23 +148,37 @@ class QuantizedLinear_fc2(QuantizedLinear):
 
 def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=False, w_bit=8, a_bit=8, kv_bit=8,
                  act_quant_sym=None, fc2_act_log2_quant=None, quant_kv=None, activation_fp_quant=False,
-                 weight_fp_quant=False, act_fp_type=None, weight_fp_type=None, fc2_fp_type=None):
+                 weight_fp_quant=False, act_fp_type=None, weight_fp_type=None, fc2_fp_type=None, real_fp4=False):
     """tr/quant_utils.py:1095-1167.  The reference matches its own FFN / SelfAttention
     classes; here a module with Linear children ``fc1``+``fc2`` is an FFN and one with
     ``mat_qkv``+``proj`` is a self-attention block.  As in the reference,
     ``quantize_bmm_input``, ``kv_bit`` and ``quant_kv`` are accepted and ignored, the
-    ada_lin Linears stay in full precision, and fc2's input format is ``fc2_fp_type``."""
+    ada_lin Linears stay in full precision, and fc2's input format is ``fc2_fp_type``.
+
+    ``real_fp4`` (additive, default off = the reference's behaviour): in the W4A4 per-group ``fp_e2`` configuration
+    fc1 / mat_qkv / proj become ``gemm.FP4Linear`` - same quantization decisions, product on the FP4 matrix cores
+    instead of an fp16 GEMM on de-quantized tensors (fc2 keeps its dual-format fake quantization)."""
+    fp4_ok = (real_fp4 and weight_quant == "per_group" and act_quant == "per_group" and w_bit == 4 and a_bit == 4
+              and activation_fp_quant and weight_fp_quant and act_fp_type == "fp_e2" and weight_fp_type == "fp_e2")
+    if real_fp4 and not fp4_ok:
+        raise ValueError("real_fp4 needs weight_quant = act_quant = 'per_group', w_bit = a_bit = 4, fp_e2 on both sides")
     common = dict(weight_quant=weight_quant, act_quant=act_quant, w_bit=w_bit, a_bit=a_bit,
                   activation_fp_quant=activation_fp_quant, weight_fp_quant=weight_fp_quant,
                   weight_fp_type=weight_fp_type)
+    def plain(lin, **kw):
+        if fp4_ok and lin.in_features % 128 == 0 and lin.out_features % 8 == 0:
+            from .gemm import FP4Linear
+            return FP4Linear.from_float(lin)
+        return QuantizedLinear.from_float(lin, **kw)
+
     for _, m in list(model.named_modules()):
         fc1, fc2 = getattr(m, "fc1", None), getattr(m, "fc2", None)
         qkv, proj = getattr(m, "mat_qkv", None), getattr(m, "proj", None)
         if isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear):
-            m.fc1 = QuantizedLinear.from_float(fc1, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+            m.fc1 = plain(fc1, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
             m.fc2 = QuantizedLinear_fc2.from_float(fc2, act_quant_sym=False, fc2_act_log2_quant=fc2_act_log2_quant,
                                                    act_fp_type=fc2_fp_type, **common)
         elif isinstance(qkv, nn.Linear) and isinstance(proj, nn.Linear):
-            m.mat_qkv = QuantizedLinear.from_float(qkv, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
-            m.proj = QuantizedLinear.from_float(proj, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+            m.mat_qkv = plain(qkv, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+            m.proj = plain(proj, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
     return model

@@ -985,3 +985,40 @@ def test_fused_producers_emit_fp4_operands(dev, x_dtype):
     z = torch.zeros(4, 256, dtype=x_dtype, device=dev)
     cz, sz = rot.rotate_quant_mx(z)
     assert not cz.any() and not sz.any()
+
+
+def test_quantize_var_real_fp4(dev):
+    """quantize_VAR(..., real_fp4=True): fc1 / mat_qkv / proj become FP4Linear, fc2 keeps its dual-format fake quant;
+    outputs agree with the default (fake-quant + fp16 GEMM) model to GEMM tolerance."""
+    import copy
+    from fpqvar_amd import gemm, quant_linear as ql
+
+    class FFN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.fc2 = torch.nn.Linear(256, 512), torch.nn.Linear(512, 256)
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mat_qkv, self.proj = torch.nn.Linear(256, 768, bias=False), torch.nn.Linear(256, 256)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.ffn, self.attn = FFN(), Attn()
+
+    cfg = dict(weight_quant="per_group", act_quant="per_group", w_bit=4, a_bit=4, act_quant_sym=True, activation_fp_quant=True,
+               weight_fp_quant=True, act_fp_type="fp_e2", weight_fp_type="fp_e2", fc2_fp_type="fp_e1m2_neg_e2m1_pos")
+    base = Toy().to(dev)
+    fake = ql.quantize_VAR(copy.deepcopy(base), **cfg).half()
+    real = ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, **cfg)
+    assert isinstance(real.ffn.fc1, gemm.FP4Linear) and isinstance(real.attn.mat_qkv, gemm.FP4Linear)
+    assert isinstance(real.attn.proj, gemm.FP4Linear) and type(real.ffn.fc2).__name__ == "QuantizedLinear_fc2"
+    x = torch.randn(70, 256, device=dev).half()
+    for a, b in ((fake.ffn.fc1, real.ffn.fc1), (fake.attn.mat_qkv, real.attn.mat_qkv), (fake.attn.proj, real.attn.proj)):
+        ya, yb = a(x).float(), b(x).float()
+        assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
+    with pytest.raises(ValueError):
+        ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, **{**cfg, "act_fp_type": "fp_e1"})
