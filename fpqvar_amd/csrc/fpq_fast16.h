@@ -608,7 +608,7 @@ __device__ __forceinline__ void fwht128(float (&t)[8], int lane_in_group) {
   for (int j = 0; j < 4; ++j) { t[j] = p[j].x; t[j + 4] = p[j].y; }
 }
 
-template <typename Tin, bool EMIT, int U>
+template <typename Tin, bool EMIT, int U, bool CODES = false>
 __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __restrict__ xv, u32x4* __restrict__ out,
                                                                u32x4* __restrict__ rot_out, int64_t n_vec,
                                                                RotArgs r, Lut16Args a, Lut16Tab tab) {
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __re
       if (EMIT && live[u]) __builtin_nontemporal_store(y, rot_out + v0 + u * kBlock);
       uint32_t m = row_max_dpp<16>(vec_absmax16(y));
       RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      if (r.code_scales) {
+      if constexpr (CODES) {
         const uint32_t c = codes_vec16(y, lut, a.shift, s.sf, s.inv);
         if (live[u]) {
           const int64_t v = v0 + u * kBlock;
@@ -738,7 +738,7 @@ __device__ __forceinline__ float row_sum_f32(float v, float* sh) {
   }
 }
 
-template <typename Tin, typename Tmod, int LANES, int MAXC>
+template <typename Tin, typename Tmod, int LANES, int MAXC, bool CODES = false>
 __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void* __restrict__ xv,
                                                                      u32x4* __restrict__ out, u32x4* __restrict__ h_out,
                                                                      u32x4* __restrict__ y_out, int64_t rows,
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
     if (y_out && live && row_live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
     uint32_t m = row_max_dpp<16>(vec_absmax16(y));
     RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-    if (r.code_scales) {
+    if constexpr (CODES) {
       const uint32_t cd = codes_vec16(y, lut, a.shift, s.sf, s.inv);
       if (live && row_live) {
         ((uint32_t*)out)[row * vpr + v] = cd;

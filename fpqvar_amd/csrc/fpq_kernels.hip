@@ -1101,12 +1101,16 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   constexpr int U = 2;
   const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
-  if (rot_out)
-    hipLaunchKernelGGL((rotate_quant16_kernel<Tin, true, U>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st, x,
-                       (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, tab);
+  const dim3 grid(grid_for(tiles, 1 << 20));
+  if (code_scales)
+    hipLaunchKernelGGL((rotate_quant16_kernel<Tin, false, U, true>), grid, dim3(kBlock), lds, st, x, (u32x4*)out,
+                       (u32x4*)nullptr, n_vec, r, h.args, tab);
+  else if (rot_out)
+    hipLaunchKernelGGL((rotate_quant16_kernel<Tin, true, U>), grid, dim3(kBlock), lds, st, x, (u32x4*)out,
+                       (u32x4*)rot_out, n_vec, r, h.args, tab);
   else
-    hipLaunchKernelGGL((rotate_quant16_kernel<Tin, false, U>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st,
-                       x, (u32x4*)out, (u32x4*)nullptr, n_vec, r, h.args, tab);
+    hipLaunchKernelGGL((rotate_quant16_kernel<Tin, false, U>), grid, dim3(kBlock), lds, st, x, (u32x4*)out,
+                       (u32x4*)nullptr, n_vec, r, h.args, tab);
   return check_launch();
 }
 
@@ -1131,8 +1135,15 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   if (g64 > cap) g64 = cap;
   const dim3 g((unsigned)g64);
   const int maxc = (int)((r.vec_per_row + lanes_per_row - 1) / lanes_per_row);
-#define FPQ_ADALN(L, M) hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, L, M>), g, dim3(kBlock), lds, st, x, \
-                                           (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab)
+#define FPQ_ADALN(L, M)                                                                                              \
+  do {                                                                                                               \
+    if (code_scales)                                                                                                 \
+      hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, L, M, true>), g, dim3(kBlock), lds, st, x,         \
+                         (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab);                       \
+    else                                                                                                             \
+      hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, L, M>), g, dim3(kBlock), lds, st, x, (u32x4*)out,  \
+                         (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab);                                    \
+  } while (0)
   if (lanes_per_row == 256) {
     if (maxc <= 1) FPQ_ADALN(256, 1);
     else FPQ_ADALN(256, 2);
