@@ -237,6 +237,24 @@ __device__ __forceinline__ float quant_sym(float xf, float s, const Fmt& f) {
 template <typename T>
 __device__ __forceinline__ float quant_dual(float xf, float sn, float sp, const Fmt& fn, const Fmt& fp) {
   bool isn = xf <= 0.0f, isp = xf > 0.0f;  // NaN: neither
+  if (fn.argmin) {
+    // fp_quant_e1m2_neg_e2m1_pos_per_group (tr/quant_utils.py:381-412), the pure-torch twin: BOTH halves of
+    // every element go through quantize_to_nearest_grid (the other half's input is 0), argmin takes the first
+    // minimal index (the smaller value on a tie) and index 0 for a NaN / +-Inf input - so a group without
+    // negatives (scale_neg = 0, 0/0) contributes table_neg[0] = -gmax_neg to every element, as in the reference.
+    Fmt gn = fn, gp = fp;
+    gn.limit = gp.limit = __builtin_inff();
+    const float a = DT<T>::round((isn ? xf : 0.0f) / sn);   // <= 0 or NaN
+    const float b = DT<T>::round((isp ? xf : 0.0f) / sp);   // >= 0 or NaN
+    const float ra = fabsf(a);
+    float qa = quant_mag(ra, 0u, gn);                        // tie -> smaller value = larger magnitude
+    qa = (qa != 0.0f) ? -qa : 0.0f;
+    if (!(ra < __builtin_inff())) qa = -fn.gmax;
+    float qb = quant_mag(b, 1u, gp);                         // tie -> smaller value
+    if (!(fabsf(b) < __builtin_inff())) qb = 0.0f;           // table_pos[0]
+    const float q = qa + qb;
+    return q * (isn ? sn : sp);
+  }
   float qn = 0.0f, qp = 0.0f;
   if (isn) {
     float xn = DT<T>::round(xf / sn);
@@ -733,6 +751,30 @@ __global__ __launch_bounds__(kBlock) void nearest_scan_kernel(const T* __restric
       }
     }
     z[i] = (T)zv;
+  }
+}
+
+// quantize_to_nearest_grid (tr/quant_utils.py:209-230): grid[argmin_j |x - grid_j|] with torch.argmin's rules -
+// the FIRST minimal index wins, a NaN or +-Inf input selects grid[0] - for any table; float32 result.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nearest_argmin_kernel(const T* __restrict__ x, const float* __restrict__ table,
+                                                               float* __restrict__ z, int64_t n, int k) {
+  __shared__ float tab[256];
+  if ((int)threadIdx.x < k) tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const float xv = (float)x[i];
+    float best = __builtin_inff(), zv = tab[0];
+    for (int j = 0; j < k; ++j) {
+      const float y = tab[j];
+      const float d = fabsf(xv - y);
+      if (d < best) {   // NaN and Inf distances never win: index 0 stays
+        best = d;
+        zv = y;
+      }
+    }
+    z[i] = zv;
   }
 }
 
@@ -1348,6 +1390,22 @@ int fpq_quant_nearest(const void* x, const float* table, void* z, int64_t n, int
   return check_launch();
 }
 
+int fpq_quant_nearest_argmin(const void* x, const float* table, float* z, int64_t n, int k, int dtype,
+                             fpq_stream_t stream) {
+  if (n < 0) return FPQ_ERR_ARG;
+  if (k < 1 || k > 256) return FPQ_ERR_SHAPE;
+  if (dtype != FPQ_F16 && dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (n == 0) return FPQ_OK;
+  if (!x || !table || !z) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for((n + kBlock - 1) / kBlock, 8192);
+  if (dtype == FPQ_F32)
+    hipLaunchKernelGGL(nearest_argmin_kernel<float>, dim3(g), dim3(kBlock), 0, st, (const float*)x, table, z, n, k);
+  else
+    hipLaunchKernelGGL(nearest_argmin_kernel<_Float16>, dim3(g), dim3(kBlock), 0, st, (const _Float16*)x, table, z, n, k);
+  return check_launch();
+}
+
 int fpq_quant_nearest_builtin(const float* x, float* z, int64_t n, int table_id, fpq_stream_t stream) {
   if (n < 0) return FPQ_ERR_ARG;
   if (table_id < 0 || table_id >= FPQ_NUM_TABLES) return FPQ_ERR_TABLE;
@@ -1457,6 +1515,24 @@ static int rotate_quant_impl(const void* x, void* out, void* rotated_out, void* 
                                          (hipStream_t)stream, (uint16_t*)code_scales);
   return launch_rotate_quant<float>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
                                     (hipStream_t)stream, (uint16_t*)code_scales);
+}
+
+int fpq_quant_rows_dual_argmin(const void* x, float* out, int64_t rows, int64_t cols, int neg_table, int pos_table,
+                               int in_dtype, const void* clip_absmax, float clip_strength, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_INT_NEG && neg_table != FPQ_E2M1_NEG) return FPQ_ERR_TABLE;
+  if (pos_table != FPQ_E2M1_POS && pos_table != FPQ_E2M3_POS) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !out) return FPQ_ERR_ARG;
+  DualArgs dual;
+  dual.fneg = make_fmt(neg_table);
+  dual.fpos = make_fmt(pos_table);
+  dual.fneg.argmin = dual.fpos.argmin = 1;
+  dual.clip_absmax = clip_absmax;
+  dual.clip_strength = clip_strength;
+  dual.nan_flag = nullptr;
+  return dispatch_rows<true>(x, out, rows, cols, in_dtype, FPQ_F32, dual.fneg, dual, (hipStream_t)stream);
 }
 
 int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols, int in_dtype,

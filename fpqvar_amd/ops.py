@@ -146,6 +146,45 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
     return out
 
 
+def quant_nearest_argmin(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """grid[argmin |x - grid|] with torch.argmin's tie / NaN rules, any table of <= 256 entries; float32 result."""
+    require_gpu(x, "quant_nearest_argmin")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_nearest_argmin: x must be float16 or float32, got {x.dtype}")
+    t = table.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+    if t.numel() < 1 or t.numel() > 256:
+        raise RuntimeError("quant_nearest_argmin: the table must hold 1..256 entries")
+    xc = _contig(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_nearest_argmin(xc.data_ptr(), t.data_ptr(), out.data_ptr(), xc.numel(), t.numel(),
+                                             dtype_id(x.dtype), stream_ptr(x.device)), "fpq_quant_nearest_argmin")
+    return out
+
+
+def quant_rows_dual_argmin(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
+                           clipping_strength: float = 1.0) -> torch.Tensor:
+    """The reference's pure-torch dual-format quantizer (argmin lookup, float32 result) in two launches: the
+    global max|x| its clamp needs, then the rows."""
+    require_gpu(x, "quant_rows_dual_argmin")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_rows_dual_argmin: x must be float16 or float32, got {x.dtype}")
+    n = x.numel()
+    if cols <= 0 or n % cols != 0:
+        raise RuntimeError(f"quant_rows_dual_argmin: numel {n} is not a multiple of the row length {cols}")
+    xc = _contig(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
+    amax = absmax(xc)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows_dual_argmin(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[neg_table],
+                                               TABLE_IDS[pos_table], dtype_id(x.dtype), amax.data_ptr(),
+                                               float(clipping_strength), stream_ptr(x.device)),
+              "fpq_quant_rows_dual_argmin")
+    return out
+
+
 def quant_rows_codes(x: torch.Tensor, table: str, cols: int, pack_nibbles: bool = False
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
     """(codes uint8, scales x.dtype[rows]).  codes are [rows, cols] or, packed, [rows, ceil(cols/2)]."""

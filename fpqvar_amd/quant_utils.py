@@ -102,6 +102,19 @@ def fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, n_bits, group_size=128, clippin
     return ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", group_size, clipping_strength)
 
 
+def quantize_to_nearest_grid(x, quant_grid):
+    """tr/quant_utils.py:209-230 in one launch (no [N, K] distance tensor): quant_grid[argmin |x - quant_grid|]."""
+    return ops.quant_nearest_argmin(x, quant_grid)
+
+
+def fp_quant_e1m2_neg_e2m1_pos_per_group(x, n_bits, group_size=128, clipping_strength=1.0):
+    """tr/quant_utils.py:381-412, the pure-torch twin (argmin lookup on both halves, float32 result; bound by
+    models_fp_quant_rotate's QuantizedLinear_fc2).  Its treatment of a group without negatives - every element
+    gets -1.75 added before scaling - is the reference's and is reproduced."""
+    assert n_bits == 4
+    return ops.quant_rows_dual_argmin(x, "e1m2_neg", "e2m1_pos", group_size, clipping_strength)
+
+
 def fp4_afpq_per_group_cuda(x, n_bits, group_size=128, clipping_strength=1.0):
     """models_fp_quant/quant_utils.py:498-535: like the function above but the negative side
     also uses the E2M1 levels (table [-6 .. 0], scale max|x_neg|/6)."""

@@ -66,6 +66,20 @@ def transform_weight(w: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return w / s.to(w.device)
 
 
+_DEFAULT_MASK = None
+
+
+def _mask_arg(d: Optional[torch.Tensor]):
+    """The 128 sign bits as the C ABI takes them; the default D (seed 42) is computed once - building it costs more
+    host time than the kernel runs."""
+    global _DEFAULT_MASK
+    if d is None:
+        if _DEFAULT_MASK is None:
+            _DEFAULT_MASK = tuple(sign_mask(sign_vector(128, 42)))
+        return (ctypes.c_uint32 * 4)(*_DEFAULT_MASK)
+    return (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+
+
 def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor] = None,
                  smooth: Optional[torch.Tensor] = None, return_rotated: bool = False):
     """out = fp_quant_*_per_group_cuda( half(x*smooth) @ half(Q_block) , 128 ) in one launch.
@@ -78,8 +92,7 @@ def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor]
     c = x.shape[-1]
     if c % 128 != 0:
         raise RuntimeError("rotate_quant: the last dimension must be a multiple of 128")
-    d = sign_vector(128, 42) if d is None else d
-    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm_ptr = None
     if smooth is not None:
@@ -118,8 +131,7 @@ def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: O
         raise RuntimeError("rotate_quant_mx: x must be float16/float32 with a last dimension that is a multiple of 128")
     c = x.shape[-1]
     rows = x.numel() // c
-    d = sign_vector(128, 42) if d is None else d
-    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     codes = torch.empty((rows, c // 2), dtype=torch.uint8, device=x.device)
@@ -144,8 +156,7 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
         raise RuntimeError("adaln_rotate_quant_mx: scale and shift must both be float16 or both float32")
     sc = scale.reshape(bsz, c).contiguous()
     sh = shift.reshape(bsz, c).contiguous()
-    d = sign_vector(128, 42) if d is None else d
-    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     codes = torch.empty((bsz * seq, c // 2), dtype=torch.uint8, device=x.device)
@@ -176,8 +187,7 @@ def adaln_rotate_quant(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor
         raise RuntimeError("adaln_rotate_quant: scale and shift must both be float16 or both float32")
     sc = scale.reshape(bsz, c).contiguous()
     sh = shift.reshape(bsz, c).contiguous()
-    d = sign_vector(128, 42) if d is None else d
-    mask = (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
+    mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm_ptr, sm = None, None
     if smooth is not None:

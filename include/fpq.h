@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 100 /* 0.1.0 */
+#define FPQ_VERSION 110 /* 0.1.1 */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -74,6 +74,12 @@ int fpq_table_values(int table_id, float* host_out);
  * caller's business: the Python binding returns a zero tensor for it. */
 int fpq_quant_nearest(const void* x, const float* table, void* z, int64_t n, int k, int dtype,
                       fpq_stream_t stream);
+
+/* quantize_to_nearest_grid (tr/quant_utils.py:209-230; also the GALT / format-search scripts' copy): the lookup of
+ * the reference's pure-torch path for ANY table - z[i] = table[argmin_j |(float)x[i] - table[j]|], FIRST minimal
+ * index (the earlier entry on a tie), table[0] for a NaN or +-Inf input; x F16 or F32, z always float32. */
+int fpq_quant_nearest_argmin(const void* x, const float* table, float* z, int64_t n, int k, int dtype,
+                             fpq_stream_t stream);
 
 /* Same lookup against a BUILT-IN table through the closed form the fused kernels
  * use (midpoint counting on the minifloat structure).  f32 only.  Exposed so
@@ -132,6 +138,16 @@ int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols,
 int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table,
                         int pos_table, int in_dtype, int out_dtype, const void* clip_absmax,
                         float clip_strength, void* nan_flag, fpq_stream_t stream);
+
+/* The pure-torch twin of the FP4 dual format, fp_quant_e1m2_neg_e2m1_pos_per_group (tr/quant_utils.py:381-412;
+ * what models_fp_quant_rotate's QuantizedLinear_fc2 binds, rot/quant_utils.py:779): same split and scales as
+ * fpq_quant_rows_dual, but BOTH halves of every element go through the argmin lookup (the other half's input
+ * is 0), a tie takes the smaller value, a NaN / +-Inf normalised value takes table[0] (so a group without
+ * negatives adds -max|neg table| to every element - the reference's behaviour, reproduced, not fixed), and
+ * the result is float32: out = (q_neg + q_pos) * (x <= 0 ? s_neg : s_pos).  clip_absmax as in
+ * fpq_quant_rows_dual (the reference always clamps; pass fpq_absmax's result). */
+int fpq_quant_rows_dual_argmin(const void* x, float* out, int64_t rows, int64_t cols, int neg_table, int pos_table,
+                               int in_dtype, const void* clip_absmax, float clip_strength, fpq_stream_t stream);
 
 /* "Neg reverse" rows: out = (T)( (q(x_nr / s_nr) * s_nr - m) + q(x_pos / s_pos) * s_pos ) with
  * m = |min(row)|, x_nr = (T)(min(x, 0) + m), both scales (T)(absmax / max|table|); products,

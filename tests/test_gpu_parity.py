@@ -480,6 +480,38 @@ def test_argmin_path_golden(dev, qu, golden, kind, dn):
 
 
 @pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
+def test_quantize_to_nearest_grid(dev, qu, dtype):
+    """The bare argmin lookup for arbitrary (here: every built-in, a permuted and a tiny) table vs torch's own
+    distance-tensor formulation on the CPU."""
+    g = torch.Generator().manual_seed(71)
+    x = torch.cat([all_fp16_as_f32(), torch.randn(5000, generator=g) * 4,
+                   torch.tensor([float("nan"), float("inf"), -float("inf"), 0.0, -0.0])]).to(dtype)
+    tables = [orc.TABLES[n] for n in orc.TABLES] + [orc.TABLES["e2m3"][torch.randperm(64, generator=g)], torch.tensor([0.25])]
+    for tab in tables:
+        want = tab[torch.argmin(torch.abs(x.unsqueeze(-1) - tab), dim=-1)]
+        assert_bits_equal(qu.quantize_to_nearest_grid(x.to(dev), tab.to(dev)), want, f"argmin lookup K={tab.numel()}")
+
+
+@pytest.mark.parametrize("dn", ("f16", "f32"))
+@pytest.mark.parametrize("kind", KINDS)
+def test_dual_argmin_path_golden(dev, qu, golden, kind, dn):
+    """fp_quant_e1m2_neg_e2m1_pos_per_group, the pure-torch twin (tr/quant_utils.py:381-412): golden vectors from the
+    reference's own function, plus the oracle on a larger tensor with groups that lack one sign."""
+    x = from_bits(golden[f"in/{kind}_{dn}"])
+    want = from_bits(golden[f"out/dual_group_argmin/e1m2_neg+e2m1_pos/{kind}_{dn}"])
+    got = qu.fp_quant_e1m2_neg_e2m1_pos_per_group(x.to(dev), 4, 128)
+    assert got.dtype == torch.float32
+    assert_bits_equal(got, want, f"dual argmin {kind} {dn}")
+    if kind in ("gelu", "gauss"):
+        xb = _inputs(kind, (64, 7680), x.dtype, 57)
+        xb[1, :128] = xb[1, :128].abs() + 0.1          # no negatives: the reference adds -1.75 to every element
+        xb[2, :128] = -xb[2, :128].abs() - 0.1
+        xb[3, :128] = 0
+        assert_bits_equal(qu.fp_quant_e1m2_neg_e2m1_pos_per_group(xb.to(dev), 4, 128, 0.9),
+                          orc.dual_per_group_argmin_sem(xb, "e1m2_neg", "e2m1_pos", 128, 0.9), f"dual argmin big {kind}")
+
+
+@pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
 def test_argmin_path_vs_oracle(dev, qu, dtype):
     x = _inputs("heavy", (128, 1920), dtype, 41)
     x[2, :128] = 0
