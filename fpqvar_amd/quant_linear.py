@@ -182,3 +182,100 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
             m.mat_qkv = plain(qkv, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
             m.proj = plain(proj, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
     return model
+
+
+# ---- per-block mixed formats (the older variants' quantize_VAR_* functions, as data) --------------------------
+def _block_index(name: str) -> int:
+    """'blocks.<i>.ffn' -> i, as the reference does (int(name.split('.')[1]))."""
+    return int(name.split(".")[1])
+
+
+def quantize_VAR_mixed(model, layer_formats, weight_quant=None, act_quant=None, w_bit=8, a_bit=8, act_quant_sym=None,
+                       fc2_act_log2_quant=None, activation_fp_quant=False, weight_fp_quant=False,
+                       ada_lin_formats=None):
+    """quantize_VAR with a format pair per (block, layer): ``layer_formats(block_idx, layer)`` returns
+    ``(act_fp_type, weight_fp_type)`` for layer in {"fc1", "fc2", "mat_qkv", "proj"}.  ``ada_lin_formats``:
+    None leaves the AdaLN Linear in full precision (as tr/ does), a pair quantizes ``ada_lin[1]`` (as the fq/ and
+    rot/ mixed variants do).  Module matching is duck-typed as in quantize_VAR."""
+    common = dict(weight_quant=weight_quant, act_quant=act_quant, w_bit=w_bit, a_bit=a_bit,
+                  activation_fp_quant=activation_fp_quant, weight_fp_quant=weight_fp_quant)
+    for name, m in list(model.named_modules()):
+        fc1, fc2 = getattr(m, "fc1", None), getattr(m, "fc2", None)
+        qkv, proj = getattr(m, "mat_qkv", None), getattr(m, "proj", None)
+        ada = getattr(m, "ada_lin", None)
+        if isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear):
+            b = _block_index(name)
+            a, w = layer_formats(b, "fc1")
+            m.fc1 = QuantizedLinear.from_float(fc1, act_quant_sym=act_quant_sym, act_fp_type=a, weight_fp_type=w, **common)
+            a, w = layer_formats(b, "fc2")
+            m.fc2 = QuantizedLinear_fc2.from_float(fc2, act_quant_sym=False, fc2_act_log2_quant=fc2_act_log2_quant,
+                                                   act_fp_type=a, weight_fp_type=w, **common)
+        elif isinstance(qkv, nn.Linear) and isinstance(proj, nn.Linear):
+            b = _block_index(name)
+            a, w = layer_formats(b, "mat_qkv")
+            m.mat_qkv = QuantizedLinear.from_float(qkv, act_quant_sym=act_quant_sym, act_fp_type=a, weight_fp_type=w, **common)
+            a, w = layer_formats(b, "proj")
+            m.proj = QuantizedLinear.from_float(proj, act_quant_sym=act_quant_sym, act_fp_type=a, weight_fp_type=w, **common)
+        if ada_lin_formats is not None and isinstance(ada, nn.Sequential) and len(ada) > 1 and isinstance(ada[1], nn.Linear):
+            a, w = ada_lin_formats
+            ada[1] = QuantizedLinear.from_float(ada[1], act_quant_sym=act_quant_sym, act_fp_type=a, weight_fp_type=w, **common)
+    return model
+
+
+def quantize_VAR_mixed_fp4_datatype(model, weight_quant=None, act_quant=None, quantize_bmm_input=False, w_bit=8,
+                                    a_bit=8, kv_bit=8, act_quant_sym=None, fc2_act_log2_quant=None, quant_kv=None,
+                                    activation_fp_quant=False, weight_fp_quant=False, act_fp_type=None,
+                                    weight_fp_type=None, fc2_fp_type=None):
+    """models_fp_quant/quant_utils.py:1256-1341: fc1 is E2M1 in blocks 6-20 and E3M0 elsewhere, mat_qkv E2M1 in
+    blocks 0, 24, 25 and E3M0 elsewhere (activations; weights always E2M1); proj, fc2 and ada_lin[1] take the
+    caller's formats."""
+    fc1_e2, qkv_e2 = set(range(6, 21)), {0, 24, 25}
+
+    def fmt(b, layer):
+        if layer == "fc1":
+            return ("fp_e2" if b in fc1_e2 else "fp_e3", "fp_e2")
+        if layer == "mat_qkv":
+            return ("fp_e2" if b in qkv_e2 else "fp_e3", "fp_e2")
+        if layer == "fc2":
+            return (fc2_fp_type, weight_fp_type)
+        return (act_fp_type, weight_fp_type)
+
+    return quantize_VAR_mixed(model, fmt, weight_quant, act_quant, w_bit, a_bit, act_quant_sym, fc2_act_log2_quant,
+                              activation_fp_quant, weight_fp_quant, ada_lin_formats=(act_fp_type, weight_fp_type))
+
+
+def quantize_VAR_use_different_datatype(model, weight_quant=None, act_quant=None, quantize_bmm_input=False, w_bit=8,
+                                        a_bit=8, kv_bit=8, act_quant_sym=None, fc2_act_log2_quant=None, quant_kv=None,
+                                        activation_fp_quant=False, weight_fp_quant=False, act_fp_type=None,
+                                        weight_fp_type=None, fc2_fp_type=None):
+    """models_fp_quant_rotate/quant_utils.py:982-1066: as the mixed FP4 variant, with mat_qkv E2M1 in blocks 24, 25 only."""
+    fc1_e2, qkv_e2 = set(range(6, 21)), {24, 25}
+
+    def fmt(b, layer):
+        if layer == "fc1":
+            return ("fp_e2" if b in fc1_e2 else "fp_e3", "fp_e2")
+        if layer == "mat_qkv":
+            return ("fp_e2" if b in qkv_e2 else "fp_e3", "fp_e2")
+        if layer == "fc2":
+            return (fc2_fp_type, weight_fp_type)
+        return (act_fp_type, weight_fp_type)
+
+    return quantize_VAR_mixed(model, fmt, weight_quant, act_quant, w_bit, a_bit, act_quant_sym, fc2_act_log2_quant,
+                              activation_fp_quant, weight_fp_quant, ada_lin_formats=(act_fp_type, weight_fp_type))
+
+
+def quantize_VAR_mixed_fp6_datatype(model, weight_quant=None, act_quant=None, quantize_bmm_input=False, w_bit=8,
+                                    a_bit=8, kv_bit=8, act_quant_sym=None, fc2_act_log2_quant=None, quant_kv=None,
+                                    activation_fp_quant=False, weight_fp_quant=False, act_fp_type=None,
+                                    weight_fp_type=None, fc2_fp_type=None):
+    """models_fp_quant/quant_utils.py:1344-1431: weights always E2M3; activations E3M2 for fc1 and mat_qkv, for fc2
+    E2M3 in blocks 0 and 23 (E3M2 elsewhere), for proj E2M3 in blocks 2-29 (E3M2 in 0, 1); ada_lin[1] E2M3 / E2M3."""
+    def fmt(b, layer):
+        if layer in ("fc1", "mat_qkv"):
+            return ("fp6_e3m2", "fp6_e2m3")
+        if layer == "fc2":
+            return ("fp6_e2m3" if b in (0, 23) else "fp6_e3m2", "fp6_e2m3")
+        return ("fp6_e2m3" if 2 <= b <= 29 else "fp6_e3m2", "fp6_e2m3")
+
+    return quantize_VAR_mixed(model, fmt, weight_quant, act_quant, w_bit, a_bit, act_quant_sym, fc2_act_log2_quant,
+                              activation_fp_quant, weight_fp_quant, ada_lin_formats=("fp6_e2m3", "fp6_e2m3"))
