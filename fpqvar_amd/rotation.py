@@ -66,6 +66,48 @@ def transform_weight(w: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return w / s.to(w.device)
 
 
+# ---- model-level preprocessing, same names as the reference (rotate_utils/rotation_utils.py:129-154,211-243;
+# learnable_transformation/transform_model_utils.py:8-28).  `layer` is one AdaLN block with .attn.mat_qkv / .ffn.fc1.
+def rotate_mat_qkv(layer, Q) -> None:
+    """W_q, W_k, W_v <- W . Q in float64 (row-wise, so rotating the stacked weight at once is the same arithmetic)."""
+    w = layer.attn.mat_qkv.weight.data
+    layer.attn.mat_qkv.weight.data = rotate_weight(w, Q)
+
+
+def rotate_fc1(layer, Q) -> None:
+    w = layer.ffn.fc1.weight.data
+    layer.ffn.fc1.weight.data = rotate_weight(w, Q)
+
+
+def rotate_model(model, device, block_rotate: bool = True) -> None:
+    """The reference's offline weight rotation for every block (mat_qkv and fc1).  Only the block-diagonal mode the
+    run scripts use (--block_rotate, 128-wide blocks, seed 42) is provided: the full-width mode needs the literal
+    Hadamard tables of hadamard_utils.py (had60 / had36 for 1920 / 2304), which are not reproduced here."""
+    if not block_rotate:
+        raise NotImplementedError("full-width Hadamard rotation (non power-of-two sizes) is not provided; use block_rotate")
+    q = block_random_hadamard_matrix(total_size=model.C, block_size=128, device=device, seed=42)
+    for layer in model.blocks:
+        rotate_mat_qkv(layer, q)
+        rotate_fc1(layer, q)
+
+
+def transform_mat_qkv(layer, mat_qkv_best_s) -> None:
+    w = layer.attn.mat_qkv.weight.data
+    layer.attn.mat_qkv.weight.data = transform_weight(w, mat_qkv_best_s).to(w.dtype)
+
+
+def transform_fc1(layer, fc1_best_s) -> None:
+    w = layer.ffn.fc1.weight.data
+    layer.ffn.fc1.weight.data = transform_weight(w, fc1_best_s).to(w.dtype)
+
+
+def transform_model(model, mat_qkv_best_s, fc1_best_s) -> None:
+    """GALT smoothing, weight side: W <- W / s per block with the learned per-channel vectors."""
+    for idx, layer in enumerate(model.blocks):
+        transform_mat_qkv(layer, mat_qkv_best_s[idx])
+        transform_fc1(layer, fc1_best_s[idx])
+
+
 _DEFAULT_MASK = None
 
 

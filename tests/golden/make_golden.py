@@ -267,6 +267,35 @@ def main():
             out["galt/fp6/w2_quant"] = bits(mod.FP6Quant_weight.apply(w2))
             out["galt/fp6/x2_quant_group"] = bits(mod.FP6Quant_activation.apply(x2))
 
+    # ---- 6. model-level preprocessing: transform_model then rotate_model (block mode) on a toy model -------------
+    import learnable_transformation.transform_model_utils as tmu   # noqa: E402
+
+    class _Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn, self.ffn = torch.nn.Module(), torch.nn.Module()
+            self.attn.mat_qkv = torch.nn.Linear(128, 384, bias=False)
+            self.ffn.fc1 = torch.nn.Linear(128, 64)
+
+    class _ToyVAR(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(21)
+            self.C = 128
+            self.blocks = torch.nn.ModuleList([_Blk() for _ in range(2)])
+
+    toy = _ToyVAR()
+    gsm = torch.Generator().manual_seed(22)
+    s_qkv = [torch.rand(128, generator=gsm) + 0.5 for _ in range(2)]
+    s_fc1 = [torch.rand(128, generator=gsm) + 0.5 for _ in range(2)]
+    for i in range(2):
+        out[f"prep/w0/qkv{i}"], out[f"prep/w0/fc1{i}"] = bits(toy.blocks[i].attn.mat_qkv.weight.detach()), bits(toy.blocks[i].ffn.fc1.weight.detach())
+        out[f"prep/s/qkv{i}"], out[f"prep/s/fc1{i}"] = bits(s_qkv[i]), bits(s_fc1[i])
+    tmu.transform_model(toy, s_qkv, s_fc1)
+    ru.rotate_model(toy, "cpu", True)
+    for i in range(2):
+        out[f"prep/w1/qkv{i}"], out[f"prep/w1/fc1{i}"] = bits(toy.blocks[i].attn.mat_qkv.weight.detach()), bits(toy.blocks[i].ffn.fc1.weight.detach())
+
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), len(out), "arrays")
 

@@ -39,3 +39,39 @@ def test_weight_side_helpers():
     torch.testing.assert_close(rot.rotate_weight(wr, q.t()), w, rtol=1e-5, atol=1e-5)
     s = torch.rand(256, generator=g) + 0.5
     assert torch.equal(rot.transform_weight(w, s), w / s)
+
+
+def test_model_level_preprocessing_matches_the_reference(golden):
+    """transform_model then rotate_model (block mode) on a toy model: weights bit-equal to what the reference's
+    learnable_transformation/transform_model_utils.py and rotate_utils/rotation_utils.py produce (tests/golden, section 6)."""
+    import torch
+    from fpqvar_amd import rotation as rot
+    from tests.conftest import assert_bits_equal, from_bits
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn, self.ffn = torch.nn.Module(), torch.nn.Module()
+            self.attn.mat_qkv = torch.nn.Linear(128, 384, bias=False)
+            self.ffn.fc1 = torch.nn.Linear(128, 64)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.C = 128
+            self.blocks = torch.nn.ModuleList([Blk() for _ in range(2)])
+
+    toy = Toy()
+    for i in range(2):
+        toy.blocks[i].attn.mat_qkv.weight.data = from_bits(golden[f"prep/w0/qkv{i}"])
+        toy.blocks[i].ffn.fc1.weight.data = from_bits(golden[f"prep/w0/fc1{i}"])
+    s_qkv = [from_bits(golden[f"prep/s/qkv{i}"]) for i in range(2)]
+    s_fc1 = [from_bits(golden[f"prep/s/fc1{i}"]) for i in range(2)]
+    rot.transform_model(toy, s_qkv, s_fc1)
+    rot.rotate_model(toy, "cpu", True)
+    for i in range(2):
+        assert_bits_equal(toy.blocks[i].attn.mat_qkv.weight.data, from_bits(golden[f"prep/w1/qkv{i}"]), f"mat_qkv {i}")
+        assert_bits_equal(toy.blocks[i].ffn.fc1.weight.data, from_bits(golden[f"prep/w1/fc1{i}"]), f"fc1 {i}")
+    import pytest
+    with pytest.raises(NotImplementedError):
+        rot.rotate_model(toy, "cpu", False)
