@@ -1102,3 +1102,37 @@ def test_quantize_var_mixed_datatype_variants(dev, qu):
     assert_bits_equal(m.blocks[7].ffn.fc1.weight, qu.fp6_quant_e2m3_per_token_cuda(w_fc1_7, 6), "mixed fp6 weight")
     x = torch.randn(5, 128, device=dev).half()
     assert m.blocks[3].ffn.fc1.half()(x).shape == (5, 256)
+
+
+def test_fuzz_shapes_tables_alignments(dev):
+    """Seeded random sweep over everything the dispatcher looks at - row length (sub-wave, one wave, one workgroup,
+    multi-pass, ragged), row count, dtype pair, table, base-pointer misalignment - against the oracle."""
+    from fpqvar_amd import ops
+    rng = np.random.default_rng(2024)
+    col_choices = [1, 2, 3, 7, 8, 16, 24, 31, 64, 100, 128, 136, 256, 384, 512, 520, 1000, 1024, 1920, 2048, 2304, 4104,
+                   7680, 9216, 16384, 16392, 20000]
+    sym, duals = ("e2m1", "e1m2", "e3m0", "e2m3", "e3m2"), (("e1m2_neg", "e2m1_pos"), ("int_neg", "e2m3_pos"), ("e2m1_neg", "e2m1_pos"))
+    for case in range(160):
+        cols = int(rng.choice(col_choices))
+        rows = int(rng.integers(1, 40 if cols < 4096 else 6))
+        dtype = torch.float16 if rng.random() < 0.6 else torch.float32
+        off = int(rng.choice([0, 0, 1, 3, 8]))                                  # elements skipped at the front of the allocation
+        g = torch.Generator().manual_seed(1000 + case)
+        x = torch.randn(rows * cols + off, generator=g) * float(np.exp(rng.normal(0, 1.5)))
+        x = x * torch.exp(0.7 * torch.randn(x.shape, generator=g))
+        if rng.random() < 0.2:
+            x[int(rng.integers(0, x.numel()))] = float(rng.choice([np.inf, -np.inf]))
+        xh = x.to(dtype)
+        xd = xh.to(dev)[off:].view(rows, cols)
+        xc = xh[off:].view(rows, cols)
+        if rng.random() < 0.55:
+            name = str(rng.choice(sym))
+            out_dtype = torch.float16 if (name in SYM6 or rng.random() < 0.3) else dtype
+            got = ops.quant_rows(xd, name, cols, out_dtype)
+            want = orc._rows_kernel_sem(xc, orc.TABLES[name]).to(out_dtype)
+            assert_bits_equal(got, want, f"case {case}: {name} rows={rows} cols={cols} {dtype} -> {out_dtype} off={off}")
+        else:
+            neg, pos = duals[int(rng.integers(0, 3))]
+            got = ops.quant_rows_dual(xd, neg, pos, cols, None)
+            want = orc._dual_rows_kernel_sem(xc, neg, pos).to(dtype)
+            assert_bits_equal(got, want, f"case {case}: {neg}+{pos} rows={rows} cols={cols} {dtype} off={off}")
