@@ -1,0 +1,254 @@
+// fpq_gemm_fp8.h - a REAL low-precision consumer for the per-token / per-channel configurations (W6A6, run.sh:7).
+// Included by fpq_kernels.hip inside its anonymous namespace, after fpq_gemm_fp4.h.
+//
+// With ONE scale per activation row and ONE per weight row the scales leave the K-sum:
+//     y[t,o] = s_a[t] * s_w[o] * sum_k La[t,k] * Lw[o,k]
+// so the whole contraction is matrix-core work with nothing to do per group (the FP4 per-group kernel spends two
+// thirds of its issue slots on the group scales).  Every level of every FP4 / FP6 table of the reference
+// (E2M3: multiples of 1/8 up to 7.5, E3M2: 1/16 .. 28, E2M1, E1M2, E3M0) is exactly an OCP FP8 E4M3 number, so the
+// operands are stored as one E4M3 byte per element and multiplied by v_mfma_f32_16x16x128_f8f6f4 (products exact,
+// fp32 accumulation; K = 1920 sums of E2M3 products stay below 2^24 * 2^-6, i.e. exact).  Probed on hardware
+// (tools/probe/mfma_fp8_probe.hip, mfma_fp6_probe.hip): lane l supplies row l & 15, k-block l >> 4 = 32 consecutive
+// bytes; the FP6-packed form of the same instruction issues at the same ~19 ns per SIMD as the FP8 form on this
+// chip, so the simpler byte layout costs nothing in matrix throughput.
+//
+// LDS image of a 16-row x 128-byte block: physical 16-byte chunk pc of row r holds logical chunk pc ^ a(r),
+// a(r) = ((r >> 1) & 1) + 4 * (r >> 3) (found by exhaustive search): the two ds_read_b128 of every fragment
+// (chunks 2kb, 2kb+1 of row l & 15) are conflict-free in all four lane groups, and the LDS-DMA that fills the block
+// (two 1 KiB pieces of 8 rows, lane j -> row j >> 3, physical chunk j & 7) reads whole 128-byte lines from memory.
+#pragma once
+
+FPQ_NOPK __device__ __forceinline__ int fp8_chunk_swz(int r) { return ((r >> 1) & 1) + ((r >> 3) << 2); }
+
+template <typename Tsa, typename Tsw, int MT, int NT>
+__global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8_rows_kernel(const uint8_t* __restrict__ A,
+                                                                       const Tsa* __restrict__ sa,
+                                                                       const uint8_t* __restrict__ W,
+                                                                       const Tsw* __restrict__ sw,
+                                                                       const _Float16* __restrict__ bias,
+                                                                       _Float16* __restrict__ out, int T, int O, int C) {
+  constexpr int WR = 2, WC = 2, BM = 16 * MT * WR, BN = 16 * NT * WC;
+  constexpr int ABLK = BM / 16, BBLK = BN / 16, NBLK = ABLK + BBLK, STAGE = NBLK * 2048;
+  constexpr int NPIECE = 2 * NBLK;                 // 1 KiB LDS-DMA pieces per stage (8 rows each)
+  static_assert(NPIECE % 4 == 0, "pieces are dealt round-robin to the four wavefronts");
+  constexpr int PIECES = NPIECE / 4;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int steps = C >> 7;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_col = (O + BN - 1) / BN, n_row = (T + BM - 1) / BM;
+  const int cpx = (n_col + 7) >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int col_blk = xcd * cpx + local % cpx, row_blk = local / cpx;
+  if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
+  const int t0 = row_blk * BM, o0 = col_blk * BN;
+
+  const uint8_t* src[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int piece = wave + 4 * i;                 // block piece >> 1, half piece & 1
+    const int r = ((piece & 1) << 3) + (lane >> 3); // row inside the 16-row block
+    const int c = (lane & 7) ^ fp8_chunk_swz(r);    // logical chunk this lane fetches
+    const int blk = piece >> 1;
+    if (blk < ABLK) {
+      const int t = t0 + blk * 16 + r;
+      src[i] = A + (int64_t)(t < T ? t : T - 1) * C + c * 16;
+    } else {
+      const int o = o0 + (blk - ABLK) * 16 + r;
+      src[i] = W + (int64_t)(o < O ? o : O - 1) * C + c * 16;
+    }
+  }
+#define FPQ_GLDS8_ISSUE(s, buf)                                                                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < PIECES; ++i_)                                                             \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i_] + (s) * 128),       \
+                                       (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +            \
+                                                                                 (wave + 4 * i_) * 1024),           \
+                                       16, 0, 0)
+  FPQ_GLDS8_ISSUE(0, 0);
+
+  v4f_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = v4f_t{0, 0, 0, 0};
+
+  // fragment offsets inside a block: row lane & 15, logical chunks 2*(lane >> 4) and +1
+  const int fr = lane & 15, fc = (lane >> 4) << 1;
+  const int off0 = (fr << 7) + (((fc) ^ fp8_chunk_swz(fr)) << 4), off1 = (fr << 7) + (((fc + 1) ^ fp8_chunk_swz(fr)) << 4);
+  const int a_base = wm * MT * 2048, b_base = (ABLK + wn * NT) * 2048;
+
+  for (int s = 0; s < steps; ++s) {
+    FPQ_SYNC();   // stage s has landed; the other buffer's readers are done
+    if (s + 1 < steps) { FPQ_GLDS8_ISSUE(s + 1, (s + 1) & 1); }
+    const uint8_t* st = smem + (s & 1) * STAGE;
+    v8i_t bf[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const u32x4 lo = *(const u32x4*)(st + b_base + n * 2048 + off0), hi = *(const u32x4*)(st + b_base + n * 2048 + off1);
+      bf[n] = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const u32x4 lo = *(const u32x4*)(st + a_base + m * 2048 + off0), hi = *(const u32x4*)(st + a_base + m * 2048 + off1);
+      const v8i_t af = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf[n], acc[m][n], 0, 0, 0, 0, 0, 0);   // fp8 e4m3, unscaled
+    }
+  }
+#undef FPQ_GLDS8_ISSUE
+  FPQ_SYNC();   // every wavefront is done with the staging buffers: the epilogue reuses them
+
+  // epilogue: row scale x column scale, bias, fp16, transpose each wavefront tile through LDS for 16-byte row stores
+  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT, LDW = WCOLS + 8;
+  _Float16* lo = (_Float16*)smem + wave * (WROWS * LDW);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float sr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4) + i;
+      sr[i] = (t < T) ? (float)sa[t] : 0.0f;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n * 16 + (lane & 15);
+      const int o = o0 + wn * WCOLS + col;
+      const float sc = (o < O) ? (float)sw[o] : 0.0f;
+      const float b = (bias && o < O) ? (float)bias[o] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lo[(m * 16 + 4 * (lane >> 4) + i) * LDW + col] = (_Float16)(acc[m][n][i] * (sr[i] * sc) + b);
+    }
+  }
+  FPQ_SYNC();
+  constexpr int EP = WROWS * (WCOLS / 8);
+#pragma unroll
+  for (int pass = 0; pass < (EP + 63) / 64; ++pass) {
+    const int piece = pass * 64 + lane;
+    if (piece < EP) {
+      const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
+      const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
+      if (t < T && o + 8 <= O) {
+        *(u32x4*)(out + (int64_t)t * O + o) = *(const u32x4*)(lo + r * LDW + cpc * 8);
+      } else if (t < T) {
+        for (int e = 0; e < 8; ++e)
+          if (o + e < O) out[(int64_t)t * O + o + e] = lo[r * LDW + cpc * 8 + e];
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+struct GemmFp8Cfg {
+  static constexpr int BM = 32 * MT, BN = 32 * NT;
+  static size_t lds() {
+    size_t main = 2 * (size_t)(BM + BN) * 128;
+    size_t epi = (size_t)4 * (16 * MT) * (16 * NT + 8) * 2;
+    return main > epi ? main : epi;
+  }
+};
+
+// Per-row quantization straight to E4M3 bytes + one scale per row (x's dtype): same scale / normalise / rounding
+// arithmetic as fpq_quant_rows, i.e. level(code) * scale reproduces fp6_quant_*_per_token_cuda exactly.
+// One workgroup per row, two passes over the row (the second one is served by L2).
+template <typename Tin>
+__global__ __launch_bounds__(kBlock) void rows_codes_fp8_kernel(const Tin* __restrict__ x, uint8_t* __restrict__ codes,
+                                                               Tin* __restrict__ scales, int64_t rows, int64_t cols, Fmt f) {
+  __shared__ uint32_t sh[kBlock / 64];
+  const bool vec = (cols & 3) == 0 && (((uintptr_t)x | (uintptr_t)codes) & 15) == 0;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const Tin* xr = x + row * cols;
+    uint32_t m = 0;
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      const uint32_t ab = DT<Tin>::absbits(load_scalar<Tin>(xr + c));
+      m = m > ab ? m : ab;
+    }
+    m = block_max(m, sh);
+    const float s = scale_of<Tin>(m, f.gmax);
+    if (threadIdx.x == 0) store_scalar<Tin>(scales + row, s);
+    auto level = [&](float e) {
+      const float xn = div_round<Tin>(e, s);
+      const uint32_t neg = (xn < 0.0f) ? 1u : 0u;
+      const float qm = quant_mag(fabsf(xn), neg, f);
+      return (neg && qm != 0.0f) ? -qm : qm;
+    };
+    if (vec) {
+      for (int64_t c = (int64_t)threadIdx.x * 4; c < cols; c += (int64_t)kBlock * 4) {
+        const float q0 = level(load_scalar<Tin>(xr + c)), q1 = level(load_scalar<Tin>(xr + c + 1));
+        const float q2 = level(load_scalar<Tin>(xr + c + 2)), q3 = level(load_scalar<Tin>(xr + c + 3));
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(q2, q3, w, true);
+        *(uint32_t*)(codes + row * cols + c) = (uint32_t)w;
+      }
+    } else {
+      for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+        const int w = __builtin_amdgcn_cvt_pk_fp8_f32(level(load_scalar<Tin>(xr + c)), 0.0f, 0, false);
+        codes[row * cols + c] = (uint8_t)(w & 0xFF);
+      }
+    }
+  }
+}
+
+// Fast form for fp16 rows of up to 4096 elements (per-token activations, C = 1920 / 2304): one wavefront owns a row,
+// the row stays in registers between the reduction and the rounding, levels come out of the same bucket table as the
+// fake-quant kernels with E4M3 bytes as entries (fpq_fast16.h).
+__device__ __forceinline__ void codes8_vec16(const u32x4& w, const uint16_t* lut, int shift, float sf, float inv,
+                                             uint32_t& lo4, uint32_t& hi4) {
+  uint32_t c[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t wk = w[k];
+    const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
+    const float y0 = mul_h_lo(wk, inv), y1 = mul_h_hi(wk, inv);
+    const float e0 = __builtin_fmaf(-y0, sf, x0), e1 = __builtin_fmaf(-y1, sf, x1);
+    const float r0 = __builtin_fmaf(e0, inv, y0), r1 = __builtin_fmaf(e1, inv, y1);
+    const uint32_t rb = f2h2(r0, r1);
+    const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+    c[2 * k] = lut[(u & 0xFFFFu) >> shift];
+    c[2 * k + 1] = lut[u >> (16 + shift)];
+  }
+  lo4 = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+  hi4 = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(kBlock) void rows16_codes8_wave_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ codes,
+                                                                   uint16_t* __restrict__ scales, int64_t rows, int64_t cols,
+                                                                   Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  {
+    const int n = 1 << (16 - a.shift);
+    for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t vpr = cols >> 3;
+  constexpr int R = kBlock / 64;
+  for (int64_t base = (int64_t)blockIdx.x * R; base < rows; base += (int64_t)gridDim.x * R) {
+    const int64_t row = base + (threadIdx.x >> 6);
+    if (row >= rows) continue;   // whole wavefront skips
+    const u32x4* xr = (const u32x4*)(x + row * cols);
+    u32x2* crow = (u32x2*)(codes + row * cols);
+    u32x4 raw[MAXC];
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t v = (int64_t)c * 64 + lane;
+      raw[c] = (v < vpr) ? __builtin_nontemporal_load(xr + v) : u32x4{0, 0, 0, 0};
+      const uint32_t t = vec_absmax16(raw[c]);
+      m = m > t ? m : t;
+    }
+    m = row_max_dpp<64>(m);
+    const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+    if (lane == 0) scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t v = (int64_t)c * 64 + lane;
+      if (v < vpr) {
+        uint32_t c_lo, c_hi;
+        codes8_vec16(raw[c], lut, a.shift, s.sf, s.inv, c_lo, c_hi);
+        __builtin_nontemporal_store(u32x2{c_lo, c_hi}, crow + v);
+      }
+    }
+  }
+}

@@ -657,6 +657,7 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 
 #include "fpq_fast16.h"
 #include "fpq_gemm_fp4.h"
+#include "fpq_gemm_fp8.h"
 
 // ---------------------------------------------------------------------------------
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
@@ -1680,6 +1681,103 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
   else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
   else FPQ_GEMM_LAUNCH(4, 4, 2, 2);
 #undef FPQ_GEMM_LAUNCH
+  return check_launch();
+}
+
+// host: OCP E4M3 byte of a value that is exactly representable (every level of the symmetric tables is)
+static uint8_t e4m3_of(float v) {
+  if (v == 0.0f) return 0;
+  const uint8_t sgn = v < 0.0f ? 0x80 : 0;
+  int e;
+  const float m = frexpf(fabsf(v), &e);        // |v| = m * 2^e, m in [0.5, 1)
+  const int ex = e - 1;                         // |v| = (2m) * 2^(e-1), 2m in [1, 2)
+  const int man = (int)((2.0f * m - 1.0f) * 8.0f);
+  return (uint8_t)(sgn | ((ex + 7) << 3) | man);
+}
+
+// bucket -> E4M3 code tables for the fast fp16 path, one per symmetric table, built once (immutable afterwards)
+static const Lut16Tab& lut16_codes8(int table_id) {
+  static const Lut16Tab* tabs = [] {
+    auto* t = new Lut16Tab[FPQ_NUM_TABLES]();
+    for (int id = 0; id < FPQ_NUM_TABLES; ++id) {
+      if (!kTables[id].symmetric) continue;
+      const Lut16Host& h = lut16_host(id, id);
+      if (!h.tab_valid) continue;
+      const int n = 1 << (16 - h.args.shift);
+      for (int i = 0; i < n; ++i) t[id].e[i] = e4m3_of(h2f(h.tab.e[i]));
+    }
+    return t;
+  }();
+  return tabs[table_id];
+}
+
+int fpq_quant_rows_codes_fp8(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
+                             int in_dtype, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !codes || !scales) return FPQ_ERR_ARG;
+  if (in_dtype == FPQ_F16 && cols % 8 == 0 && cols <= 4096 && (((uintptr_t)x | (uintptr_t)codes) & 15) == 0 &&
+      lut16_host(table_id, table_id).tab_valid) {
+    const Lut16Host& h = lut16_host(table_id, table_id);
+    const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+    const int64_t wgs = (rows + kBlock / 64 - 1) / (kBlock / 64);
+    const dim3 gw(grid_for(wgs, 8192));
+    const int maxc = (int)((cols / 8 + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+#define FPQ_C8(M) hipLaunchKernelGGL((rows16_codes8_wave_kernel<M>), gw, dim3(kBlock), lds, st, (const uint16_t*)x, codes, \
+                                     (uint16_t*)scales, rows, cols, h.args, lut16_codes8(table_id))
+    if (maxc <= 2) FPQ_C8(2);
+    else if (maxc <= 4) FPQ_C8(4);
+    else FPQ_C8(8);
+#undef FPQ_C8
+    return check_launch();
+  }
+  const dim3 g(grid_for(rows, 65535));
+  if (in_dtype == FPQ_F16)
+    hipLaunchKernelGGL(rows_codes_fp8_kernel<_Float16>, g, dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)x,
+                       codes, (_Float16*)scales, rows, cols, make_fmt(table_id));
+  else
+    hipLaunchKernelGGL(rows_codes_fp8_kernel<float>, g, dim3(kBlock), 0, (hipStream_t)stream, (const float*)x, codes,
+                       (float*)scales, rows, cols, make_fmt(table_id));
+  return check_launch();
+}
+
+int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream) {
+  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (tokens == 0 || outs == 0) return FPQ_OK;
+  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const char* env8 = getenv("FPQ_GEMM8_CFG");
+  const int cfg8 = env8 ? atoi(env8) : 0;
+#define FPQ_GO8(TA, TW, MT, NT)                                                                                     \
+  do {                                                                                                               \
+    using Cfg = GemmFp8Cfg<MT, NT>;                                                                                  \
+    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
+    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
+    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
+    hipLaunchKernelGGL((gemm_fp8_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
+                       a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
+                       (_Float16*)out, (int)tokens, (int)outs, (int)k);                                              \
+  } while (0)
+#define FPQ_GO8T(MT, NT)                                                                                             \
+  do {                                                                                                               \
+    if (a_scale_dtype == FPQ_F16 && w_scale_dtype == FPQ_F16) FPQ_GO8(_Float16, _Float16, MT, NT);                   \
+    else if (a_scale_dtype == FPQ_F16) FPQ_GO8(_Float16, float, MT, NT);                                             \
+    else if (w_scale_dtype == FPQ_F16) FPQ_GO8(float, _Float16, MT, NT);                                             \
+    else FPQ_GO8(float, float, MT, NT);                                                                              \
+  } while (0)
+  if (cfg8 == 1) FPQ_GO8T(8, 4);
+  else FPQ_GO8T(4, 4);
+#undef FPQ_GO8T
+#undef FPQ_GO8
   return check_launch();
 }
 

@@ -91,3 +91,74 @@ class FP4Linear(torch.nn.Module):
         """The same product for an activation that already is in operand form - what the fused producers
         `rotation.rotate_quant_mx` / `rotation.adaln_rotate_quant_mx` emit: fp16 [tokens, out_features]."""
         return linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)
+
+
+# ---- per-token activations x per-channel weights (W6A6): one scale per row, FP8-coded levels ---------------------
+_FP8_TABLES = {"fp6_e2m3": "e2m3", "fp6_e3m2": "e3m2", "fp_e2": "e2m1", "fp_e1": "e1m2", "fp_e3": "e3m0",
+               "e2m3": "e2m3", "e3m2": "e3m2", "e2m1": "e2m1", "e1m2": "e1m2", "e3m0": "e3m0"}
+
+
+def quantize_fp8(x: torch.Tensor, table: str = "e2m3") -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [..., K] fp16/fp32 -> (codes uint8 [rows, K]: the level of every element as an OCP E4M3 byte,
+    scales [rows] in x.dtype); one scale per row of K elements, e4m3(code) * scale == the fake-quantized value."""
+    require_gpu(x, "quantize_fp8")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quantize_fp8: x must be float16 or float32, got {x.dtype}")
+    from ._lib import TABLE_IDS
+    k = x.shape[-1]
+    xc = x.contiguous()
+    rows = xc.numel() // k
+    codes = torch.empty((rows, k), dtype=torch.uint8, device=x.device)
+    scales = torch.empty((rows,), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows_codes_fp8(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
+                                             TABLE_IDS[_FP8_TABLES[table]], dtype_id(x.dtype), stream_ptr(x.device)),
+              "fpq_quant_rows_codes_fp8")
+    return codes, scales
+
+
+def dequantize_fp8(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """Reference decoder in torch ops (tests / debugging): fp32 [rows, K]."""
+    return codes.view(torch.float8_e4m3fn).float() * scales.float().unsqueeze(-1)
+
+
+def linear_fp8(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
+               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP8 matrix cores (row-scaled operands)."""
+    require_gpu(a_codes, "linear_fp8")
+    tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1]
+    if w_codes.shape[1] != k:
+        raise RuntimeError("linear_fp8: operand shapes mismatch")
+    out = torch.empty((tokens, outs), dtype=torch.float16, device=a_codes.device)
+    b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
+    with torch.cuda.device(a_codes.device):
+        check(lib().fpq_gemm_fp8_rows(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
+                                      w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
+                                      out.data_ptr(), tokens, outs, k, stream_ptr(a_codes.device)), "fpq_gemm_fp8_rows")
+    return out
+
+
+class FP8Linear(torch.nn.Module):
+    """Drop-in for QuantizedLinear in the per_channel / per_token configurations (W6A6 `fp6_e2m3` / `fp6_e3m2`,
+    run.sh:7) on the FP8 matrix cores: same quantization decisions as the reference (e4m3(code) * scale == its
+    fake-quantized tensors), weights stored as one byte per element + one fp32 scale per output channel."""
+
+    def __init__(self, w_codes, w_scales, bias, in_features, out_features, act_table):
+        super().__init__()
+        self.in_features, self.out_features, self.act_table = in_features, out_features, act_table
+        self.register_buffer("w_codes", w_codes)
+        self.register_buffer("w_scales", w_scales)
+        self.register_buffer("bias", bias)
+
+    @classmethod
+    def from_float(cls, module: torch.nn.Linear, weight_fp_type: str = "fp6_e2m3", act_fp_type: str = "fp6_e2m3"):
+        assert isinstance(module, torch.nn.Linear) and module.in_features % 128 == 0 and module.out_features % 8 == 0
+        codes, scales = quantize_fp8(module.weight.detach().float(), weight_fp_type)
+        bias = None if module.bias is None else module.bias.detach().to(torch.float16)
+        return cls(codes, scales, bias, module.in_features, module.out_features, act_fp_type)
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        a_codes, a_scales = quantize_fp8(x.to(torch.float16).reshape(-1, self.in_features), self.act_table)
+        return linear_fp8(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)

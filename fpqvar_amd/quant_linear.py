@@ -148,7 +148,8 @@ class QuantizedLinear_fc2(QuantizedLinear):
 
 def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=False, w_bit=8, a_bit=8, kv_bit=8,
                  act_quant_sym=None, fc2_act_log2_quant=None, quant_kv=None, activation_fp_quant=False,
-                 weight_fp_quant=False, act_fp_type=None, weight_fp_type=None, fc2_fp_type=None, real_fp4=False):
+                 weight_fp_quant=False, act_fp_type=None, weight_fp_type=None, fc2_fp_type=None, real_fp4=False,
+                 real_fp6=False):
     """tr/quant_utils.py:1095-1167.  The reference matches its own FFN / SelfAttention
     classes; here a module with Linear children ``fc1``+``fc2`` is an FFN and one with
     ``mat_qkv``+``proj`` is a self-attention block.  As in the reference,
@@ -162,6 +163,13 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
               and activation_fp_quant and weight_fp_quant and act_fp_type == "fp_e2" and weight_fp_type == "fp_e2")
     if real_fp4 and not fp4_ok:
         raise ValueError("real_fp4 needs weight_quant = act_quant = 'per_group', w_bit = a_bit = 4, fp_e2 on both sides")
+    # ``real_fp6`` (additive, default off): in the W6A6 per_channel / per_token configuration (run.sh:7) fc1 / mat_qkv /
+    # proj become ``gemm.FP8Linear`` - levels stored as E4M3 bytes, one scale per row, product on the FP8 matrix cores.
+    fp6_ok = (real_fp6 and weight_quant == "per_channel" and act_quant == "per_token" and w_bit == 6 and a_bit == 6
+              and activation_fp_quant and weight_fp_quant and act_fp_type in ("fp6_e2m3", "fp6_e3m2")
+              and weight_fp_type in ("fp6_e2m3", "fp6_e3m2"))
+    if real_fp6 and not fp6_ok:
+        raise ValueError("real_fp6 needs weight_quant='per_channel', act_quant='per_token', w_bit = a_bit = 6, fp6 formats")
     common = dict(weight_quant=weight_quant, act_quant=act_quant, w_bit=w_bit, a_bit=a_bit,
                   activation_fp_quant=activation_fp_quant, weight_fp_quant=weight_fp_quant,
                   weight_fp_type=weight_fp_type)
@@ -169,6 +177,9 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
         if fp4_ok and lin.in_features % 128 == 0 and lin.out_features % 8 == 0:
             from .gemm import FP4Linear
             return FP4Linear.from_float(lin)
+        if fp6_ok and lin.in_features % 128 == 0 and lin.out_features % 8 == 0:
+            from .gemm import FP8Linear
+            return FP8Linear.from_float(lin, weight_fp_type, act_fp_type)
         return QuantizedLinear.from_float(lin, **kw)
 
     for _, m in list(model.named_modules()):

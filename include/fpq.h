@@ -239,6 +239,24 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
                     int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
                     fpq_stream_t stream);
 
+/* ---- F2 for the per-token / per-channel configurations (W6A6, run.sh:7) ----------------------------------------
+ * Per-row quantization straight to one OCP FP8 E4M3 byte per element (every level of the symmetric FP4 / FP6 tables
+ * is exactly an E4M3 number) + one scale per row in x's dtype: same arithmetic as fpq_quant_rows with cols = row
+ * length, i.e. e4m3(code) * scale reproduces fp6_quant_{e2m3,e3m2}_per_token_cuda (tr/quant_utils.py:503-534) and the
+ * per-channel weight quantization of QuantizedLinear.from_float (:808-829).  codes: [rows, cols]; scales: [rows]. */
+int fpq_quant_rows_codes_fp8(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
+                             int in_dtype, fpq_stream_t stream);
+
+/* out[t, o] = bias[o] + a_scale[t] * w_scale[o] * sum_k e4m3(a[t,k]) * e4m3(w[o,k]) on the FP8 matrix cores (exact
+ * products, fp32 accumulation, nothing but matrix instructions in the K loop: with one scale per row the scales
+ * leave the sum); replaces F.linear(act_quant(x), W_q, b) of tr/quant_utils.py:765-767 for per_token activations x
+ * per_channel weights.  a_codes [tokens, k], w_codes [outs, k], bias fp16 [outs] or NULL, out fp16 [tokens, outs];
+ * k % 128 == 0, outs % 8 == 0, code arrays and out 16-byte aligned.  Tolerance-level agreement with the reference's
+ * fp16 GEMM on the de-quantized tensors (as fpq_gemm_fp4_mx). */
+int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream);
+
 /* Inverse of fpq_quant_rows_codes: out = (Tout)((float)table_dedup[code] * (float)scale). */
 int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, int64_t rows,
                            int64_t cols, int table_id, int scale_dtype, int out_dtype,

@@ -1054,6 +1054,18 @@ def test_quantize_var_real_fp4(dev):
         assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
     with pytest.raises(ValueError):
         ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, **{**cfg, "act_fp_type": "fp_e1"})
+    # W6A6 per_channel / per_token -> FP8Linear
+    cfg6 = dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True, activation_fp_quant=True,
+                weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3", fc2_fp_type="fp6_int_neg_e2m3_pos")
+    fake6 = ql.quantize_VAR(copy.deepcopy(base), **cfg6).half()
+    real6 = ql.quantize_VAR(copy.deepcopy(base), real_fp6=True, **cfg6)
+    assert isinstance(real6.ffn.fc1, gemm.FP8Linear) and isinstance(real6.attn.proj, gemm.FP8Linear)
+    assert type(real6.ffn.fc2).__name__ == "QuantizedLinear_fc2"
+    for a, b in ((fake6.ffn.fc1, real6.ffn.fc1), (fake6.attn.mat_qkv, real6.attn.mat_qkv), (fake6.attn.proj, real6.attn.proj)):
+        ya, yb = a(x).float(), b(x).float()
+        assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
+    with pytest.raises(ValueError):
+        ql.quantize_VAR(copy.deepcopy(base), real_fp6=True, **cfg)
 
 
 def test_quantize_var_mixed_datatype_variants(dev, qu):
@@ -1136,3 +1148,63 @@ def test_fuzz_shapes_tables_alignments(dev):
             got = ops.quant_rows_dual(xd, neg, pos, cols, None)
             want = orc._dual_rows_kernel_sem(xc, neg, pos).to(dtype)
             assert_bits_equal(got, want, f"case {case}: {neg}+{pos} rows={rows} cols={cols} {dtype} off={off}")
+
+
+# ------------------------------------------------------------------ F2 for W6A6: FP8-coded row-scaled GEMM
+@pytest.mark.parametrize("table", ("e2m3", "e3m2", "e2m1"))
+@pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
+def test_fp8_codes_reproduce_fake_quant(dev, qu, table, dtype):
+    from fpqvar_amd import gemm, ops
+    x = _inputs("heavy", (70, 1920), dtype, 61)
+    x[3] = 0
+    x[5, 7] = float("inf")
+    xd = x.to(dev)
+    codes, scales = gemm.quantize_fp8(xd, table)
+    assert codes.shape == (70, 1920) and scales.shape == (70,) and scales.dtype == dtype
+    want = ops.quant_rows(xd, table, 1920, torch.float32)                    # fp32 product q * s of the fake quantizer
+    got = gemm.dequantize_fp8(codes, scales)
+    ok = ~torch.isnan(want)
+    assert_bits_equal(got[ok], want[ok], f"fp8 codes {table}")
+    assert bool(torch.isnan(got[~ok]).all())
+    for cols in (1000, 3):                                                   # ragged rows take the byte-store path
+        xr = _inputs("gauss", (9, cols), dtype, 62).to(dev)
+        c, s = gemm.quantize_fp8(xr, table)
+        assert_bits_equal(gemm.dequantize_fp8(c, s), ops.quant_rows(xr, table, cols, torch.float32), f"ragged {cols}")
+
+
+@pytest.mark.parametrize("T,O,K", ((256, 256, 1920), (1000, 5760, 1920), (130, 1928, 256), (64, 128, 7680), (20, 6912, 2304), (1, 8, 128)))
+def test_fp8_gemm(dev, T, O, K):
+    from fpqvar_amd import gemm
+    g = torch.Generator().manual_seed(202 + T)
+    x = (torch.randn(T, K, generator=g) * torch.exp(0.3 * torch.randn(T, K, generator=g))).half().to(dev)
+    w = (torch.randn(O, K, generator=g) * 0.02).to(dev)
+    bias = (torch.randn(O, generator=g) * 0.1).half().to(dev)
+    ac, asc = gemm.quantize_fp8(x, "e2m3")
+    wc, wsc = gemm.quantize_fp8(w, "e2m3")
+    y = gemm.linear_fp8(ac, asc, wc, wsc, bias)
+    assert y.shape == (T, O) and y.dtype == torch.float16
+    a64, w64 = gemm.dequantize_fp8(ac, asc).double(), gemm.dequantize_fp8(wc, wsc).double()
+    ref = a64 @ w64.t() + bias.double()
+    err = (y.double() - ref).abs()
+    tol = 2.0 ** -10 * ref.abs() + 1e-5 * (a64.abs() @ w64.abs().t()) + 1e-6     # fp16 output rounding + fp32 accumulation
+    assert bool((err <= tol).all()), float((err / tol).max())
+    # against the reference's formulation: fake-quantized fp16 tensors through an fp16 GEMM
+    import fpqvar_amd.quant_utils as qu
+    ref16 = torch.nn.functional.linear(qu.fp6_quant_e2m3_per_token_cuda(x, 6), qu.fp6_quant_e2m3_per_token_cuda(w, 6), bias)
+    assert float((y.float() - ref16.float()).abs().max()) <= 2e-2 * float(ref16.float().abs().max()) + 1e-3
+
+
+def test_fp8_linear_module(dev):
+    from fpqvar_amd import gemm, quant_linear as ql
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(1920, 640).to(dev)
+    x = torch.randn(3, 50, 1920, device=dev).half()
+    fp8 = gemm.FP8Linear.from_float(lin)
+    cfg = dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True, activation_fp_quant=True,
+               weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3")
+    fake = ql.QuantizedLinear.from_float(lin, **cfg).half()
+    ya, yb = fake(x).float(), fp8(x).float()
+    assert yb.shape == (3, 50, 640)
+    assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
+    # the stored weight decodes to the reference's quantized weight
+    assert_bits_equal(gemm.dequantize_fp8(fp8.w_codes, fp8.w_scales).half(), fake.weight, "FP8Linear weight")
