@@ -40,6 +40,10 @@ _SIGS = {
                                              _c.c_int, _c.c_void_p]),
     "fpq_gemm_fp8_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                       _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    "fpq_quant_rows_codes_fp6": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                             _c.c_int, _c.c_void_p]),
+    "fpq_gemm_fp6_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                      _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p]),
     "fpq_quant_nearest_argmin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
                                              _c.c_void_p]),
     "fpq_quant_rows_dual_argmin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,

@@ -1,0 +1,262 @@
+// fpq_gemm_fp6.h - the row-scaled GEMM of fpq_gemm_fp8.h with the operands in the 6-bit packed form of the same
+// matrix instruction (cbsz = blgp = 2, FP6 E2M3): 96 bytes per row and 128-element K step instead of 128, i.e. 25 %
+// less LDS-DMA and fragment traffic in a kernel that is bound by exactly that.  Included after fpq_gemm_fp8.h.
+//
+// Operand layout, probed on hardware (tools/probe/mfma_fp6_probe.hip): lane l supplies row l & 15, k-block l >> 4 =
+// 32 consecutive elements as a 192-bit little-endian string, element j in bits [6j, 6j+6): sign, 2 exponent bits
+// (bias 1), 3 mantissa bits - which is just the dense 6-bit packing of the row, 24 bytes per k-block.
+//
+// LDS image: 32-row "super-blocks" of 96-byte rows (3072 B = three 1 KiB LDS-DMA pieces; piece p, lane j -> 16-byte
+// chunk p*64 + j of the super-block = row ci / 6, physical chunk ci % 6).  Physical chunk pc of row r holds logical
+// chunk (pc - rot(r)) mod 6, rot(r) = (r >> 3) & 1 (found by exhaustive search): the three ds_read_b64 of a fragment
+// (bytes 24*kb + 8t of row l & 15) are conflict-free in both 32-lane groups.
+#pragma once
+
+FPQ_NOPK __device__ __forceinline__ int fp6_rot(int r) { return (r >> 3) & 1; }
+
+template <typename Tsa, typename Tsw, int MT, int NT>
+__global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const uint8_t* __restrict__ A,
+                                                                       const Tsa* __restrict__ sa,
+                                                                       const uint8_t* __restrict__ W,
+                                                                       const Tsw* __restrict__ sw,
+                                                                       const _Float16* __restrict__ bias,
+                                                                       _Float16* __restrict__ out, int T, int O, int C) {
+  constexpr int WR = 2, WC = 2, BM = 16 * MT * WR, BN = 16 * NT * WC;
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tiles are made of 32-row super-blocks");
+  constexpr int ASB = BM / 32, BSB = BN / 32, NSB = ASB + BSB, STAGE = NSB * 3072;
+  constexpr int NPIECE = 3 * NSB;
+  static_assert(NPIECE % 4 == 0 && NPIECE / 4 < 16, "pieces are dealt round-robin to the four wavefronts");
+  constexpr int PIECES = NPIECE / 4;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int steps = C >> 7, row_bytes = (C >> 2) * 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_col = (O + BN - 1) / BN, n_row = (T + BM - 1) / BM;
+  const int cpx = (n_col + 7) >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int col_blk = xcd * cpx + local % cpx, row_blk = local / cpx;
+  if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
+  const int t0 = row_blk * BM, o0 = col_blk * BN;
+
+  const uint8_t* src[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int piece = wave + 4 * i;                 // super-block piece / 3, part piece % 3
+    const int sb = piece / 3, ci = (piece % 3) * 64 + lane;
+    const int r = ci / 6, pc = ci - 6 * r;          // row inside the super-block, physical chunk
+    int c = pc - fp6_rot(r);
+    c = c < 0 ? c + 6 : c;                          // logical chunk this lane fetches
+    if (sb < ASB) {
+      const int t = t0 + sb * 32 + r;
+      src[i] = A + (int64_t)(t < T ? t : T - 1) * row_bytes + c * 16;
+    } else {
+      const int o = o0 + (sb - ASB) * 32 + r;
+      src[i] = W + (int64_t)(o < O ? o : O - 1) * row_bytes + c * 16;
+    }
+  }
+#define FPQ_GLDS6_ISSUE(s, buf)                                                                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < PIECES; ++i_)                                                             \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i_] + (s) * 96),        \
+                                       (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +            \
+                                                                                 (wave + 4 * i_) * 1024),           \
+                                       16, 0, 0)
+  FPQ_GLDS6_ISSUE(0, 0);
+
+  v4f_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = v4f_t{0, 0, 0, 0};
+
+  // the three 8-byte pieces of this lane's fragment inside a 16-row half of a super-block
+  const int fr = lane & 15, kb = lane >> 4;
+  int foff[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int b = kb * 24 + 8 * t;
+    int pc = (b >> 4) + fp6_rot(fr);
+    pc = pc >= 6 ? pc - 6 : pc;
+    foff[t] = fr * 96 + pc * 16 + (b & 15);
+  }
+  const int a_base = wm * MT * 1536, b_base = ASB * 3072 + wn * NT * 1536;   // tile row mt -> 1536 * mt (two per super-block)
+
+  // Two LDS stages, one barrier per step.  Measured on mat_qkv [65536 x 1920 -> 5760]: 0.81 ms; the same loop
+  // without its MFMAs 0.70 ms, without its LDS-DMA 0.60 ms, 256 x 128 tiles 0.81 ms, a three-stage ring with counted
+  // vmcnt 0.92 ms - i.e. the operand feed (DMA + barrier per 128-element step), not the matrix pipe, sets the pace.
+  for (int s = 0; s < steps; ++s) {
+    FPQ_SYNC();   // stage s has landed; the other buffer's readers are done
+    if (s + 1 < steps) { FPQ_GLDS6_ISSUE(s + 1, (s + 1) & 1); }
+    const uint8_t* st = smem + (s & 1) * STAGE;
+    v8i_t bf[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const uint8_t* p = st + b_base + n * 1536;
+      const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
+      bf[n] = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const uint8_t* p = st + a_base + m * 1536;
+      const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
+      const v8i_t af = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf[n], acc[m][n], 2, 2, 0, 0, 0, 0);   // fp6 e2m3, unscaled
+    }
+  }
+#undef FPQ_GLDS6_ISSUE
+  FPQ_SYNC();   // every wavefront is done with the staging buffers: the epilogue reuses them
+
+  // epilogue: row scale x column scale, bias, fp16, transpose each wavefront tile through LDS for 16-byte row stores
+  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT, LDW = WCOLS + 8;
+  _Float16* lo = (_Float16*)smem + wave * (WROWS * LDW);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float sr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4) + i;
+      sr[i] = (t < T) ? (float)sa[t] : 0.0f;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n * 16 + (lane & 15);
+      const int o = o0 + wn * WCOLS + col;
+      const float sc = (o < O) ? (float)sw[o] : 0.0f;
+      const float b = (bias && o < O) ? (float)bias[o] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lo[(m * 16 + 4 * (lane >> 4) + i) * LDW + col] = (_Float16)(acc[m][n][i] * (sr[i] * sc) + b);
+    }
+  }
+  FPQ_SYNC();
+  constexpr int EP = WROWS * (WCOLS / 8);
+#pragma unroll
+  for (int pass = 0; pass < (EP + 63) / 64; ++pass) {
+    const int piece = pass * 64 + lane;
+    if (piece < EP) {
+      const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
+      const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
+      if (t < T && o + 8 <= O) {
+        *(u32x4*)(out + (int64_t)t * O + o) = *(const u32x4*)(lo + r * LDW + cpc * 8);
+      } else if (t < T) {
+        for (int e = 0; e < 8; ++e)
+          if (o + e < O) out[(int64_t)t * O + o + e] = lo[r * LDW + cpc * 8 + e];
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+struct GemmFp6Cfg {
+  static constexpr int BM = 32 * MT, BN = 32 * NT;
+  static size_t lds() {
+    size_t main = 2 * (size_t)(BM + BN) * 96;
+    size_t epi = (size_t)4 * (16 * MT) * (16 * NT + 8) * 2;
+    return main > epi ? main : epi;
+  }
+};
+
+// Fast form for fp16 rows (per-token activations): one wavefront per row, every lane owns whole 32-element
+// k-blocks (64 bytes in, 24 bytes out), bucket table with 6-bit codes as entries.
+template <int MAXC>
+__global__ __launch_bounds__(kBlock) void rows16_codes6_wave_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ codes,
+                                                                   uint16_t* __restrict__ scales, int64_t rows, int64_t cols,
+                                                                   Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  {
+    const int n = 1 << (16 - a.shift);
+    for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t nblk = cols >> 5;                 // 32-element k-blocks per row
+  constexpr int R = kBlock / 64;
+  for (int64_t base = (int64_t)blockIdx.x * R; base < rows; base += (int64_t)gridDim.x * R) {
+    const int64_t row = base + (threadIdx.x >> 6);
+    if (row >= rows) continue;   // whole wavefront skips
+    const u32x4* xr = (const u32x4*)(x + row * cols);
+    u32x4 raw[MAXC][4];
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t b = (int64_t)c * 64 + lane;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        raw[c][v] = (b < nblk) ? xr[4 * b + v] : u32x4{0, 0, 0, 0};
+        const uint32_t t = vec_absmax16(raw[c][v]);
+        m = m > t ? m : t;
+      }
+    }
+    m = row_max_dpp<64>(m);
+    const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+    if (lane == 0) scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t b = (int64_t)c * 64 + lane;
+      if (b < nblk) {
+        uint32_t o[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          uint32_t lo4, hi4;                       // eight 6-bit codes, one per byte
+          codes8_vec16(raw[c][v], lut, a.shift, s.sf, s.inv, lo4, hi4);
+          // 8 codes = 48 bits at bit offset 48 * v
+          const uint64_t p48 = (uint64_t)((lo4 & 0x3Fu) | ((lo4 >> 2) & 0xFC0u) | ((lo4 >> 4) & 0x3F000u) | ((lo4 >> 6) & 0xFC0000u)) |
+                               ((uint64_t)((hi4 & 0x3Fu) | ((hi4 >> 2) & 0xFC0u) | ((hi4 >> 4) & 0x3F000u) | ((hi4 >> 6) & 0xFC0000u)) << 24);
+          const int bit = 48 * v;
+          o[bit >> 5] |= (uint32_t)(p48 << (bit & 31));
+          o[(bit >> 5) + 1] |= (uint32_t)(p48 >> (32 - (bit & 31)));
+          if ((bit & 31) + 48 > 64) o[(bit >> 5) + 2] |= (uint32_t)(p48 >> (64 - (bit & 31)));
+        }
+        u32x2* dst = (u32x2*)(codes + row * (nblk * 24) + b * 24);
+        __builtin_nontemporal_store(u32x2{o[0], o[1]}, dst);
+        __builtin_nontemporal_store(u32x2{o[2], o[3]}, dst + 1);
+        __builtin_nontemporal_store(u32x2{o[4], o[5]}, dst + 2);
+      }
+    }
+  }
+}
+
+// level (exactly an E2M3 number, sign included) -> 6-bit code
+__host__ __device__ __forceinline__ uint32_t e2m3_of_level(float q) {
+  const uint32_t sgn = (q < 0.0f) ? 32u : 0u;
+  const float a = q < 0.0f ? -q : q;
+  uint32_t mag;
+  if (a < 1.0f) mag = (uint32_t)(a * 8.0f);                                        // subnormal: m / 8
+  else if (a < 2.0f) mag = (1u << 3) | (uint32_t)((a - 1.0f) * 8.0f);
+  else if (a < 4.0f) mag = (2u << 3) | (uint32_t)((a * 0.5f - 1.0f) * 8.0f);
+  else mag = (3u << 3) | (uint32_t)((a * 0.25f - 1.0f) * 8.0f);
+  return sgn | mag;
+}
+
+// Generic form (fp32 weights, long or unaligned rows): one workgroup per row, a thread packs whole 32-element blocks.
+template <typename Tin>
+__global__ __launch_bounds__(kBlock) void rows_codes_fp6_kernel(const Tin* __restrict__ x, uint8_t* __restrict__ codes,
+                                                               Tin* __restrict__ scales, int64_t rows, int64_t cols, Fmt f) {
+  __shared__ uint32_t sh[kBlock / 64];
+  const int64_t nblk = cols >> 5;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const Tin* xr = x + row * cols;
+    uint32_t m = 0;
+    for (int64_t c = threadIdx.x; c < cols; c += kBlock) {
+      const uint32_t ab = DT<Tin>::absbits(load_scalar<Tin>(xr + c));
+      m = m > ab ? m : ab;
+    }
+    m = block_max(m, sh);
+    const float s = scale_of<Tin>(m, f.gmax);
+    if (threadIdx.x == 0) store_scalar<Tin>(scales + row, s);
+    for (int64_t b = threadIdx.x; b < nblk; b += kBlock) {
+      uint32_t o[6] = {0, 0, 0, 0, 0, 0};
+      for (int j = 0; j < 32; ++j) {
+        const float xn = div_round<Tin>(load_scalar<Tin>(xr + b * 32 + j), s);
+        const uint32_t neg = (xn < 0.0f) ? 1u : 0u;
+        const float qm = quant_mag(fabsf(xn), neg, f);
+        const uint32_t code = e2m3_of_level((neg && qm != 0.0f) ? -qm : qm);
+        const int bit = 6 * j;
+        o[bit >> 5] |= code << (bit & 31);
+        if ((bit & 31) > 26) o[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+      }
+      uint32_t* dst = (uint32_t*)(codes + row * (nblk * 24) + b * 24);
+      for (int i = 0; i < 6; ++i) dst[i] = o[i];
+    }
+  }
+}

@@ -658,6 +658,7 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 #include "fpq_fast16.h"
 #include "fpq_gemm_fp4.h"
 #include "fpq_gemm_fp8.h"
+#include "fpq_gemm_fp6.h"
 
 // ---------------------------------------------------------------------------------
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
@@ -1741,6 +1742,88 @@ int fpq_quant_rows_codes_fp8(const void* x, uint8_t* codes, void* scales, int64_
   else
     hipLaunchKernelGGL(rows_codes_fp8_kernel<float>, g, dim3(kBlock), 0, (hipStream_t)stream, (const float*)x, codes,
                        (float*)scales, rows, cols, make_fmt(table_id));
+  return check_launch();
+}
+
+static const Lut16Tab& lut16_codes6_e2m3() {
+  static const Lut16Tab* tab = [] {
+    auto* t = new Lut16Tab();
+    const Lut16Host& h = lut16_host(FPQ_E2M3, FPQ_E2M3);
+    const int n = 1 << (16 - h.args.shift);
+    for (int i = 0; i < n; ++i) t->e[i] = (uint16_t)e2m3_of_level(h2f(h.tab.e[i]));
+    return t;
+  }();
+  return *tab;
+}
+
+int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
+                             int in_dtype, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id != FPQ_E2M3) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (cols % 32 != 0) return FPQ_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!x || !codes || !scales) return FPQ_ERR_ARG;
+  if ((((uintptr_t)codes) & 7) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == FPQ_F16 && cols <= 8192 && (((uintptr_t)x) & 15) == 0) {
+    const Lut16Host& h = lut16_host(table_id, table_id);
+    const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+    const int64_t wgs = (rows + kBlock / 64 - 1) / (kBlock / 64);
+    const dim3 gw(grid_for(wgs, 8192));
+    const int maxc = (int)((cols / 32 + 63) / 64);
+#define FPQ_C6(M) hipLaunchKernelGGL((rows16_codes6_wave_kernel<M>), gw, dim3(kBlock), lds, st, (const uint16_t*)x, codes, \
+                                     (uint16_t*)scales, rows, cols, h.args, lut16_codes6_e2m3())
+    if (maxc <= 1) FPQ_C6(1);
+    else if (maxc <= 2) FPQ_C6(2);
+    else FPQ_C6(4);
+#undef FPQ_C6
+    return check_launch();
+  }
+  const dim3 g(grid_for(rows, 65535));
+  if (in_dtype == FPQ_F16)
+    hipLaunchKernelGGL(rows_codes_fp6_kernel<_Float16>, g, dim3(kBlock), 0, st, (const _Float16*)x, codes,
+                       (_Float16*)scales, rows, cols, make_fmt(table_id));
+  else
+    hipLaunchKernelGGL(rows_codes_fp6_kernel<float>, g, dim3(kBlock), 0, st, (const float*)x, codes, (float*)scales, rows,
+                       cols, make_fmt(table_id));
+  return check_launch();
+}
+
+int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream) {
+  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (tokens == 0 || outs == 0) return FPQ_OK;
+  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const char* env6 = getenv("FPQ_GEMM6_CFG");
+  const int cfg6 = env6 ? atoi(env6) : 0;
+#define FPQ_GO6(TA, TW, MT, NT)                                                                                     \
+  do {                                                                                                               \
+    using Cfg = GemmFp6Cfg<MT, NT>;                                                                                  \
+    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
+    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
+    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
+    hipLaunchKernelGGL((gemm_fp6_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
+                       a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
+                       (_Float16*)out, (int)tokens, (int)outs, (int)k);                                              \
+  } while (0)
+#define FPQ_GO6T(MT, NT)                                                                                             \
+  do {                                                                                                               \
+    if (a_scale_dtype == FPQ_F16 && w_scale_dtype == FPQ_F16) FPQ_GO6(_Float16, _Float16, MT, NT);                   \
+    else if (a_scale_dtype == FPQ_F16) FPQ_GO6(_Float16, float, MT, NT);                                             \
+    else if (w_scale_dtype == FPQ_F16) FPQ_GO6(float, _Float16, MT, NT);                                             \
+    else FPQ_GO6(float, float, MT, NT);                                                                              \
+  } while (0)
+  if (cfg6 == 1) FPQ_GO6T(8, 4);
+  else FPQ_GO6T(4, 4);
+#undef FPQ_GO6T
+#undef FPQ_GO6
   return check_launch();
 }
 

@@ -162,3 +162,76 @@ class FP8Linear(torch.nn.Module):
         lead = x.shape[:-1]
         a_codes, a_scales = quantize_fp8(x.to(torch.float16).reshape(-1, self.in_features), self.act_table)
         return linear_fp8(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)
+
+
+# ---- the same with 6-bit packed operands (FP6 E2M3 on both sides: the W6A6 run configuration) ---------------------
+def quantize_fp6(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [..., K] fp16/fp32 (K % 32 == 0) -> (codes uint8 [rows, K * 3 / 4]: dense 6-bit E2M3 codes,
+    scales [rows] in x.dtype); e2m3(code) * scale == fp6_quant_e2m3_per_token_cuda(x)."""
+    require_gpu(x, "quantize_fp6")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quantize_fp6: x must be float16 or float32, got {x.dtype}")
+    from ._lib import TABLE_IDS
+    k = x.shape[-1]
+    if k % 32 != 0:
+        raise RuntimeError("quantize_fp6: the last dimension must be a multiple of 32")
+    xc = x.contiguous()
+    rows = xc.numel() // k
+    codes = torch.empty((rows, k * 3 // 4), dtype=torch.uint8, device=x.device)
+    scales = torch.empty((rows,), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_rows_codes_fp6(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
+                                             TABLE_IDS["e2m3"], dtype_id(x.dtype), stream_ptr(x.device)),
+              "fpq_quant_rows_codes_fp6")
+    return codes, scales
+
+
+def dequantize_fp6(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """Reference decoder in torch ops (tests / debugging): fp32 [rows, K]."""
+    b = codes.reshape(codes.shape[0], -1, 3).to(torch.int32)
+    word = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+    c = torch.stack((word & 63, (word >> 6) & 63, (word >> 12) & 63, (word >> 18) & 63), dim=-1).reshape(codes.shape[0], -1)
+    e, m = (c >> 3) & 3, (c & 7).float()
+    mag = torch.where(e == 0, m / 8.0, (1.0 + m / 8.0) * torch.pow(2.0, (e - 1).float()))
+    val = torch.where((c & 32) != 0, -mag, mag)
+    return val * scales.float().unsqueeze(-1)
+
+
+def linear_fp6(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
+               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP6 matrix-core form (row-scaled operands)."""
+    require_gpu(a_codes, "linear_fp6")
+    tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 4 // 3
+    if w_codes.shape[1] != a_codes.shape[1]:
+        raise RuntimeError("linear_fp6: operand shapes mismatch")
+    out = torch.empty((tokens, outs), dtype=torch.float16, device=a_codes.device)
+    b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
+    with torch.cuda.device(a_codes.device):
+        check(lib().fpq_gemm_fp6_rows(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
+                                      w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
+                                      out.data_ptr(), tokens, outs, k, stream_ptr(a_codes.device)), "fpq_gemm_fp6_rows")
+    return out
+
+
+class FP6Linear(torch.nn.Module):
+    """FP8Linear with 6-bit packed operands, for E2M3 activations x E2M3 weights (run.sh:7): 0.75 byte per weight."""
+
+    def __init__(self, w_codes, w_scales, bias, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.register_buffer("w_codes", w_codes)
+        self.register_buffer("w_scales", w_scales)
+        self.register_buffer("bias", bias)
+
+    @classmethod
+    def from_float(cls, module: torch.nn.Linear):
+        assert isinstance(module, torch.nn.Linear) and module.in_features % 128 == 0 and module.out_features % 8 == 0
+        codes, scales = quantize_fp6(module.weight.detach().float())
+        bias = None if module.bias is None else module.bias.detach().to(torch.float16)
+        return cls(codes, scales, bias, module.in_features, module.out_features)
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        a_codes, a_scales = quantize_fp6(x.to(torch.float16).reshape(-1, self.in_features))
+        return linear_fp6(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)

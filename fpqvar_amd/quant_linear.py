@@ -178,8 +178,10 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
             from .gemm import FP4Linear
             return FP4Linear.from_float(lin)
         if fp6_ok and lin.in_features % 128 == 0 and lin.out_features % 8 == 0:
-            from .gemm import FP8Linear
-            return FP8Linear.from_float(lin, weight_fp_type, act_fp_type)
+            from .gemm import FP6Linear, FP8Linear
+            if weight_fp_type == "fp6_e2m3" and act_fp_type == "fp6_e2m3":
+                return FP6Linear.from_float(lin)                       # 6-bit packed operands
+            return FP8Linear.from_float(lin, weight_fp_type, act_fp_type)   # mixed / E3M2: E4M3-coded levels
         return QuantizedLinear.from_float(lin, **kw)
 
     for _, m in list(model.named_modules()):

@@ -257,6 +257,16 @@ int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_
                       const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
                       int64_t k, fpq_stream_t stream);
 
+/* The same pair with the operands in the matrix instruction's 6-bit packed form (FP6 E2M3: sign, 2 exponent bits with
+ * bias 1, 3 mantissa bits; element j of a row in bits [6j, 6j+6) of the row's little-endian bit string, i.e. dense
+ * packing, 3/4 byte per element): 25 % less operand traffic in a kernel bound by exactly that.  table_id must be
+ * FPQ_E2M3, cols % 32 == 0 (GEMM: k % 128 == 0); codes: [rows, cols * 3 / 4]; everything else as the FP8 pair. */
+int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
+                             int in_dtype, fpq_stream_t stream);
+int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream);
+
 /* Inverse of fpq_quant_rows_codes: out = (Tout)((float)table_dedup[code] * (float)scale). */
 int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, int64_t rows,
                            int64_t cols, int table_id, int scale_dtype, int out_dtype,

@@ -1059,7 +1059,7 @@ def test_quantize_var_real_fp4(dev):
                 weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3", fc2_fp_type="fp6_int_neg_e2m3_pos")
     fake6 = ql.quantize_VAR(copy.deepcopy(base), **cfg6).half()
     real6 = ql.quantize_VAR(copy.deepcopy(base), real_fp6=True, **cfg6)
-    assert isinstance(real6.ffn.fc1, gemm.FP8Linear) and isinstance(real6.attn.proj, gemm.FP8Linear)
+    assert isinstance(real6.ffn.fc1, gemm.FP6Linear) and isinstance(real6.attn.proj, gemm.FP6Linear)
     assert type(real6.ffn.fc2).__name__ == "QuantizedLinear_fc2"
     for a, b in ((fake6.ffn.fc1, real6.ffn.fc1), (fake6.attn.mat_qkv, real6.attn.mat_qkv), (fake6.attn.proj, real6.attn.proj)):
         ya, yb = a(x).float(), b(x).float()
@@ -1208,3 +1208,59 @@ def test_fp8_linear_module(dev):
     assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
     # the stored weight decodes to the reference's quantized weight
     assert_bits_equal(gemm.dequantize_fp8(fp8.w_codes, fp8.w_scales).half(), fake.weight, "FP8Linear weight")
+
+
+# ------------------------------------------------------------------ the same with 6-bit packed operands
+@pytest.mark.parametrize("dtype", (torch.float16, torch.float32))
+def test_fp6_codes_reproduce_fake_quant(dev, dtype):
+    from fpqvar_amd import gemm, ops
+    for rows, cols in ((70, 1920), (9, 2304), (5, 7680), (3, 12288), (4, 32)):
+        x = _inputs("heavy", (rows, cols), dtype, 63 + cols)
+        x[0] = 0
+        xd = x.to(dev)
+        codes, scales = gemm.quantize_fp6(xd)
+        assert codes.shape == (rows, cols * 3 // 4) and scales.shape == (rows,) and scales.dtype == dtype
+        assert_bits_equal(gemm.dequantize_fp6(codes, scales), ops.quant_rows(xd, "e2m3", cols, torch.float32), f"fp6 codes {cols}")
+        c8, s8 = gemm.quantize_fp8(xd, "e2m3")
+        assert_bits_equal(gemm.dequantize_fp6(codes, scales), gemm.dequantize_fp8(c8, s8), "fp6 vs fp8 codes")
+    # an unaligned fp16 base pointer takes the generic kernel
+    xu = _inputs("gauss", (6 * 256 + 8,), torch.float16, 64).to(dev)[8:].view(6, 256)
+    c, s = gemm.quantize_fp6(xu[:, :])
+    assert_bits_equal(gemm.dequantize_fp6(c, s), ops.quant_rows(xu, "e2m3", 256, torch.float32), "fp6 generic path")
+
+
+@pytest.mark.parametrize("T,O,K", ((256, 256, 1920), (1000, 5760, 1920), (130, 1928, 256), (64, 128, 7680), (20, 6912, 2304), (1, 8, 128)))
+def test_fp6_gemm(dev, T, O, K):
+    from fpqvar_amd import gemm
+    g = torch.Generator().manual_seed(302 + T)
+    x = (torch.randn(T, K, generator=g) * torch.exp(0.3 * torch.randn(T, K, generator=g))).half().to(dev)
+    w = (torch.randn(O, K, generator=g) * 0.02).to(dev)
+    bias = (torch.randn(O, generator=g) * 0.1).half().to(dev)
+    ac, asc = gemm.quantize_fp6(x)
+    wc, wsc = gemm.quantize_fp6(w)
+    y = gemm.linear_fp6(ac, asc, wc, wsc, bias)
+    assert y.shape == (T, O) and y.dtype == torch.float16
+    # same operands through the FP8-coded kernel: both accumulate exact products in fp32 in the same k order per
+    # MFMA, only the K-step differs - equal to fp32-accumulation tolerance, and mostly bit-equal
+    y8 = gemm.linear_fp8(*gemm.quantize_fp8(x, "e2m3"), *gemm.quantize_fp8(w, "e2m3"), bias)
+    a64, w64 = gemm.dequantize_fp6(ac, asc).double(), gemm.dequantize_fp6(wc, wsc).double()
+    ref = a64 @ w64.t() + bias.double()
+    err = (y.double() - ref).abs()
+    tol = 2.0 ** -10 * ref.abs() + 1e-5 * (a64.abs() @ w64.abs().t()) + 1e-6
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert float((y.float() - y8.float()).abs().max()) <= 2.0 ** -9 * float(y8.float().abs().max()) + 1e-4
+
+
+def test_fp6_linear_module(dev):
+    from fpqvar_amd import gemm, quant_linear as ql
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(1920, 640).to(dev)
+    x = torch.randn(3, 50, 1920, device=dev).half()
+    fp6 = gemm.FP6Linear.from_float(lin)
+    cfg = dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True, activation_fp_quant=True,
+               weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3")
+    fake = ql.QuantizedLinear.from_float(lin, **cfg).half()
+    ya, yb = fake(x).float(), fp6(x).float()
+    assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
+    assert_bits_equal(gemm.dequantize_fp6(fp6.w_codes, fp6.w_scales).half(), fake.weight, "FP6Linear weight")
+    assert fp6.w_codes.numel() == 640 * 1920 * 3 // 4

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """W6A6 (per-token activations x per-channel weights, FP6 E2M3) act-quant + Linear for VAR-d30's mat_qkv / fc1 / proj
 shapes at 65536 rows: reference formulation (fused fake-quant + fp16 F.linear on de-quantized tensors) vs the
-FP8-coded path (quantize to E4M3 bytes + fpq_gemm_fp8_rows)."""
+FP8-coded path (quantize to E4M3 bytes + fpq_gemm_fp8_rows) and the 6-bit packed path (fpq_gemm_fp6_rows)."""
 import json
 import os
 import sys
@@ -43,7 +43,12 @@ def main():
         ac, asc = gemm.quantize_fp8(x, "e2m3")
         t_q = timed(lambda: gemm.quantize_fp8(x, "e2m3"))
         t_g8 = timed(lambda: gemm.linear_fp8(ac, asc, wc, wsc))
-        res[name] = {"T,K,O": [T, K, O], "ref_fakequant_plus_fp16_gemm_ms": round(t_ref, 3), "fp16_gemm_only_ms": round(t_gemm16, 3),
+        a6, s6 = gemm.quantize_fp6(x)
+        w6, ws6 = gemm.quantize_fp6(w)
+        t_q6 = timed(lambda: gemm.quantize_fp6(x))
+        t_g6 = timed(lambda: gemm.linear_fp6(a6, s6, w6, ws6))
+        res[name] = {"T,K,O": [T, K, O], "quantize_to_fp6_codes_ms": round(t_q6, 3), "fp6_gemm_ms": round(t_g6, 3),
+                     "fp6_gemm_TFLOPs": round(flops / t_g6 / 1e9, 1), "fp6_path_total_ms": round(t_q6 + t_g6, 3), "ref_fakequant_plus_fp16_gemm_ms": round(t_ref, 3), "fp16_gemm_only_ms": round(t_gemm16, 3),
                      "fp16_gemm_TFLOPs": round(flops / t_gemm16 / 1e9, 1), "quantize_to_fp8_codes_ms": round(t_q, 3),
                      "fp8_gemm_ms": round(t_g8, 3), "fp8_gemm_TFLOPs": round(flops / t_g8 / 1e9, 1),
                      "fp8_path_total_ms": round(t_q + t_g8, 3)}
