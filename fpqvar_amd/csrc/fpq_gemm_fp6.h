@@ -80,13 +80,17 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
   }
   const int a_base = wm * MT * 1536, b_base = ASB * 3072 + wn * NT * 1536;   // tile row mt -> 1536 * mt (two per super-block)
 
-  // Two LDS stages, one barrier per step.  Measured on mat_qkv [65536 x 1920 -> 5760]: 0.81 ms; the same loop
-  // without its MFMAs 0.70 ms, without its LDS-DMA 0.60 ms, 256 x 128 tiles 0.81 ms, a three-stage ring with counted
-  // vmcnt 0.92 ms - i.e. the operand feed (DMA + barrier per 128-element step), not the matrix pipe, sets the pace.
+  // Two LDS stages, one barrier per step; the LDS-DMA instructions of step s+1 are issued one at a time between the
+  // MFMAs of step s.  Measured on mat_qkv [65536 x 1920 -> 5760] (ms; 128x128 / 256x128 tiles): DMA burst after the
+  // barrier 0.81 / 0.81, interleaved 0.79 / 0.75, register staging (global_load + ds_write) 0.88 / 0.85, three-stage
+  // ring with counted vmcnt 0.92, the burst loop without MFMAs 0.70, without DMA 0.60.  In-kernel stamps of the burst
+  // form: 2000 cycles per step = ~250 waiting at the barrier + 400-680 issuing six LDS-DMAs (65-110 cycles each)
+  // + the 16 MFMAs (608 cycles alone, 1216 for the two wavefronts of a SIMD): the operand feed, not the matrix pipe.
   for (int s = 0; s < steps; ++s) {
     FPQ_SYNC();   // stage s has landed; the other buffer's readers are done
-    if (s + 1 < steps) { FPQ_GLDS6_ISSUE(s + 1, (s + 1) & 1); }
     const uint8_t* st = smem + (s & 1) * STAGE;
+    const bool more = s + 1 < steps;
+    const int nb = (s + 1) & 1;
     v8i_t bf[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -94,14 +98,25 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
       const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
       bf[n] = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
     }
+    int issued = 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const uint8_t* p = st + a_base + m * 1536;
       const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
       const v8i_t af = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+      for (int n = 0; n < NT; ++n) {
         acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf[n], acc[m][n], 2, 2, 0, 0, 0, 0);   // fp6 e2m3, unscaled
+        constexpr int DMA_EVERY = (MT * NT) / PIECES > 0 ? (MT * NT) / PIECES : 1;   // one DMA piece after every DMA_EVERY-th MFMA
+        if (((m * NT + n) % DMA_EVERY) == DMA_EVERY - 1 && issued < PIECES) {
+          if (more)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[issued] + (s + 1) * 96),
+                                             (__attribute__((address_space(3))) void*)(smem + nb * STAGE + (wave + 4 * issued) * 1024),
+                                             16, 0, 0);
+          ++issued;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   }
 #undef FPQ_GLDS6_ISSUE

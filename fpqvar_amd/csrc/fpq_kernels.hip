@@ -1801,8 +1801,8 @@ int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_
   if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const char* env6 = getenv("FPQ_GEMM6_CFG");
-  const int cfg6 = env6 ? atoi(env6) : 0;
+  const char* env6 = getenv("FPQ_GEMM6_CFG");     // 0: 128 x 128 tiles, 1: 256 x 128 (default for tall problems)
+  const int cfg6 = env6 ? atoi(env6) : (tokens >= 4096 ? 1 : 0);
 #define FPQ_GO6(TA, TW, MT, NT)                                                                                     \
   do {                                                                                                               \
     using Cfg = GemmFp6Cfg<MT, NT>;                                                                                  \
