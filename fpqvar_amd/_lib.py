@@ -57,6 +57,13 @@ _SIGS = {
     "fpq_adaln_rotate_quant_rows_codes_mx": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
                                                          _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
                                                          _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_void_p]),
+    "fpq_adaln_rotate_quant_token_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                                      _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
+                                                      _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),
+    "fpq_adaln_rotate_quant_token_rows_codes_fp8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                                                _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
+                                                                _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int,
+                                                                _c.c_void_p]),
     "fpq_adaln_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
                                                 _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float,
                                                 _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),

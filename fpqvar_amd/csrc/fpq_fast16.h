@@ -738,7 +738,7 @@ __device__ __forceinline__ float row_sum_f32(float v, float* sh) {
   }
 }
 
-template <typename Tin, typename Tmod, int LANES, int MAXC, bool CODES = false>
+template <typename Tin, typename Tmod, int LANES, int MAXC, bool CODES = false, bool TOKEN = false>
 __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void* __restrict__ xv,
                                                                      u32x4* __restrict__ out, u32x4* __restrict__ h_out,
                                                                      u32x4* __restrict__ y_out, int64_t rows,
@@ -822,6 +822,10 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
   }
   const float var = row_sum_f32<LANES>(s2, shf) * inv_c;
   const float rstd = 1.0f / __builtin_sqrtf(var + ad.eps);
+  u32x4 ys[TOKEN ? MAXC : 1];
+  uint32_t mrow = 0;
+  (void)ys;
+  (void)mrow;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const int64_t v = (int64_t)c * LANES + lane;
@@ -884,6 +888,12 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
 #pragma unroll
     for (int k = 0; k < 4; ++k) y[k] = f2h2(t[2 * k] * r.c_h, t[2 * k + 1] * r.c_h);
     if (y_out && live && row_live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
+    if constexpr (TOKEN) {   // per-token scale: keep the rotated row, quantize after the row maximum is known
+      ys[c] = y;
+      const uint32_t mv = vec_absmax16(y);
+      mrow = mrow > mv ? mrow : mv;
+      continue;
+    }
     uint32_t m = row_max_dpp<16>(vec_absmax16(y));
     RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
     if constexpr (CODES) {
@@ -895,6 +905,41 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
     } else {
       u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
       if (live && row_live) __builtin_nontemporal_store(o, out + row * vpr + v);
+    }
+  }
+  if constexpr (TOKEN) {
+    // fp6_quant_*_per_token_cuda on the rotated row (tr/quant_utils.py:503-534): one scale for the whole row
+    static_assert(!TOKEN || LANES == 64, "the per-token form keeps a row inside one wavefront");
+    mrow = row_max_dpp<64>(mrow);
+    const RowScale16 s = row_scale16(mrow, a.fpos.gmax, a.inv_gpos);
+    if (r.code_scales && lane == 0 && row_live) r.code_scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int64_t v = (int64_t)c * LANES + lane;
+      if (v < vpr && row_live) {
+        if constexpr (CODES) {   // E4M3 bytes of the levels (fpq_gemm_fp8.h), 8 per vector
+          const uint32_t wk0 = ys[c][0], wk1 = ys[c][1], wk2 = ys[c][2], wk3 = ys[c][3];
+          uint32_t cb[8];
+          const uint32_t ws[4] = {wk0, wk1, wk2, wk3};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t wk = ws[k];
+            const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
+            const float y0 = mul_h_lo(wk, s.inv), y1 = mul_h_hi(wk, s.inv);
+            const float e0 = __builtin_fmaf(-y0, s.sf, x0), e1 = __builtin_fmaf(-y1, s.sf, x1);
+            const float r0 = __builtin_fmaf(e0, s.inv, y0), r1 = __builtin_fmaf(e1, s.inv, y1);
+            const uint32_t rb = f2h2(r0, r1);
+            const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+            cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
+            cb[2 * k + 1] = lut[u >> (16 + a.shift)];
+          }
+          const u32x2 o2 = {cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24), cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24)};
+          __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
+        } else {
+          u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+          __builtin_nontemporal_store(o, out + row * vpr + v);
+        }
+      }
     }
   }
   }   // row loop

@@ -1161,10 +1161,12 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
 template <typename Tin, typename Tmod>
 int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out, int64_t rows, int64_t cols,
                               const AdaLnArgs& ad, const float* smooth, const uint32_t sign[4], int table_id,
-                              hipStream_t st, int lanes_per_row, uint16_t* code_scales = nullptr) {
+                              hipStream_t st, int lanes_per_row, uint16_t* code_scales = nullptr,
+                              int token_mode = 0 /*1: per-token values, 2: per-token E4M3 codes*/,
+                              const Lut16Tab* token_code_tab = nullptr) {
   const Lut16Host& h = lut16_host(table_id, table_id);
   if (!h.tab_valid) return FPQ_ERR_TABLE;
-  const Lut16Tab& tab = code_scales ? lut16_mx_codes_e2m1() : h.tab;
+  const Lut16Tab& tab = token_mode == 2 ? *token_code_tab : (code_scales && !token_mode ? lut16_mx_codes_e2m1() : h.tab);
   RotArgs r;
   r.code_scales = code_scales;
   r.smooth = smooth;
@@ -1188,6 +1190,22 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, L, M>), g, dim3(kBlock), lds, st, x, (u32x4*)out,  \
                          (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab);                                    \
   } while (0)
+  if (token_mode) {   // one wavefront per row only (C <= 2560)
+#define FPQ_ADALN_TOK(M)                                                                                             \
+  do {                                                                                                               \
+    if (token_mode == 2)                                                                                             \
+      hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, 64, M, true, true>), g, dim3(kBlock), lds, st, x,  \
+                         (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab);                       \
+    else                                                                                                             \
+      hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, 64, M, false, true>), g, dim3(kBlock), lds, st, x, \
+                         (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab);                       \
+  } while (0)
+    if (lanes_per_row != 64 || maxc > 5) return FPQ_ERR_SHAPE;
+    if (maxc <= 4) FPQ_ADALN_TOK(4);
+    else FPQ_ADALN_TOK(5);
+#undef FPQ_ADALN_TOK
+    return check_launch();
+  }
   if (lanes_per_row == 256) {
     if (maxc <= 1) FPQ_ADALN(256, 1);
     else FPQ_ADALN(256, 2);
@@ -1551,7 +1569,8 @@ int fpq_rotate_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, 
 static int adaln_rotate_quant_impl(const void* x, void* out, void* h_out, void* rotated_out, void* code_scales,
                                    int64_t rows, int64_t cols, int in_dtype, const void* scale, const void* shift,
                                    int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
-                                   const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+                                   const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream,
+                                   int token_mode = 0, const Lut16Tab* token_code_tab = nullptr) {
   if (rows < 0 || cols < 0 || rows_per_batch <= 0 || !sign_mask_host) return FPQ_ERR_ARG;
   if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
   if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (mod_dtype != FPQ_F16 && mod_dtype != FPQ_F32))
@@ -1573,11 +1592,13 @@ static int adaln_rotate_quant_impl(const void* x, void* out, void* h_out, void* 
   // loop; measured 0.180 ms vs 0.199 ms per [65500 x 1920] on MI355X), one workgroup per row beyond.
   // FPQ_ADALN_LANES / FPQ_ADALN_GRID override the choice for experiments.
   const char* env = getenv("FPQ_ADALN_LANES");
-  const int lanes = env ? atoi(env) : (cols / 8 <= 64 * 5 ? 64 : 256);
+  const int lanes = (env && !token_mode) ? atoi(env) : (cols / 8 <= 64 * 5 ? 64 : 256);
   const int lpr = (lanes == 64) ? 64 : 256;
+  if (token_mode && lpr != 64) return FPQ_ERR_SHAPE;   // the per-token form keeps a row inside one wavefront: C <= 2560
   hipStream_t st = (hipStream_t)stream;
 #define FPQ_GO(TI, TM) return launch_adaln_rotate_quant<TI, TM>(x, out, h_out, rotated_out, rows, cols, ad, smooth, \
-                                                              sign_mask_host, table_id, st, lpr, (uint16_t*)code_scales)
+                                                              sign_mask_host, table_id, st, lpr, (uint16_t*)code_scales, \
+                                                              token_mode, token_code_tab)
   if (in_dtype == FPQ_F16 && mod_dtype == FPQ_F16) FPQ_GO(_Float16, _Float16);
   if (in_dtype == FPQ_F16) FPQ_GO(_Float16, float);
   if (mod_dtype == FPQ_F16) FPQ_GO(float, _Float16);
@@ -1743,6 +1764,25 @@ int fpq_quant_rows_codes_fp8(const void* x, uint8_t* codes, void* scales, int64_
     hipLaunchKernelGGL(rows_codes_fp8_kernel<float>, g, dim3(kBlock), 0, (hipStream_t)stream, (const float*)x, codes,
                        (float*)scales, rows, cols, make_fmt(table_id));
   return check_launch();
+}
+
+int fpq_adaln_rotate_quant_token_rows(const void* x, void* out, void* h_out, void* rotated_out, void* row_scales,
+                                      int64_t rows, int64_t cols, int in_dtype, const void* scale, const void* shift,
+                                      int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
+                                      const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  if ((((uintptr_t)row_scales) & 1) != 0) return FPQ_ERR_ARG;
+  return adaln_rotate_quant_impl(x, out, h_out, rotated_out, row_scales, rows, cols, in_dtype, scale, shift, mod_dtype,
+                                 rows_per_batch, eps, smooth, sign_mask_host, table_id, stream, 1, nullptr);
+}
+
+int fpq_adaln_rotate_quant_token_rows_codes_fp8(const void* x, uint8_t* codes, void* row_scales, int64_t rows, int64_t cols,
+                                                int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                                int64_t rows_per_batch, float eps, const float* smooth,
+                                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  if (rows > 0 && cols > 0 && !row_scales) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  return adaln_rotate_quant_impl(x, codes, nullptr, nullptr, row_scales, rows, cols, in_dtype, scale, shift, mod_dtype,
+                                 rows_per_batch, eps, smooth, sign_mask_host, table_id, stream, 2, &lut16_codes8(table_id));
 }
 
 static const Lut16Tab& lut16_codes6_e2m3() {

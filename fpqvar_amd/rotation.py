@@ -211,6 +211,43 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
     return codes, scales
 
 
+def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, table: str = "e2m3",
+                             d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None, eps: float = 1e-6,
+                             emit: str = "values"):
+    """The fused producer for the per-token configurations (W6A6): LayerNorm, modulate, smooth, rotate, then
+    fp6_quant_*_per_token_cuda with one scale per token row.  emit="values": fp16 [B, L, C];
+    emit="fp8": (codes uint8 [B*L, C], scales fp16 [B*L]) for gemm.linear_fp8.  C <= 2560."""
+    require_gpu(x, "adaln_rotate_quant_token")
+    if x.dim() != 3:
+        raise RuntimeError("adaln_rotate_quant_token: x must be [B, L, C]")
+    bsz, seq, c = x.shape
+    if c % 128 != 0 or c > 2560:
+        raise RuntimeError("adaln_rotate_quant_token: C must be a multiple of 128 and at most 2560")
+    if scale.dtype != shift.dtype or scale.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("adaln_rotate_quant_token: scale and shift must both be float16 or both float32")
+    sc = scale.reshape(bsz, c).contiguous()
+    sh = shift.reshape(bsz, c).contiguous()
+    mask = _mask_arg(d)
+    xc = x if x.is_contiguous() else x.contiguous()
+    sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
+    rows = bsz * seq
+    with torch.cuda.device(x.device):
+        if emit == "fp8":
+            codes = torch.empty((rows, c), dtype=torch.uint8, device=x.device)
+            scales = torch.empty((rows,), dtype=torch.float16, device=x.device)
+            check(lib().fpq_adaln_rotate_quant_token_rows_codes_fp8(
+                xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),
+                dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, TABLE_IDS[table], stream_ptr(x.device)),
+                "fpq_adaln_rotate_quant_token_rows_codes_fp8")
+            return codes, scales
+        out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        check(lib().fpq_adaln_rotate_quant_token_rows(
+            xc.data_ptr(), out.data_ptr(), None, None, None, rows, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),
+            dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, TABLE_IDS[table], stream_ptr(x.device)),
+            "fpq_adaln_rotate_quant_token_rows")
+    return out
+
+
 def adaln_rotate_quant(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, table: str = "e2m1",
                        d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None, eps: float = 1e-6,
                        return_intermediates: bool = False):

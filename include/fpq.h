@@ -192,6 +192,21 @@ int fpq_adaln_rotate_quant_rows(const void* x, void* out, void* h_out, void* rot
                                 int64_t rows_per_batch, float eps, const float* smooth,
                                 const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
 
+/* The same producer for the per-token configurations (W6A6, run.sh:7 with --rotate --block_rotate): the quantizer
+ * behind the rotation is fp6_quant_{e2m3,e3m2}_per_token_cuda (tr/quant_utils.py:503-534), ONE scale per token row
+ * of `cols` channels.  A row lives in one wavefront: cols <= 2560 (d30: 1920, d36: 2304).  row_scales: NULL or fp16
+ * [rows] receiving the scales.  Parity as fpq_adaln_rotate_quant_rows: out == fpq_quant_rows(y, cols = row length)
+ * bit for bit on the rotated y produced here.  The _codes_fp8 form emits the operand format of fpq_gemm_fp8_rows
+ * (E4M3 bytes [rows, cols] + fp16 row scales) instead of values. */
+int fpq_adaln_rotate_quant_token_rows(const void* x, void* out, void* h_out, void* rotated_out, void* row_scales,
+                                      int64_t rows, int64_t cols, int in_dtype, const void* scale, const void* shift,
+                                      int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
+                                      const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
+int fpq_adaln_rotate_quant_token_rows_codes_fp8(const void* x, uint8_t* codes, void* row_scales, int64_t rows,
+                                                int64_t cols, int in_dtype, const void* scale, const void* shift,
+                                                int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
+                                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
+
 /* max|x| over n elements (NaN-propagating, like torch's x.abs().max()), written
  * as ONE scalar of `dtype` to `out`.  `out` must hold 4 bytes; it is zeroed on the
  * stream first (hipMemsetAsync) and then combined with device atomics. */

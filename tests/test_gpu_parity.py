@@ -1264,3 +1264,29 @@ def test_fp6_linear_module(dev):
     assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
     assert_bits_equal(gemm.dequantize_fp6(fp6.w_codes, fp6.w_scales).half(), fake.weight, "FP6Linear weight")
     assert fp6.w_codes.numel() == 640 * 1920 * 3 // 4
+
+
+@pytest.mark.parametrize("C", (1920, 2304))
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+def test_adaln_rotate_quant_per_token(dev, C, x_dtype):
+    """The fused producer of the W6A6 configuration: same LayerNorm / modulate / smooth / rotate stages as the
+    per-group form (their rotated output is the bit-level reference here), then ONE scale per token row."""
+    from fpqvar_amd import gemm, ops, rotation as rot
+    g = torch.Generator().manual_seed(83)
+    B, L = 3, 37
+    x = (torch.randn(B, L, C, generator=g) * 2 + 0.3).to(x_dtype).to(dev)
+    scale = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    shift = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    s = (torch.rand(C, generator=g) * 1.5 + 0.25).to(dev)
+    _, _, y = rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s, return_intermediates=True)   # rotated fp16 rows
+    for table in ("e2m3", "e3m2"):
+        out = rot.adaln_rotate_quant_token(x, scale, shift, table, smooth=s)
+        assert out.shape == (B, L, C) and out.dtype == torch.float16
+        assert_bits_equal(out, ops.quant_rows(y, table, C, torch.float16), f"per-token quant of the rotated row, {table}")
+        assert_bits_equal(out, orc.per_token_kernel_sem(y.cpu(), table), f"oracle, {table}")
+        codes, scales = rot.adaln_rotate_quant_token(x, scale, shift, table, smooth=s, emit="fp8")
+        c2, s2 = gemm.quantize_fp8(y.reshape(B * L, C), table)
+        assert torch.equal(scales, s2) and torch.equal(codes, c2), f"fp8 operands, {table}"
+    with pytest.raises(RuntimeError):
+        rot.adaln_rotate_quant_token(torch.zeros(1, 2, 4096, device=dev).half(), torch.zeros(1, 1, 4096, device=dev).half(),
+                                     torch.zeros(1, 1, 4096, device=dev).half())
