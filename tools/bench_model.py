@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--batch", type=int, default=100)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--paths", default="F,Q,R")
+    ap.add_argument("--config", default="w4a4", choices=("w4a4", "w6a6"),
+                    help="w4a4: run.sh line 4 (per-group fp_e2, fc2 dual FP4); w6a6: run.sh line 10 (per-token / per-channel fp6_e2m3, fc2 dual FP6)")
     ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -75,13 +77,53 @@ def main():
         return rot.rotate_weight(w, q64) if rotate else w
 
     w32 = {"qkv": lin_w(3 * C, C, s_qkv, True), "proj": lin_w(C, C), "fc1": lin_w(HID, C, s_fc1, True), "fc2": lin_w(C, HID)}
-    wq = {n: qu.fp_quant_e2_per_group_cuda(w, 4, 128).half() for n, w in w32.items()}
-    fp4 = {n: gemm.quantize_mx(w32[n]) for n in ("qkv", "proj", "fc1")}
+    W6 = args.config == "w6a6"
+    if W6:
+        wq = {n: qu.fp6_quant_e2m3_per_token_cuda(w, 6) for n, w in w32.items()}
+        fp4 = {n: gemm.quantize_fp8(w32[n], "e2m3") for n in ("qkv", "fc1")}        # operands of the row-scaled GEMMs
+        fp4["proj"] = gemm.quantize_fp6(w32["proj"])
+    else:
+        wq = {n: qu.fp_quant_e2_per_group_cuda(w, 4, 128).half() for n, w in w32.items()}
+        fp4 = {n: gemm.quantize_mx(w32[n]) for n in ("qkv", "proj", "fc1")}
     mods = [[(torch.randn(B, 1, C, device=dev) * 0.2).half() for _ in range(6)] for _ in range(depth)]
     e2m1 = qu.fp4_e2m1_grid.to(dev)
     e2m3 = qu.fp6_e2m3_grid.to(dev)
     gneg = torch.tensor([-1.75, -1.5, -1.25, -1.0, -0.75, -0.5, -0.25, 0.0], device=dev)
     gpos = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], device=dev)
+    ineg, e2m3p = qu.int_neg_grid.to(dev), qu.e2m3_pos_grid.to(dev)
+
+    # the reference's op sequences for the two configurations
+    def r_act(t):      # activation quantizer of mat_qkv / proj / fc1
+        return ref_sym(t, e2m3, None, torch.float16) if W6 else ref_sym(t, e2m1, 128)
+
+    def r_fc2(t):      # fc2's dual-format input quantizer
+        if not W6:
+            return ref_dual(t, gneg, gpos)
+        zeros = torch.zeros_like(t)
+        xn_, xp_ = torch.where(t <= 0, t, zeros), torch.where(t > 0, t, zeros)
+        sn = xn_.abs().max(dim=-1, keepdim=True)[0] / ineg.abs().max()
+        sp = xp_.abs().max(dim=-1, keepdim=True)[0] / e2m3p.abs().max()
+        qa, _ = quant_cuda.quant((xn_ / sn).view(-1).to(torch.float32), ineg)
+        qb, _ = quant_cuda.quant((xp_ / sp).view(-1).to(torch.float32), e2m3p)
+        return (qa.view(t.shape) * sn + qb.view(t.shape) * sp).to(t.dtype)
+
+    # this library's single launches
+    def f_act(t):
+        return qu.fp6_quant_e2m3_per_token_cuda(t, 6) if W6 else qu.fp_quant_e2_per_group_cuda(t, 4, 128)
+
+    def f_fc2(t):
+        return qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(t, 6) if W6 else qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(t, 4, 128)
+
+    def f_producer(t, sc, sh, sm):
+        return rot.adaln_rotate_quant_token(t, sc, sh, "e2m3", smooth=sm) if W6 else rot.adaln_rotate_quant(t, sc, sh, "e2m1", smooth=sm)
+
+    def q_producer_linear(t, sc, sh, sm, name):
+        if W6:
+            return gemm.linear_fp8(*rot.adaln_rotate_quant_token(t, sc, sh, "e2m3", smooth=sm, emit="fp8"), *fp4[name])
+        return gemm.linear_fp4(*rot.adaln_rotate_quant_mx(t, sc, sh, smooth=sm), *fp4[name])
+
+    def q_proj(t2d):
+        return gemm.linear_fp6(*gemm.quantize_fp6(t2d), *fp4["proj"]) if W6 else gemm.linear_fp4(*gemm.quantize_mx(t2d), *fp4["proj"])
     max_len = sum(p * p for p in PATCH_NUMS)
 
     def attend(q, kc, vc):                      # q [B,L,H,c]; kc, vc [B,Ltot,H,c] (flash layout, as the KV runs use)
@@ -135,7 +177,7 @@ def main():
                 if path == "R":
                     with torch.autocast("cuda", dtype=torch.float16):
                         x1 = torch.matmul(Fn.layer_norm(x, (C,), eps=1e-6).mul(sc1.add(1)).add_(sh1).mul(s_qkv), q32)
-                        qkv = Fn.linear(ref_sym(x1, e2m1, 128), wq["qkv"]).view(B, L, 3, H, hd)
+                        qkv = Fn.linear(r_act(x1), wq["qkv"]).view(B, L, 3, H, hd)
                         q, k, v = qkv.unbind(2)
                         if caches[b] is None:
                             kc, vc = k, v
@@ -145,33 +187,33 @@ def main():
                             cv = ref_sym(cv.contiguous(), e2m3, None, torch.float16)
                             kc, vc = torch.cat((ck, k), dim=1), torch.cat((cv, v), dim=1)
                         caches[b] = (kc, vc)
-                        a = Fn.linear(ref_sym(attend(q, kc, vc), e2m1, 128), wq["proj"])
+                        a = Fn.linear(r_act(attend(q, kc, vc)), wq["proj"])
                         x = x + a.mul(g1)
                         x2 = torch.matmul(Fn.layer_norm(x, (C,), eps=1e-6).mul(sc2.add(1)).add_(sh2).mul(s_fc1), q32)
-                        h = Fn.gelu(Fn.linear(ref_sym(x2, e2m1, 128), wq["fc1"]), approximate="tanh")
-                        x = x + Fn.linear(ref_dual(h, gneg, gpos), wq["fc2"]).mul(g2)
+                        h = Fn.gelu(Fn.linear(r_act(x2), wq["fc1"]), approximate="tanh")
+                        x = x + Fn.linear(r_fc2(h), wq["fc2"]).mul(g2)
                     continue
                 if path == "F":
-                    qkv = Fn.linear(rot.adaln_rotate_quant(x, sc1, sh1, "e2m1", smooth=s_qkv), wq["qkv"])
+                    qkv = Fn.linear(f_producer(x, sc1, sh1, s_qkv), wq["qkv"])
                 else:
-                    qkv = gemm.linear_fp4(*rot.adaln_rotate_quant_mx(x, sc1, sh1, smooth=s_qkv), *fp4["qkv"])
+                    qkv = q_producer_linear(x, sc1, sh1, s_qkv, "qkv")
                 q, k, v = qkv.view(B, L, 3, H, hd).unbind(2)
                 kc, vc = caches[b].append(k, v)
                 a = attend(q, kc, vc)
                 if path == "F":
-                    a = Fn.linear(qu.fp_quant_e2_per_group_cuda(a, 4, 128), wq["proj"])
+                    a = Fn.linear(f_act(a), wq["proj"])
                 else:
-                    a = gemm.linear_fp4(*gemm.quantize_mx(a.view(B * L, C)), *fp4["proj"]).view(B, L, C)
+                    a = q_proj(a.view(B * L, C)).view(B, L, C)
                 x = x + a.mul(g1)
                 if path == "F":
-                    h = Fn.linear(rot.adaln_rotate_quant(x, sc2, sh2, "e2m1", smooth=s_fc1), wq["fc1"])
+                    h = Fn.linear(f_producer(x, sc2, sh2, s_fc1), wq["fc1"])
                 else:
-                    h = gemm.linear_fp4(*rot.adaln_rotate_quant_mx(x, sc2, sh2, smooth=s_fc1), *fp4["fc1"]).view(B, L, HID)
+                    h = q_producer_linear(x, sc2, sh2, s_fc1, "fc1").view(B, L, HID)
                 h = Fn.gelu(h, approximate="tanh")
-                x = x + Fn.linear(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128), wq["fc2"]).mul(g2)
+                x = x + Fn.linear(f_fc2(h), wq["fc2"]).mul(g2)
         return x
 
-    res = {"workload": f"VAR-d30 256x256 transformer part, {depth} blocks x 10 steps, B={B} (CFG), W4A4 + FP6 KV cache, random weights",
+    res = {"workload": f"VAR-d30 256x256 transformer part, {depth} blocks x 10 steps, B={B} (CFG), {args.config.upper()} + FP6 KV cache, random weights",
            "depth": depth, "batch_rows": B}
     paths = args.paths.split(",")
     for path in paths:
