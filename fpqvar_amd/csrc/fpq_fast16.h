@@ -391,10 +391,11 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
   extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
   __shared__ uint32_t sh[kBlock / 64];
   const int64_t vec_per_row = cols >> 3;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  // rows blockIdx.x, blockIdx.x + gridDim.x, ...: the workgroups in flight sweep the tensor front to back together
+  // (consecutive rows per workgroup measured 0.68 of 8 TB/s on [65536 x 7680], this order 0.79-0.81)
+  (void)rows_per_block;
   bool first = true;
-  for (int64_t row = r0; row < r1; ++row) {
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const u32x4* xr = (const u32x4*)(x + row * cols);
     u32x4* orow = (u32x4*)(out + row * cols);
     u32x4 raw[MAXC];

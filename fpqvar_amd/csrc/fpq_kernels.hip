@@ -1262,7 +1262,10 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   }
   const int maxc = (int)((vec_per_row + kBlock - 1) / kBlock);
   // enough workgroups to fill the chip several times over, each walking consecutive rows
-  const int64_t target_wgs = h.tab_valid ? 16384 : 2048;   // table evaluated per workgroup when it is not an argument
+  // one row per workgroup, dispatched in address order, when the table arrives as a kernel argument (measured on
+  // [65536 x 7680]: 0.785 of 8 TB/s vs 0.676 with four consecutive rows per workgroup); a table that every workgroup
+  // has to evaluate itself is amortised over more rows
+  const int64_t target_wgs = h.tab_valid ? (1 << 20) : 2048;
   int64_t rpb = (rows + target_wgs - 1) / target_wgs;
   if (rpb < 1) rpb = 1;
   const int64_t grid = (rows + rpb - 1) / rpb;

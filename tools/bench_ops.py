@@ -14,6 +14,9 @@ R = 65536
 CASES = {
     # name: (rows, cols, dtype, bytes per element, fn(x))
     "sym_e2m1_g128_f16": (R, 1920, torch.float16, 4, lambda x: ops.quant_rows(x, "e2m1", 128)),
+    "sym_e2m1_g128_f16_7680": (R, 7680, torch.float16, 4, lambda x: ops.quant_rows(x, "e2m1", 128)),
+    "sym_e2m1_g128_f16_16384x7680": (R // 4, 7680, torch.float16, 4, lambda x: ops.quant_rows(x, "e2m1", 128)),
+    "sym_e2m3_token_f16_16384x7680": (R // 4, 7680, torch.float16, 4, lambda x: ops.quant_rows(x, "e2m3", 7680, torch.float16)),
     "dual_fp4_g128_f16_7680": (R, 7680, torch.float16, 4, lambda x: ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", 128, 1.0)),
     "dual_fp6_g128_f16_7680": (R, 7680, torch.float16, 4, lambda x: ops.quant_rows_dual(x, "int_neg", "e2m3_pos", 128, None)),
     "dual_fp6_token_f16_7680": (R, 7680, torch.float16, 4, lambda x: ops.quant_rows_dual(x, "int_neg", "e2m3_pos", 7680, None)),
