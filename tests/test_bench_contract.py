@@ -45,3 +45,46 @@ def test_bench_prints_one_contract_line():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 0.3 < rf["frac"] < 1.0, rf            # a 5-step run on a cold box is slower than the steady state, never absurd
     assert res["value"] > 400
+
+
+def _calib_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from fpqvar_amd import calibrate as cal
+        from oracle import fpq_oracle as orc
+        # the HIP quantizer and the CUDA synchronisation points are replaced: this checks bench.py's control flow
+        # (every rank reaches every collective, the gathered form is timed at N > 1), not the kernels
+        cal.default_weight_quantizer = lambda *a, **k: (lambda name, w: orc.per_group_kernel_sem(w, "e2m1", 128).half())
+        torch.cuda.synchronize = lambda *a, **k: None
+        torch.cuda.empty_cache = lambda *a, **k: None
+        res = bench.weight_calibration(torch.device("cpu"), dist, world, rank, depth=2, iters=1)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_calibration_control_flow_gloo_world2():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_calib_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[1] is None                                  # only rank 0 reports
+    r0 = got[0]
+    assert r0["n_gpus"] == 2 and r0["scaling"] == "strong" and r0["elements"] == 2 * 12 * 128 * 128
+    assert r0["ms"] > 0 and r0["ms_with_all_gather"] > 0 and r0["gathered_bytes_per_rank"] == 2 * r0["elements"]
