@@ -26,7 +26,10 @@ import torch.nn.functional as Fn  # noqa: E402
 import quant_cuda  # noqa: E402  (the drop-in module)
 from fpqvar_amd import gemm, kv_cache, quant_utils as qu, rotation as rot  # noqa: E402
 
-PATCH_NUMS = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
+MODELS = {   # name: (depth, patch_nums, rows per token = images x CFG); SURVEY.md section 8 header, configs C3 / C5
+    "d30-256": (30, (1, 2, 3, 4, 5, 6, 8, 10, 13, 16), 100),
+    "d36-512": (36, (1, 2, 3, 4, 6, 9, 13, 18, 24, 32), 20),
+}
 
 
 def ref_sym(x, grid, group=None, out_dtype=None):
@@ -54,8 +57,10 @@ def ref_dual(x, gneg, gpos, group=128):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--depth", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=100)
+    ap.add_argument("--model", default="d30-256", choices=tuple(MODELS),
+                    help="d30-256: VAR-d30 256x256 (C = 1920); d36-512: VAR-d36 512x512 (C = 2304, 2240 tokens)")
+    ap.add_argument("--depth", type=int, default=None, help="run fewer blocks than the model has")
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--paths", default="F,Q,R")
     ap.add_argument("--config", default="w4a4", choices=("w4a4", "w6a6"),
@@ -64,7 +69,8 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    C, H, HID, B, depth = 64 * 30, 30, 4 * 64 * 30, args.batch, args.depth
+    heads, PATCH_NUMS, rows = MODELS[args.model]
+    C, H, HID, B, depth = 64 * heads, heads, 4 * 64 * heads, args.batch or rows, args.depth or heads
     hd = C // H
     s_qkv, s_fc1 = torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5
     q64 = rot.block_random_hadamard_matrix(C, 128, dev, 42)
@@ -213,7 +219,7 @@ def main():
                 x = x + Fn.linear(f_fc2(h), wq["fc2"]).mul(g2)
         return x
 
-    res = {"workload": f"VAR-d30 256x256 transformer part, {depth} blocks x 10 steps, B={B} (CFG), {args.config.upper()} + FP6 KV cache, random weights",
+    res = {"workload": f"VAR-{args.model} transformer part, {depth} blocks x {len(PATCH_NUMS)} steps ({max_len} tokens), B={B} (CFG), {args.config.upper()} + FP6 KV cache, random weights",
            "depth": depth, "batch_rows": B}
     paths = args.paths.split(",")
     for path in paths:
