@@ -32,6 +32,9 @@ _SIGS = {
     "fpq_quant_nearest_builtin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
     "fpq_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                    _c.c_void_p]),
+    "fpq_kv_cache_step": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p,
+                                      _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int,
+                                      _c.c_void_p]),
     "fpq_quant_rows_argmin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                           _c.c_void_p]),
     "fpq_quant_rows_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,

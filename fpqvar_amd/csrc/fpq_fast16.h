@@ -314,6 +314,72 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
   }
 }
 
+// ---------------------------------------------------------------------------------
+// KV-cache step (the reference's tr/basic_var.py:186-209): ONE launch
+//   (a) quantizes, in place, the cache entries the previous step appended (their first - and, the quantizer being
+//       idempotent on its own output, only - quantization), rows of 8 * LPR halves, and
+//   (b) copies the new k / v rows (any batch / token pitch, e.g. views of the fused qkv output) behind them.
+// The cache is fp16 [2 (k, v), batch, max_len, row_elems]; blockIdx.z = k / v, blockIdx.y = batch entry,
+// blockIdx.x < q_tiles: job (a), else job (b).  Every branch is uniform over the workgroup.
+// ---------------------------------------------------------------------------------
+struct KvStepArgs {
+  u32x4* cache;
+  int64_t slab_vec;        // 16-byte vectors per (k|v, batch entry) slab = max_len * row_vec
+  int row_vec;             // vectors per token row
+  int batch;
+  int64_t q_first_vec;     // first vector of the rows to quantize (inside a slab)
+  int64_t q_vecs;
+  int q_tiles;
+  const uint16_t* src[2];  // new k, new v: [batch, n_new, row_elems], rows contiguous
+  int64_t src_batch_pitch, src_token_pitch;   // in elements
+  int64_t new_first_vec;
+  int64_t new_vecs;
+};
+
+template <int LPR, int U>
+__global__ __launch_bounds__(kBlock) void kv16_step_kernel(KvStepArgs k, Lut16Args a, Lut16Tab tab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  const int kv = blockIdx.z, b = blockIdx.y;
+  u32x4* slab = k.cache + ((int64_t)kv * k.batch + b) * k.slab_vec;
+  if ((int)blockIdx.x < k.q_tiles) {
+    u32x4* p = slab + k.q_first_vec;
+    const int64_t v0 = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+    u32x4 raw[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * kBlock;
+      live[u] = v < k.q_vecs;     // q_vecs is a multiple of LPR: a row is live or dead as a whole
+      raw[u] = live[u] ? p[v] : u32x4{0, 0, 0, 0};
+    }
+    {
+      const int n = 1 << (16 - a.shift);
+      for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t m = row_max_dpp<LPR>(vec_absmax16(raw[u]));
+      const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      const u32x4 o = quant_vec16<false>(raw[u], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      if (live[u]) p[v0 + u * kBlock] = o;
+    }
+  } else {
+    const uint16_t* s = k.src[kv] + (int64_t)b * k.src_batch_pitch;
+    u32x4* d = slab + k.new_first_vec;
+    const int64_t v0 = (int64_t)((int)blockIdx.x - k.q_tiles) * (kBlock * U) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * kBlock;
+      if (v < k.new_vecs) {
+        const int64_t l = v / k.row_vec;
+        const int c = (int)(v - l * k.row_vec);
+        d[v] = *(const u32x4*)(s + l * k.src_token_pitch + c * 8);
+      }
+    }
+  }
+}
+
 // Same rows, but LPR lanes own a row of 2*LPR vectors (two 16-byte vectors per lane, LPR*16 bytes
 // apart): the per-row work - cross-lane max, scale, reciprocal - is paid once per 16 elements of a
 // lane instead of once per 8.  Every load / store instruction still touches whole 128-byte lines

@@ -1458,6 +1458,54 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
                               (hipStream_t)stream);
 }
 
+int fpq_kv_cache_step(void* cache, int64_t batch, int64_t max_len, int64_t row_elems, int64_t quant_start,
+                      int64_t quant_stop, const void* new_k, const void* new_v, int64_t new_batch_pitch,
+                      int64_t new_token_pitch, int64_t new_start, int64_t n_new, int64_t group, int table_id,
+                      fpq_stream_t stream) {
+  if (batch < 0 || max_len < 0 || row_elems <= 0 || n_new < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (quant_start < 0 || quant_stop < quant_start || new_start < quant_stop || new_start + n_new > max_len)
+    return FPQ_ERR_ARG;
+  if (group != 8 && group != 16 && group != 32 && group != 64 && group != 128 && group != 256 && group != 512)
+    return FPQ_ERR_SHAPE;                      // rows of 8 * {1..64} halves, owned by 1..64 lanes
+  if (row_elems % group != 0 || batch > 65535) return FPQ_ERR_SHAPE;
+  if (new_batch_pitch % 8 != 0 || new_token_pitch % 8 != 0 || new_token_pitch < 0 || new_batch_pitch < 0) return FPQ_ERR_SHAPE;
+  const int64_t n_quant = quant_stop - quant_start;
+  if (batch == 0 || (n_quant == 0 && n_new == 0)) return FPQ_OK;
+  if (!cache || (n_new > 0 && (!new_k || !new_v))) return FPQ_ERR_ARG;
+  if ((((uintptr_t)cache | (uintptr_t)new_k | (uintptr_t)new_v) & 15) != 0) return FPQ_ERR_ARG;
+  const Lut16Host& h = lut16_host(table_id, table_id);
+  if (!h.tab_valid) return FPQ_ERR_TABLE;
+  constexpr int U = 2;
+  KvStepArgs k;
+  k.cache = (u32x4*)cache;
+  k.row_vec = (int)(row_elems / 8);
+  k.slab_vec = max_len * k.row_vec;
+  k.batch = (int)batch;
+  k.q_first_vec = quant_start * k.row_vec;
+  k.q_vecs = n_quant * k.row_vec;
+  const int64_t q_tiles = (k.q_vecs + kBlock * U - 1) / (kBlock * U);
+  k.src[0] = (const uint16_t*)new_k;
+  k.src[1] = (const uint16_t*)new_v;
+  k.src_batch_pitch = new_batch_pitch;
+  k.src_token_pitch = new_token_pitch;
+  k.new_first_vec = new_start * k.row_vec;
+  k.new_vecs = n_new * k.row_vec;
+  const int64_t c_tiles = (k.new_vecs + kBlock * U - 1) / (kBlock * U);
+  if (q_tiles + c_tiles > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  k.q_tiles = (int)q_tiles;
+  const dim3 grid((unsigned)(q_tiles + c_tiles), (unsigned)batch, 2);
+  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  hipStream_t st = (hipStream_t)stream;
+#define FPQ_KV_CASE(L) \
+  case L: hipLaunchKernelGGL((kv16_step_kernel<L, U>), grid, dim3(kBlock), lds, st, k, h.args, h.tab); break;
+  switch ((int)(group / 8)) {
+    FPQ_KV_CASE(1) FPQ_KV_CASE(2) FPQ_KV_CASE(4) FPQ_KV_CASE(8) FPQ_KV_CASE(16) FPQ_KV_CASE(32) FPQ_KV_CASE(64)
+  }
+#undef FPQ_KV_CASE
+  return check_launch();
+}
+
 int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols, int table_id, int in_dtype,
                           int clamp3, fpq_stream_t stream) {
   if (rows < 0 || cols < 0) return FPQ_ERR_ARG;

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import quant_utils as qu
+from . import ops, quant_utils as qu
 
 
 def quantize_kv(t: torch.Tensor, kv_bit: int) -> torch.Tensor:
@@ -65,22 +65,33 @@ class IncrementalKVCache:
         assert kv_bit in (4, 6)
         assert kv_bit == 6 or (heads * head_dim) % 128 == 0
         self.kv_bit = kv_bit
-        self.k = torch.empty(batch, max_len, heads, head_dim, dtype=dtype, device=device)
-        self.v = torch.empty_like(self.k)
+        self.kv = torch.empty(2, batch, max_len, heads, head_dim, dtype=dtype, device=device)   # K and V in one slab
+        self.k, self.v = self.kv[0], self.kv[1]
         self.len = 0
-        self._pending = None        # (start, stop, quantized k, quantized v) of the previous step's entries
+        self._prev = 0              # entries [_prev, len) were appended by the last step and are still unquantized
+        # one launch per step (fpq_kv_cache_step) when the rows fit the fused kernels' lanes
+        group = head_dim if kv_bit == 6 else 128
+        self._group = group if (dtype == torch.float16 and group in (8, 16, 32, 64, 128, 256, 512)) else None
 
     @torch.no_grad()
     def append(self, k: torch.Tensor, v: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """k, v: [B, n, H, c] (views of a fused qkv output are fine).  Returns the K / V attention runs on at this
+        step: everything older than the previous step's entries as quantized before, the previous step's entries
+        quantized now, the new ones as they are - what the reference's quantize-then-concatenate produces."""
         n = k.shape[1]
         assert self.len + n <= self.k.shape[1], "IncrementalKVCache: max_len exceeded"
-        if self._pending is not None:             # what the reference's quantize-the-cache does NEW work on
-            a, b, qk, qv = self._pending
-            self.k[:, a:b].copy_(qk)
-            self.v[:, a:b].copy_(qv)
-        self.k[:, self.len:self.len + n].copy_(k)
-        self.v[:, self.len:self.len + n].copy_(v)
-        kc, vc = k.contiguous(), v.contiguous()
-        self._pending = (self.len, self.len + n, quantize_kv(kc, self.kv_bit), quantize_kv(vc, self.kv_bit))
+        fused = (self._group is not None and k.dtype == torch.float16 and v.dtype == torch.float16
+                 and k.stride() == v.stride() and k.stride(3) == 1 and k.stride(2) == k.shape[3]
+                 and k.stride(0) % 8 == 0 and k.stride(1) % 8 == 0 and k.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0)
+        if fused:
+            ops.kv_cache_step(self.kv, self._prev, self.len, k, v, self.len, self._group, "e2m3" if self.kv_bit == 6 else "e2m1")
+        else:
+            if self.len > self._prev:             # what the reference's quantize-the-cache does NEW work on
+                a, b = self._prev, self.len
+                self.k[:, a:b].copy_(quantize_kv(self.k[:, a:b].contiguous(), self.kv_bit))
+                self.v[:, a:b].copy_(quantize_kv(self.v[:, a:b].contiguous(), self.kv_bit))
+            self.k[:, self.len:self.len + n].copy_(k)
+            self.v[:, self.len:self.len + n].copy_(v)
+        self._prev = self.len
         self.len += n
         return self.k[:, :self.len], self.v[:, :self.len]

@@ -68,6 +68,30 @@ def quant_rows(x: torch.Tensor, table: str, cols: int, out_dtype: Optional[torch
     return out
 
 
+def kv_cache_step(cache: torch.Tensor, quant_start: int, quant_stop: int, k: torch.Tensor, v: torch.Tensor,
+                  new_start: int, group: int, table: str) -> None:
+    """fpq_kv_cache_step: quantize tokens [quant_start, quant_stop) of the fp16 cache [2, B, max_len, H, c] in place
+    and copy the new k / v [B, n, H, c] (rows contiguous, any batch / token stride) to tokens new_start.."""
+    require_gpu(cache, "kv_cache_step")
+    if cache.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
+        raise RuntimeError("kv_cache_step: cache, k and v must be float16")
+    if cache.dim() != 5 or cache.shape[0] != 2 or not cache.is_contiguous():
+        raise RuntimeError("kv_cache_step: cache must be a contiguous [2, B, max_len, H, c] tensor")
+    _, B, max_len, H, c = cache.shape
+    if k.shape != v.shape or k.dim() != 4 or k.shape[0] != B or tuple(k.shape[2:]) != (H, c):
+        raise RuntimeError(f"kv_cache_step: k / v must be [B, n, H, c] = [{B}, n, {H}, {c}], got {tuple(k.shape)} / {tuple(v.shape)}")
+    n = k.shape[1]
+    for t in (k, v):
+        if n and (t.stride(3) != 1 or t.stride(2) != c):
+            raise RuntimeError("kv_cache_step: the (H, c) rows of k / v must be contiguous")
+    if n and (k.stride() != v.stride()):
+        raise RuntimeError("kv_cache_step: k and v must share their strides")
+    with torch.cuda.device(cache.device):
+        check(lib().fpq_kv_cache_step(cache.data_ptr(), B, max_len, H * c, quant_start, quant_stop, k.data_ptr(),
+                                      v.data_ptr(), k.stride(0) if n else 0, k.stride(1) if n else 0, new_start, n, group,
+                                      TABLE_IDS[table], stream_ptr(cache.device)), "fpq_kv_cache_step")
+
+
 def quant_rows_argmin(x: torch.Tensor, table: str, cols: int, clamp3: bool) -> torch.Tensor:
     """The reference's pure-torch quantizers (argmin lookup, float32 result) in one launch."""
     require_gpu(x, "quant_rows_argmin")

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 110 /* 0.1.1 */
+#define FPQ_VERSION 111 /* 0.1.1 + fpq_kv_cache_step */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -103,6 +103,24 @@ int fpq_quant_nearest_builtin(const float* x, float* z, int64_t n, int table_id,
  * table_id must be one of the symmetric tables (E2M1, E1M2, E3M0, E2M3, E3M2). */
 int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int table_id, int in_dtype,
                    int out_dtype, fpq_stream_t stream);
+
+/* One step of an incrementally maintained KV cache.  The reference
+ * (SelfAttention.forward, tr/basic_var.py:186-209) re-quantizes the WHOLE cached K and V at every
+ * step before concatenating the new k / v; since the quantizer returns its own output unchanged
+ * (tests/test_kv_idempotence.py), only the entries appended by the previous step change.  This
+ * call does both halves of a step in one launch:
+ *   - fake-quantizes tokens [quant_start, quant_stop) of K and V in place, rows of `group`
+ *     consecutive halves sharing one scale (64 = fp6_quant_e2m3_per_token_cuda on head_dim 64,
+ *     tr/quant_utils.py:503-517; 128 = fp_quant_e2_per_group_cuda, :313-330), and
+ *   - copies the new rows new_k / new_v [batch, n_new, row_elems] to tokens
+ *     [new_start, new_start + n_new); their rows must be contiguous, batch and token pitch (in
+ *     elements, multiples of 8) are free - views of a fused qkv projection need no copy.
+ * cache: fp16 [2 (K, V), batch, max_len, row_elems], 16-byte aligned like new_k / new_v.
+ * Requires quant_stop <= new_start and new_start + n_new <= max_len. */
+int fpq_kv_cache_step(void* cache, int64_t batch, int64_t max_len, int64_t row_elems, int64_t quant_start,
+                      int64_t quant_stop, const void* new_k, const void* new_v, int64_t new_batch_pitch,
+                      int64_t new_token_pitch, int64_t new_start, int64_t n_new, int64_t group, int table_id,
+                      fpq_stream_t stream);
 
 /* The reference's pure-torch quantizers ("CPU path", also what QuantizedLinear uses on
  * the GPU for per_channel / per_token FP4, tr/quant_utils.py:699-704,796-807):

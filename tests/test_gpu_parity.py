@@ -792,10 +792,13 @@ def test_adaln_rotate_quant_fused(dev, C, L, x_dtype):
     assert float((_ulp_diff_f16(h3.cpu(), h3_ref.cpu()) > 0).float().mean()) < 2e-3
 
 
+@pytest.mark.parametrize("source", ("qkv_view", "separate", "unaligned"))
 @pytest.mark.parametrize("kv_bit", (6, 4))
-def test_incremental_kv_equals_requantize_everything(dev, kv_bit):
-    """10 scale steps of VAR's KV cache: quantizing each entry once (IncrementalKVCache) reproduces the
-    reference's re-quantize-the-whole-cache loop bit for bit (see tests/test_kv_idempotence.py)."""
+def test_incremental_kv_equals_requantize_everything(dev, kv_bit, source):
+    """10 scale steps of VAR's KV cache: quantizing each entry once (IncrementalKVCache, one fpq_kv_cache_step launch
+    per step) reproduces the reference's re-quantize-the-whole-cache loop bit for bit (see
+    tests/test_kv_idempotence.py) - with k / v as views of a fused qkv output (the model's case), as separate
+    tensors, and through the multi-launch path taken when the views are not 16-byte aligned."""
     from fpqvar_amd import kv_cache as kv
     g = torch.Generator().manual_seed(91)
     B, H, c = 6, 30, 64
@@ -805,10 +808,40 @@ def test_incremental_kv_equals_requantize_everything(dev, kv_bit):
     for pn in patch:
         k = torch.nn.functional.normalize(torch.randn(B, pn * pn, H, c, generator=g), dim=-1).half().to(dev)
         v = torch.randn(B, pn * pn, H, c, generator=g).half().to(dev)
+        if source == "qkv_view":
+            qkv = torch.stack((torch.zeros_like(k), k, v), dim=2)          # [B, L, 3, H, c] as mat_qkv's output is viewed
+            k_in, v_in = qkv[:, :, 1], qkv[:, :, 2]
+            assert not k_in.is_contiguous() or pn == 1
+        elif source == "unaligned":
+            buf = torch.zeros(2, B, pn * pn, H * c + 4, dtype=torch.float16, device=dev)
+            buf[..., 4:] = torch.stack((k, v)).view(2, B, pn * pn, H * c)
+            k_in, v_in = buf[0, :, :, 4:].view(B, pn * pn, H, c), buf[1, :, :, 4:].view(B, pn * pn, H, c)
+            assert k_in.data_ptr() % 16 != 0
+        else:
+            k_in, v_in = k, v
         ck, cv = kv.update_kv_cache(ck, cv, k, v, True, kv_bit, 1)       # the reference's O(L^2) loop
-        ik, iv = inc.append(k, v)
+        ik, iv = inc.append(k_in, v_in)
         assert_bits_equal(ik.contiguous(), ck, f"K step pn={pn}")
         assert_bits_equal(iv.contiguous(), cv, f"V step pn={pn}")
+
+
+def test_kv_cache_step_argument_checks(dev):
+    from fpqvar_amd import ops
+    cache = torch.zeros(2, 2, 8, 2, 64, dtype=torch.float16, device=dev)
+    k = torch.randn(2, 3, 2, 64, device=dev).half()
+    with pytest.raises(RuntimeError):
+        ops.kv_cache_step(cache, 0, 0, k, k, 6, 64, "e2m3")              # 6 + 3 > max_len
+    with pytest.raises(RuntimeError):
+        ops.kv_cache_step(cache, 0, 4, k, k, 3, 64, "e2m3")              # would overwrite rows being quantized
+    with pytest.raises(RuntimeError):
+        ops.kv_cache_step(cache, 0, 0, k, k, 0, 48, "e2m3")              # rows of 48 halves have no lane mapping
+    with pytest.raises(RuntimeError):
+        ops.kv_cache_step(cache, 0, 0, k.float(), k.float(), 0, 64, "e2m3")
+    ops.kv_cache_step(cache, 0, 0, k, k, 0, 64, "e2m3")                    # copy only
+    assert torch.equal(cache[0, :, :3], k) and torch.equal(cache[1, :, :3], k) and not cache[:, :, 3:].any()
+    ops.kv_cache_step(cache, 0, 3, k[:, :0], k[:, :0], 3, 64, "e2m3")      # quantize only
+    from fpqvar_amd import quant_utils as qu
+    assert torch.equal(cache[0, :, :3], qu.fp6_quant_e2m3_per_token_cuda(k, 6))
 
 
 # ------------------------------------------------------------------ F2: hardware FP4 codes + MFMA GEMM
