@@ -23,6 +23,11 @@ _DTYPES = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
 _lib: Optional[ctypes.CDLL] = None
 
 _c = ctypes
+class GemmEpilogue(_c.Structure):
+    """fpq_gemm_epilogue_t (include/fpq.h)."""
+    _fields_ = [("gate", _c.c_void_p), ("residual", _c.c_void_p), ("rows_per_gate", _c.c_int64)]
+
+
 _SIGS = {
     "fpq_version": (_c.c_int, []),
     "fpq_strerror": (_c.c_char_p, [_c.c_int]),
@@ -77,6 +82,12 @@ _SIGS = {
                                             _c.c_void_p]),
     "fpq_gemm_fp4_mx": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                     _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    "fpq_gemm_fp4_mx_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                       _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_gemm_fp8_rows_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                         _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_gemm_fp6_rows_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                         _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_dequant_rows_codes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                            _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }

@@ -36,12 +36,45 @@ __device__ __forceinline__ int gemm_lds_off(int row, int kb) {
 
 // Workgroup = WR x WC wavefronts, each owning MT x NT MFMA tiles (16x16): tile BM = 16*MT*WR tokens by
 // BN = 16*NT*WC outputs.
+// Optional tail of every GEMM epilogue below: out = residual + y * gate[t / rows_per_gate, :] with y the fp16 Linear
+// output, each operation in fp16 with one rounding - what torch computes for the AdaLN blocks'
+// `x = x + attn(...).mul_(gamma1)` / `x + ffn(...).mul(gamma2)` (tr/basic_var.py:264,267; gamma is [B, 1, C]).
+struct GemmEpi {
+  const _Float16* gate;    // [ceil(T / rows_per_gate), O] or nullptr
+  const _Float16* resid;   // [T, O] or nullptr; may alias out
+  int rows_per_gate;
+};
+typedef _Float16 fpq_h2_t __attribute__((ext_vector_type(2)));
+
+// (macros, not functions: the kernels carry different target attributes and a callee is only inlined into a kernel
+// with the same ones)
+#define FPQ_GEMM_EPI_VEC(y, e, t, o, O)                                                                  \
+  do {                                                                                                   \
+    if ((e).gate) {                                                                                      \
+      const u32x4 g_ = *(const u32x4*)((e).gate + (int64_t)((t) / (e).rows_per_gate) * (O) + (o));       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
+          (y)[i_] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(fpq_h2_t, (uint32_t)(y)[i_]) *      \
+                                                     __builtin_bit_cast(fpq_h2_t, (uint32_t)g_[i_]));    \
+    }                                                                                                    \
+    if ((e).resid) {                                                                                     \
+      const u32x4 r_ = *(const u32x4*)((e).resid + (int64_t)(t) * (O) + (o));                            \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
+          (y)[i_] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(fpq_h2_t, (uint32_t)r_[i_]) +       \
+                                                     __builtin_bit_cast(fpq_h2_t, (uint32_t)(y)[i_]));   \
+    }                                                                                                    \
+  } while (0)
+#define FPQ_GEMM_EPI_ONE(y, e, t, o, O)                                                                  \
+  do {                                                                                                   \
+    if ((e).gate) (y) = (y) * (e).gate[(int64_t)((t) / (e).rows_per_gate) * (O) + (o)];                  \
+    if ((e).resid) (y) = (e).resid[(int64_t)(t) * (O) + (o)] + (y);                                      \
+  } while (0)
+
 template <typename Tsw, int MT, int NT, int WR, int WC>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_fp4_kernel(const uint8_t* __restrict__ A,
                                                                const _Float16* __restrict__ sa,
                                                                const uint8_t* __restrict__ W, const Tsw* __restrict__ sw,
                                                                const _Float16* __restrict__ bias,
-                                                               _Float16* __restrict__ out, int T, int O, int C) {
+                                                               _Float16* out, int T, int O, int C, GemmEpi epi) {
   constexpr int BM = 16 * MT * WR, BN = 16 * NT * WC, NTHR = 64 * WR * WC;
   constexpr int ABYTES = BM * 64, BBYTES = BN * 64, STAGE = ABYTES + BBYTES;
   constexpr int HA = (BM * 4 + NTHR - 1) / NTHR, HB = (BN * 4 + NTHR - 1) / NTHR;   // staging chunks per thread
@@ -182,10 +215,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_fp4_kernel(const uint8_t* _
       const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
       const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
       if (t < T && o + 8 <= O) {
-        *(u32x4*)(out + (int64_t)t * O + o) = *(const u32x4*)(lo + r * LDW + cpc * 8);
+        u32x4 y = *(const u32x4*)(lo + r * LDW + cpc * 8);
+        FPQ_GEMM_EPI_VEC(y, epi, t, o, O);
+        *(u32x4*)(out + (int64_t)t * O + o) = y;
       } else if (t < T) {
         for (int e = 0; e < 8; ++e)
-          if (o + e < O) out[(int64_t)t * O + o + e] = lo[r * LDW + cpc * 8 + e];
+          if (o + e < O) {
+            _Float16 y = lo[r * LDW + cpc * 8 + e];
+            FPQ_GEMM_EPI_ONE(y, epi, t, o + e, O);
+            out[(int64_t)t * O + o + e] = y;
+          }
       }
     }
   }
@@ -246,7 +285,7 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
                                                               const _Float16* __restrict__ sa,
                                                               const uint8_t* __restrict__ W, const Tsw* __restrict__ sw,
                                                               const _Float16* __restrict__ bias,
-                                                              _Float16* __restrict__ out, int T, int O, int C) {
+                                                              _Float16* out, int T, int O, int C, GemmEpi epi) {
   constexpr int WR = 2, WC = 2, BM = 16 * MT * WR, BN = 16 * NT * WC, NTHR = 256;
   constexpr int ABLK = BM / 16, BBLK = BN / 16, NBLK = ABLK + BBLK, STAGE = NBLK * 1024;
   static_assert(NBLK % 4 == 0, "blocks are dealt round-robin to the four wavefronts");
@@ -393,10 +432,16 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
       const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
       const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
       if (t < T && o + 8 <= O) {
-        *(u32x4*)(out + (int64_t)t * O + o) = *(const u32x4*)(lo + r * LDW + cpc * 8);
+        u32x4 y = *(const u32x4*)(lo + r * LDW + cpc * 8);
+        FPQ_GEMM_EPI_VEC(y, epi, t, o, O);
+        *(u32x4*)(out + (int64_t)t * O + o) = y;
       } else if (t < T) {
         for (int e = 0; e < 8; ++e)
-          if (o + e < O) out[(int64_t)t * O + o + e] = lo[r * LDW + cpc * 8 + e];
+          if (o + e < O) {
+            _Float16 y = lo[r * LDW + cpc * 8 + e];
+            FPQ_GEMM_EPI_ONE(y, epi, t, o + e, O);
+            out[(int64_t)t * O + o + e] = y;
+          }
       }
     }
   }

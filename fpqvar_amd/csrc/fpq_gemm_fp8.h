@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
                                                                        const uint8_t* __restrict__ W,
                                                                        const Tsw* __restrict__ sw,
                                                                        const _Float16* __restrict__ bias,
-                                                                       _Float16* __restrict__ out, int T, int O, int C) {
+                                                                       _Float16* out, int T, int O, int C, GemmEpi epi) {
   constexpr int WR = 2, WC = 2, BM = 16 * MT * WR, BN = 16 * NT * WC;
   constexpr int ABLK = BM / 16, BBLK = BN / 16, NBLK = ABLK + BBLK, STAGE = NBLK * 2048;
   constexpr int NPIECE = 2 * NBLK;                 // 1 KiB LDS-DMA pieces per stage (8 rows each)
@@ -129,10 +129,16 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
       const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
       const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
       if (t < T && o + 8 <= O) {
-        *(u32x4*)(out + (int64_t)t * O + o) = *(const u32x4*)(lo + r * LDW + cpc * 8);
+        u32x4 y = *(const u32x4*)(lo + r * LDW + cpc * 8);
+        FPQ_GEMM_EPI_VEC(y, epi, t, o, O);
+        *(u32x4*)(out + (int64_t)t * O + o) = y;
       } else if (t < T) {
         for (int e = 0; e < 8; ++e)
-          if (o + e < O) out[(int64_t)t * O + o + e] = lo[r * LDW + cpc * 8 + e];
+          if (o + e < O) {
+            _Float16 y = lo[r * LDW + cpc * 8 + e];
+            FPQ_GEMM_EPI_ONE(y, epi, t, o + e, O);
+            out[(int64_t)t * O + o + e] = y;
+          }
       }
     }
   }

@@ -1700,7 +1700,44 @@ int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t
 int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
                     int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
                     fpq_stream_t stream) {
+  return fpq_gemm_fp4_mx_ex(a_codes, a_scales, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k, nullptr, stream);
+}
+
+int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream) {
+  return fpq_gemm_fp6_rows_ex(a_codes, a_scales, a_scale_dtype, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k,
+                              nullptr, stream);
+}
+
+int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream) {
+  return fpq_gemm_fp8_rows_ex(a_codes, a_scales, a_scale_dtype, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k,
+                              nullptr, stream);
+}
+
+// validates an optional epilogue descriptor and turns it into the kernels' form
+static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi* epi) {
+  epi->gate = nullptr;
+  epi->resid = nullptr;
+  epi->rows_per_gate = 1;
+  if (!ep) return FPQ_OK;
+  if (ep->gate && (ep->rows_per_gate < 1 || ep->rows_per_gate > 0x7FFFFFFF)) return FPQ_ERR_ARG;
+  if ((((uintptr_t)ep->gate | (uintptr_t)ep->residual) & 15) != 0) return FPQ_ERR_ARG;
+  epi->gate = (const _Float16*)ep->gate;
+  epi->resid = (const _Float16*)ep->residual;
+  if (ep->gate) epi->rows_per_gate = (int)ep->rows_per_gate;
+  (void)tokens;
+  return FPQ_OK;
+}
+
+int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  GemmEpi epi;
+  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
   if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
   if (k % 128 != 0 || k > 128 * 64 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
   if (tokens == 0 || outs == 0) return FPQ_OK;
@@ -1722,11 +1759,11 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
     if (w_scale_dtype == FPQ_F16)                                                                                    \
       hipLaunchKernelGGL((gemm_fp4_kernel<_Float16, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),        \
                          Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,   \
-                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                     \
+                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                     \
     else                                                                                                             \
       hipLaunchKernelGGL((gemm_fp4_kernel<float, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),           \
                          Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,      \
-                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                     \
+                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                     \
   } while (0)
 #define FPQ_GEMM_GLDS(MT, NT)                                                                                        \
   do {                                                                                                               \
@@ -1739,11 +1776,11 @@ int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t*
       if (w_scale_dtype == FPQ_F16)                                                                                  \
         hipLaunchKernelGGL((gemm_fp4_glds_kernel<_Float16, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,      \
                            a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,                   \
-                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                   \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
       else                                                                                                           \
         hipLaunchKernelGGL((gemm_fp4_glds_kernel<float, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,         \
                            a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,                      \
-                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k);                   \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
       return check_launch();                                                                                         \
     }                                                                                                                \
   } while (0)
@@ -1881,10 +1918,12 @@ int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_
   return check_launch();
 }
 
-int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
-                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
-                      int64_t k, fpq_stream_t stream) {
+int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  GemmEpi epi;
+  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
   if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
   if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
     return FPQ_ERR_DTYPE;
@@ -1902,7 +1941,7 @@ int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_
     if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
     hipLaunchKernelGGL((gemm_fp6_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
                        a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
-                       (_Float16*)out, (int)tokens, (int)outs, (int)k);                                              \
+                       (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                                              \
   } while (0)
 #define FPQ_GO6T(MT, NT)                                                                                             \
   do {                                                                                                               \
@@ -1918,10 +1957,12 @@ int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_
   return check_launch();
 }
 
-int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
-                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
-                      int64_t k, fpq_stream_t stream) {
+int fpq_gemm_fp8_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  GemmEpi epi;
+  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
   if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
   if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
     return FPQ_ERR_DTYPE;
@@ -1939,7 +1980,7 @@ int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_
     if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
     hipLaunchKernelGGL((gemm_fp8_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
                        a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
-                       (_Float16*)out, (int)tokens, (int)outs, (int)k);                                              \
+                       (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                                              \
   } while (0)
 #define FPQ_GO8T(MT, NT)                                                                                             \
   do {                                                                                                               \

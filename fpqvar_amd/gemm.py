@@ -10,9 +10,37 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import check, dtype_id, lib, require_gpu, stream_ptr
+import ctypes
+
+from ._lib import GemmEpilogue, check, dtype_id, lib, require_gpu, stream_ptr
 
 E2M1_LEVELS = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
+
+
+def _epilogue(name: str, tokens: int, outs: int, gate: Optional[torch.Tensor], residual: Optional[torch.Tensor],
+              out: Optional[torch.Tensor], device):
+    """The GEMMs' optional fused tail `residual + y * gate` (fpq_gemm_epilogue_t): gate is gamma of the AdaLN block,
+    [B, 1, outs] or [B, outs] fp16 with tokens % B == 0; residual is [..., outs] fp16 with `tokens` rows.
+    Returns (pointer or None, objects to keep alive until the launch, output tensor)."""
+    if gate is None and residual is None:
+        return None, (), torch.empty((tokens, outs), dtype=torch.float16, device=device) if out is None else out
+    ep, keep = GemmEpilogue(None, None, 1), []
+    if gate is not None:
+        g = gate.reshape(-1, outs)
+        if g.dtype != torch.float16 or g.shape[0] == 0 or tokens % g.shape[0] != 0:
+            raise RuntimeError(f"{name}: gate must be float16 [B, outs] with tokens % B == 0, got {tuple(gate.shape)} {gate.dtype}")
+        g = g.contiguous()
+        ep.gate, ep.rows_per_gate = g.data_ptr(), max(tokens // g.shape[0], 1)
+        keep.append(g)
+    if residual is not None:
+        r = residual.reshape(-1, outs)
+        if r.dtype != torch.float16 or r.shape[0] != tokens:
+            raise RuntimeError(f"{name}: residual must be float16 with {tokens} rows of {outs}, got {tuple(residual.shape)} {residual.dtype}")
+        r = r.contiguous()
+        ep.residual = r.data_ptr()
+        keep.append(r)
+    keep.append(ep)
+    return ctypes.byref(ep), keep, torch.empty((tokens, outs), dtype=torch.float16, device=device) if out is None else out
 
 
 def quantize_mx(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -42,18 +70,22 @@ def dequantize_mx(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
 
 
 def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
-               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores."""
+               bias: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores; with gate / residual the
+    AdaLN block's `residual + y.mul(gate)` (tr/basic_var.py:264) is applied in the epilogue, bit-identical to the two
+    torch ops on the plain result."""
     require_gpu(a_codes, "linear_fp4")
     tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
     if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16:
         raise RuntimeError("linear_fp4: operand shapes / activation scale dtype mismatch")
-    out = torch.empty((tokens, outs), dtype=torch.float16, device=a_codes.device)
+    ep, keep, out = _epilogue("linear_fp4", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
     with torch.cuda.device(a_codes.device):
-        check(lib().fpq_gemm_fp4_mx(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
-                                    dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
-                                    tokens, outs, k, stream_ptr(a_codes.device)), "fpq_gemm_fp4_mx")
+        check(lib().fpq_gemm_fp4_mx_ex(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
+                                       dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
+                                       tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp4_mx_ex")
+    del keep
     return out
 
 
@@ -80,17 +112,18 @@ class FP4Linear(torch.nn.Module):
         return cls(codes, scales, bias, module.in_features, module.out_features)
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, gate=None, residual=None):
+        """gate / residual: the AdaLN block's `residual + y.mul(gate)` fused into the GEMM (see linear_fp4)."""
         lead = x.shape[:-1]
         a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features))
-        y = linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)
+        y = linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual)
         return y.view(*lead, self.out_features)
 
     @torch.no_grad()
-    def forward_operands(self, a_codes: torch.Tensor, a_scales: torch.Tensor) -> torch.Tensor:
+    def forward_operands(self, a_codes: torch.Tensor, a_scales: torch.Tensor, gate=None, residual=None) -> torch.Tensor:
         """The same product for an activation that already is in operand form - what the fused producers
         `rotation.rotate_quant_mx` / `rotation.adaln_rotate_quant_mx` emit: fp16 [tokens, out_features]."""
-        return linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)
+        return linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual)
 
 
 # ---- per-token activations x per-channel weights (W6A6): one scale per row, FP8-coded levels ---------------------
@@ -123,18 +156,21 @@ def dequantize_fp8(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
 
 
 def linear_fp8(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
-               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP8 matrix cores (row-scaled operands)."""
+               bias: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP8 matrix cores (row-scaled operands); optional
+    fused `residual + y.mul(gate)` as in linear_fp4."""
     require_gpu(a_codes, "linear_fp8")
     tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1]
     if w_codes.shape[1] != k:
         raise RuntimeError("linear_fp8: operand shapes mismatch")
-    out = torch.empty((tokens, outs), dtype=torch.float16, device=a_codes.device)
+    ep, keep, out = _epilogue("linear_fp8", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
     with torch.cuda.device(a_codes.device):
-        check(lib().fpq_gemm_fp8_rows(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
-                                      w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
-                                      out.data_ptr(), tokens, outs, k, stream_ptr(a_codes.device)), "fpq_gemm_fp8_rows")
+        check(lib().fpq_gemm_fp8_rows_ex(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
+                                         w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
+                                         out.data_ptr(), tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp8_rows_ex")
+    del keep
     return out
 
 
@@ -158,10 +194,10 @@ class FP8Linear(torch.nn.Module):
         return cls(codes, scales, bias, module.in_features, module.out_features, act_fp_type)
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, gate=None, residual=None):
         lead = x.shape[:-1]
         a_codes, a_scales = quantize_fp8(x.to(torch.float16).reshape(-1, self.in_features), self.act_table)
-        return linear_fp8(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)
+        return linear_fp8(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual).view(*lead, self.out_features)
 
 
 # ---- the same with 6-bit packed operands (FP6 E2M3 on both sides: the W6A6 run configuration) ---------------------
@@ -198,18 +234,21 @@ def dequantize_fp6(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
 
 
 def linear_fp6(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
-               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP6 matrix-core form (row-scaled operands)."""
+               bias: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP6 matrix cores (row-scaled operands); optional
+    fused `residual + y.mul(gate)` as in linear_fp4."""
     require_gpu(a_codes, "linear_fp6")
     tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 4 // 3
     if w_codes.shape[1] != a_codes.shape[1]:
         raise RuntimeError("linear_fp6: operand shapes mismatch")
-    out = torch.empty((tokens, outs), dtype=torch.float16, device=a_codes.device)
+    ep, keep, out = _epilogue("linear_fp6", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
     with torch.cuda.device(a_codes.device):
-        check(lib().fpq_gemm_fp6_rows(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
-                                      w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
-                                      out.data_ptr(), tokens, outs, k, stream_ptr(a_codes.device)), "fpq_gemm_fp6_rows")
+        check(lib().fpq_gemm_fp6_rows_ex(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
+                                         w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
+                                         out.data_ptr(), tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp6_rows_ex")
+    del keep
     return out
 
 
@@ -231,7 +270,7 @@ class FP6Linear(torch.nn.Module):
         return cls(codes, scales, bias, module.in_features, module.out_features)
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, gate=None, residual=None):
         lead = x.shape[:-1]
         a_codes, a_scales = quantize_fp6(x.to(torch.float16).reshape(-1, self.in_features))
-        return linear_fp6(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)
+        return linear_fp6(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual).view(*lead, self.out_features)

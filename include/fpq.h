@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 111 /* 0.1.1 + fpq_kv_cache_step */
+#define FPQ_VERSION 112 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -299,6 +299,25 @@ int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_
 int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
                       const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
                       int64_t k, fpq_stream_t stream);
+
+/* The three GEMMs with an optional fused tail, for the AdaLN blocks' `x = x + attn(...).mul_(gamma1)` /
+ * `x + ffn(...).mul(gamma2)` (tr/basic_var.py:264,267): out = residual + y * gate[t / rows_per_gate, :], y being the
+ * fp16 result of the plain call, each operation in fp16 with one rounding (bit-identical to the two torch ops on y).
+ * Either pointer may be NULL; `residual` may be `out` itself; both 16-byte aligned.  epilogue == NULL: the plain call. */
+typedef struct fpq_gemm_epilogue {
+  const void* gate;      /* fp16 [ceil(tokens / rows_per_gate), outs] or NULL (gamma viewed as [B, C]) */
+  const void* residual;  /* fp16 [tokens, outs] or NULL */
+  int64_t rows_per_gate; /* consecutive token rows sharing a gate row (tokens per batch entry), >= 1 */
+} fpq_gemm_epilogue_t;
+int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
+int fpq_gemm_fp8_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
+int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
 
 /* Inverse of fpq_quant_rows_codes: out = (Tout)((float)table_dedup[code] * (float)scale). */
 int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, int64_t rows,

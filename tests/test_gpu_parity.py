@@ -1358,3 +1358,28 @@ def test_rccl_single_rank_group_paths(dev):
         assert total == 50 and abs(rate - 25.0) < 1e-9
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ("fp4", "fp6", "fp8"))
+@pytest.mark.parametrize("B,L,O,K", ((4, 75, 1920, 1920), (3, 1, 264, 256), (2, 333, 520, 128), (1, 7, 8, 128)))
+def test_gemm_fused_gate_residual_is_bitwise_the_two_torch_ops(dev, kind, B, L, O, K):
+    """linear_*(…, gate, residual) == residual + linear_*(…).mul(gate) bit for bit (tr/basic_var.py:264: the AdaLN
+    block's gated residual), for gate only, residual only, both, and the residual aliasing nothing / a view."""
+    from fpqvar_amd import gemm
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B * L, K, generator=g).half().to(dev)
+    w = (torch.randn(O, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(O, generator=g).half().to(dev)
+    gate = (torch.randn(B, 1, O, generator=g) * 0.5).half().to(dev)
+    resid = torch.randn(B, L, O, generator=g).half().to(dev)
+    quant, lin = {"fp4": (gemm.quantize_mx, gemm.linear_fp4), "fp6": (gemm.quantize_fp6, gemm.linear_fp6),
+                  "fp8": (gemm.quantize_fp8, gemm.linear_fp8)}[kind]
+    a, wq = quant(x), quant(w)
+    y = lin(*a, *wq, bias)
+    assert_bits_equal(lin(*a, *wq, bias, gate, resid).view(B, L, O), resid + y.view(B, L, O).mul(gate), f"{kind} gate+residual")
+    assert_bits_equal(lin(*a, *wq, bias, gate, None).view(B, L, O), y.view(B, L, O).mul(gate), f"{kind} gate only")
+    assert_bits_equal(lin(*a, *wq, bias, None, resid).view(B, L, O), resid + y.view(B, L, O), f"{kind} residual only")
+    with pytest.raises(RuntimeError):
+        lin(*a, *wq, bias, gate.float(), resid)
+    with pytest.raises(RuntimeError):
+        lin(*a, *wq, bias, gate, resid[:, :0])

@@ -128,8 +128,10 @@ def main():
             return gemm.linear_fp8(*rot.adaln_rotate_quant_token(t, sc, sh, "e2m3", smooth=sm, emit="fp8"), *fp4[name])
         return gemm.linear_fp4(*rot.adaln_rotate_quant_mx(t, sc, sh, smooth=sm), *fp4[name])
 
-    def q_proj(t2d):
-        return gemm.linear_fp6(*gemm.quantize_fp6(t2d), *fp4["proj"]) if W6 else gemm.linear_fp4(*gemm.quantize_mx(t2d), *fp4["proj"])
+    def q_proj(t2d, gate, resid):       # x + proj(a).mul(gamma1), gate and residual applied in the GEMM epilogue
+        if W6:
+            return gemm.linear_fp6(*gemm.quantize_fp6(t2d), *fp4["proj"], None, gate, resid)
+        return gemm.linear_fp4(*gemm.quantize_mx(t2d), *fp4["proj"], None, gate, resid)
     max_len = sum(p * p for p in PATCH_NUMS)
 
     def attend(q, kc, vc):                      # q [B,L,H,c]; kc, vc [B,Ltot,H,c] (flash layout, as the KV runs use)
@@ -207,10 +209,9 @@ def main():
                 kc, vc = caches[b].append(k, v)
                 a = attend(q, kc, vc)
                 if path == "F":
-                    a = Fn.linear(f_act(a), wq["proj"])
+                    x = x + Fn.linear(f_act(a), wq["proj"]).mul(g1)
                 else:
-                    a = q_proj(a.view(B * L, C)).view(B, L, C)
-                x = x + a.mul(g1)
+                    x = q_proj(a.view(B * L, C), g1, x).view(B, L, C)
                 if path == "F":
                     h = Fn.linear(f_producer(x, sc2, sh2, s_fc1), wq["fc1"])
                 else:
