@@ -659,6 +659,7 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 #include "fpq_gemm_fp4.h"
 #include "fpq_gemm_fp8.h"
 #include "fpq_gemm_fp6.h"
+#include "fpq_attention.h"
 
 // ---------------------------------------------------------------------------------
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
@@ -1456,6 +1457,40 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
   dual.nan_flag = nullptr;
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,
                               (hipStream_t)stream);
+}
+
+int fpq_attention_blhc(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t lq, int64_t lkv,
+                       int64_t heads, int64_t head_dim, int64_t q_batch_pitch, int64_t q_token_pitch,
+                       int64_t kv_batch_pitch, int64_t kv_token_pitch, float scale, fpq_stream_t stream) {
+  if (batch < 0 || lq < 0 || lkv < 0 || heads <= 0) return FPQ_ERR_ARG;
+  if (head_dim != 64) return FPQ_ERR_SHAPE;
+  if (batch == 0 || lq == 0) return FPQ_OK;
+  if (lkv == 0 || !(scale > 0.0f)) return FPQ_ERR_ARG;            // softmax over nothing
+  if (!q || !k || !v || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  if (q_batch_pitch % 8 != 0 || q_token_pitch % 8 != 0 || kv_batch_pitch % 8 != 0 || kv_token_pitch % 8 != 0)
+    return FPQ_ERR_SHAPE;
+  if (lq > 0x7FFFFFFF || lkv > 0x7FFFFFFF || batch * heads > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  AttnArgs a;
+  a.q = (const uint16_t*)q;
+  a.k = (const uint16_t*)k;
+  a.v = (const uint16_t*)v;
+  a.out = (uint16_t*)out;
+  a.q_batch = q_batch_pitch;
+  a.q_token = q_token_pitch;
+  a.kv_batch = kv_batch_pitch;
+  a.kv_token = kv_token_pitch;
+  a.batch = (int)batch;
+  a.heads = (int)heads;
+  a.lq = (int)lq;
+  a.lkv = (int)lkv;
+  a.q_tiles = (int)((lq + 127) / 128);
+  a.scale_log2e = scale * 1.4426950408889634f;
+  const int64_t groups = (batch * heads + 7) / 8;
+  const int64_t n_wg = groups * a.q_tiles * 8;
+  if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  hipLaunchKernelGGL(attn_fwd64_kernel, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch();
 }
 
 int fpq_kv_cache_step(void* cache, int64_t batch, int64_t max_len, int64_t row_elems, int64_t quant_start,

@@ -68,6 +68,35 @@ def quant_rows(x: torch.Tensor, table: str, cols: int, out_dtype: Optional[torch
     return out
 
 
+def attention_blhc(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """fpq_attention_blhc: softmax(q k^T * scale) v for fp16 q [B, Lq, H, 64], k / v [B, Lkv, H, 64] (views with
+    contiguous (H, 64) rows are taken as they are) -> [B, Lq, H, 64]; flash_attn_func(q, k, v, softmax_scale=scale)."""
+    require_gpu(q, "attention_blhc")
+    if q.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
+        raise RuntimeError("attention_blhc: q, k and v must be float16")
+    if q.dim() != 4 or k.dim() != 4 or k.shape != v.shape or q.shape[0] != k.shape[0] or q.shape[2:] != k.shape[2:]:
+        raise RuntimeError(f"attention_blhc: expected q [B, Lq, H, c] and k / v [B, Lkv, H, c], got {tuple(q.shape)} {tuple(k.shape)} {tuple(v.shape)}")
+    B, Lq, H, c = q.shape
+    Lkv = k.shape[1]
+    if c != 64:
+        raise RuntimeError("attention_blhc: head_dim must be 64")
+    if Lkv == 0 and Lq > 0 and B > 0:
+        raise RuntimeError("attention_blhc: no keys")
+
+    def rows_ok(t):
+        return t.shape[1] == 0 or t.shape[0] == 0 or (t.stride(3) == 1 and t.stride(2) == c and t.stride(0) % 8 == 0
+                                                      and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0)
+    q = q if rows_ok(q) else q.contiguous()
+    if not (rows_ok(k) and rows_ok(v) and k.stride() == v.stride()):
+        k, v = k.contiguous(), v.contiguous()
+    out = torch.empty((B, Lq, H, c), dtype=torch.float16, device=q.device)
+    with torch.cuda.device(q.device):
+        check(lib().fpq_attention_blhc(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, Lkv, H, c,
+                                       q.stride(0), q.stride(1), k.stride(0), k.stride(1), float(scale),
+                                       stream_ptr(q.device)), "fpq_attention_blhc")
+    return out
+
+
 def kv_cache_step(cache: torch.Tensor, quant_start: int, quant_stop: int, k: torch.Tensor, v: torch.Tensor,
                   new_start: int, group: int, table: str) -> None:
     """fpq_kv_cache_step: quantize tokens [quant_start, quant_stop) of the fp16 cache [2, B, max_len, H, c] in place

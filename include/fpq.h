@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 112 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex */
+#define FPQ_VERSION 113 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex, fpq_attention_blhc */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -103,6 +103,18 @@ int fpq_quant_nearest_builtin(const float* x, float* z, int64_t n, int table_id,
  * table_id must be one of the symmetric tables (E2M1, E1M2, E3M0, E2M3, E3M2). */
 int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int table_id, int in_dtype,
                    int out_dtype, fpq_stream_t stream);
+
+/* out = softmax(q k^T * scale) v per (batch, head) for head_dim 64, fp16, in the [B, L, H, c] layout the reference
+ * passes to flash_attn_func(q, k, v, softmax_scale=self.scale) in SelfAttention.forward (tr/basic_var.py:173,211) -
+ * the consumer of the KV cache; at inference there is no mask and no dropout (attn_bias is None with KV caching,
+ * :159).  q [B, lq, H, 64] and k / v [B, lkv, H, 64] may be views: rows of H * 64 halves contiguous, batch / token
+ * pitch in elements (multiples of 8) free (q out of the fused qkv output, k / v out of fpq_kv_cache_step's cache);
+ * out [B, lq, H, 64] contiguous; all 16-byte aligned.  fp32 scores and accumulation on the matrix cores, online
+ * softmax; agreement with a reference attention is to fp16 tolerance (P is rounded to fp16 before P V, as in flash
+ * attention), not bit-exact. */
+int fpq_attention_blhc(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t lq, int64_t lkv,
+                       int64_t heads, int64_t head_dim, int64_t q_batch_pitch, int64_t q_token_pitch,
+                       int64_t kv_batch_pitch, int64_t kv_token_pitch, float scale, fpq_stream_t stream);
 
 /* One step of an incrementally maintained KV cache.  The reference
  * (SelfAttention.forward, tr/basic_var.py:186-209) re-quantizes the WHOLE cached K and V at every

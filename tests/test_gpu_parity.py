@@ -1383,3 +1383,26 @@ def test_gemm_fused_gate_residual_is_bitwise_the_two_torch_ops(dev, kind, B, L, 
         lin(*a, *wq, bias, gate.float(), resid)
     with pytest.raises(RuntimeError):
         lin(*a, *wq, bias, gate, resid[:, :0])
+
+
+@pytest.mark.parametrize("B,H,Lq,Lkv", ((2, 3, 1, 1), (2, 5, 4, 5), (1, 30, 36, 91), (3, 2, 100, 255), (2, 4, 169, 424),
+                                        (1, 2, 256, 680), (1, 3, 130, 64), (2, 1, 33, 129), (1, 9, 7, 2240)))
+def test_attention_over_the_cache_matches_sdpa(dev, B, H, Lq, Lkv):
+    """fpq_attention_blhc vs an fp32 softmax(q k^T s) v reference on the same fp16 inputs, with q / k / v as the model
+    has them (q a view of the qkv output, k / v views of the KV-cache slab) and contiguous.  Tolerance: P is rounded to
+    fp16 before P V and the output to fp16, so |err| <= 2e-3 * max|v| is generous; typical 3e-4."""
+    from fpqvar_amd import ops
+    g = torch.Generator().manual_seed(Lq * 7 + Lkv)
+    qkv = torch.randn(B, Lq, 3, H, 64, generator=g).half().to(dev)
+    slab = torch.randn(2, B, Lkv + 5, H, 64, generator=g).half().to(dev)
+    q = torch.nn.functional.normalize(qkv[:, :, 0].float(), dim=-1).mul(8.0).half()      # VAR: l2-normalised q * learned scale
+    qkv[:, :, 0] = q
+    q_view, k_view, v_view = qkv[:, :, 0], slab[0, :, :Lkv], slab[1, :, :Lkv]
+    for scale in (1.0, 0.125):
+        ref = torch.nn.functional.scaled_dot_product_attention(q_view.transpose(1, 2).float(), k_view.transpose(1, 2).float(),
+                                                               v_view.transpose(1, 2).float(), scale=scale).transpose(1, 2)
+        for qq, kk, vv in ((q_view, k_view, v_view), (q_view.contiguous(), k_view.contiguous(), v_view.contiguous())):
+            out = ops.attention_blhc(qq, kk, vv, scale)
+            assert out.shape == (B, Lq, H, 64) and out.dtype == torch.float16
+            err = (out.float() - ref).abs().max().item()
+            assert err <= 2e-3 * float(v_view.abs().max()), (scale, err)

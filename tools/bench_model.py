@@ -10,7 +10,8 @@ Three ways to run everything around the attention core:
      quant_cuda.quant, dense fp16 GEMM with the block-diagonal Q, fp16 Linears on de-quantized tensors, the whole KV
      cache re-quantized at every step)
   F  Level 1 + 1b: one launch per quantizer, fused LayerNorm/modulate/smooth/rotate/quant producer, incremental KV
-  Q  F with mat_qkv / proj / fc1 on the FP4 matrix cores (producers emit the GEMM operands directly)
+  Q  F with mat_qkv / proj / fc1 on the FP4 matrix cores (producers emit the GEMM operands directly, proj applies
+     the block's gate and residual in its epilogue) and attention by fpq_attention_blhc straight off the cache views
 Prints the time per batch for each and the speed-ups.
 """
 import argparse
@@ -24,7 +25,7 @@ import torch  # noqa: E402
 import torch.nn.functional as Fn  # noqa: E402
 
 import quant_cuda  # noqa: E402  (the drop-in module)
-from fpqvar_amd import gemm, kv_cache, quant_utils as qu, rotation as rot  # noqa: E402
+from fpqvar_amd import gemm, kv_cache, ops, quant_utils as qu, rotation as rot  # noqa: E402
 
 MODELS = {   # name: (depth, patch_nums, rows per token = images x CFG); SURVEY.md section 8 header, configs C3 / C5
     "d30-256": (30, (1, 2, 3, 4, 5, 6, 8, 10, 13, 16), 100),
@@ -207,7 +208,7 @@ def main():
                     qkv = q_producer_linear(x, sc1, sh1, s_qkv, "qkv")
                 q, k, v = qkv.view(B, L, 3, H, hd).unbind(2)
                 kc, vc = caches[b].append(k, v)
-                a = attend(q, kc, vc)
+                a = attend(q, kc, vc) if path == "F" else ops.attention_blhc(q, kc, vc, hd ** -0.5).view(B, L, C)
                 if path == "F":
                     x = x + Fn.linear(f_act(a), wq["proj"]).mul(g1)
                 else:
