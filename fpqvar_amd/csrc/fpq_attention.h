@@ -37,7 +37,7 @@ struct AttnArgs {
 constexpr int kAttnKv = 64;          // keys per staged tile
 constexpr int kAttnTile = kAttnKv * 128;   // bytes of one K (or V) tile
 
-__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[4 * kAttnTile];   // [buffer][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // all query tiles of one (batch, head) on one XCD, next to each other in dispatch order
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnArgs a) {
   // Q fragments: row q, channels 16 ks + 8 hi + j
   int qrow = qt * 128 + wave * 32 + ql;
   const bool q_live = qrow < a.lq;
+  const bool wave_live = __builtin_amdgcn_readfirstlane(qt * 128 + wave * 32) < a.lq;   // a wavefront past the last query row only helps staging
   qrow = q_live ? qrow : a.lq - 1;
   attn_h8_t qf[4];
   {
@@ -72,22 +73,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnArgs a) {
     st_koff[i] = r * 128 + 16 * (c ^ ((r >> 1) & 7));
     st_voff[i] = r * 128 + ((16 * c) ^ (64 * ((r >> 1) & 1)));
   }
-  u32x4 gk[2], gv[2];
+  u32x4 gk[2], gv[2], gk2[2], gv2[2];   // tile t + 1 and tile t + 2 in flight: two iterations to cover the load latency
   const int n_tiles = (a.lkv + kAttnKv - 1) / kAttnKv;
-#define FPQ_ATTN_FETCH(t)                                                                             \
+#define FPQ_ATTN_FETCH(t, GK, GV)                                                                     \
   _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                  \
     int kv_ = (t) * kAttnKv + st_row[i_];                                                             \
     kv_ = kv_ < a.lkv ? kv_ : a.lkv - 1;                                                              \
-    gk[i_] = *(const u32x4*)(kbase + (int64_t)kv_ * a.kv_token + 8 * st_ch[i_]);                     \
-    gv[i_] = *(const u32x4*)(vbase + (int64_t)kv_ * a.kv_token + 8 * st_ch[i_]);                     \
+    GK[i_] = *(const u32x4*)(kbase + (int64_t)kv_ * a.kv_token + 8 * st_ch[i_]);                     \
+    GV[i_] = *(const u32x4*)(vbase + (int64_t)kv_ * a.kv_token + 8 * st_ch[i_]);                     \
   }
-#define FPQ_ATTN_STAGE(buf)                                                                           \
+#define FPQ_ATTN_STAGE(buf, GK, GV)                                                                   \
   _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                  \
-    *(u32x4*)(smem + (buf) * 2 * kAttnTile + st_koff[i_]) = gk[i_];                                   \
-    *(u32x4*)(smem + (buf) * 2 * kAttnTile + kAttnTile + st_voff[i_]) = gv[i_];                       \
+    *(u32x4*)(smem + (buf) * 2 * kAttnTile + st_koff[i_]) = GK[i_];                                   \
+    *(u32x4*)(smem + (buf) * 2 * kAttnTile + kAttnTile + st_voff[i_]) = GV[i_];                       \
   }
-  FPQ_ATTN_FETCH(0);
-  FPQ_ATTN_STAGE(0);
+  FPQ_ATTN_FETCH(0, gk, gv);
+  FPQ_ATTN_STAGE(0, gk, gv);
+  // Everything issued so far (the Q fragments too) has to have landed before the loop: otherwise the compiler, not
+  // knowing how many prefetches are in flight on each path, waits for vmcnt(0) in front of the loop's first MFMAs -
+  // i.e. for the prefetch it has just issued - in every iteration.
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __builtin_amdgcn_sched_barrier(0);
+  FPQ_ATTN_FETCH(1, gk, gv);
 
   // fragment addresses inside a tile
   //   K (A operand of S^T): row 32 u + ql, chunk 2 ks + hi
@@ -108,13 +116,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.0f;
   const float c = a.scale_log2e;
 
-  for (int t = 0; t < n_tiles; ++t) {
+  // One iteration = one tile.  g1 holds tile t + 1 (fetched an iteration ago, staged at the end of this one), g2
+  // receives tile t + 2; the two register sets swap roles from one iteration to the next (no copies: a copy would
+  // wait for the load it copies).
+  auto iter = [&](int t, u32x4 (&gk1)[2], u32x4 (&gv1)[2], u32x4 (&gk2_)[2], u32x4 (&gv2_)[2]) {
     __syncthreads();   // tile t is in buffer t & 1; the other buffer's readers (iteration t - 1) are done
     const bool more = t + 1 < n_tiles;
-    if (more) { FPQ_ATTN_FETCH(t + 1); }
+    FPQ_ATTN_FETCH(t + 2, gk2_, gv2_);   // unconditional (rows past the end clamp to the last key): a fixed number of loads
+                                         // in flight lets the staging below wait for exactly its own
     const uint8_t* kt = smem + (t & 1) * 2 * kAttnTile;
     const uint8_t* vt = kt + kAttnTile;
 
+    if (wave_live) {   // uniform over the wavefront: EXEC stays all ones inside (the transposed reads need that)
     attn_f16_t s[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -174,7 +187,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnArgs a) {
           const attn_s8_t both = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(attn_h8_t, both), pf[u][sst], o[dt], 0, 0, 0);
         }
-    if (more) { FPQ_ATTN_STAGE((t + 1) & 1); }
+    }
+    if (more) { FPQ_ATTN_STAGE((t + 1) & 1, gk1, gv1); }
+  };
+  for (int t = 0; t < n_tiles; t += 2) {
+    iter(t, gk, gv, gk2, gv2);
+    if (t + 1 < n_tiles) iter(t + 1, gk2, gv2, gk, gv);
   }
 #undef FPQ_ATTN_FETCH
 #undef FPQ_ATTN_STAGE
