@@ -149,6 +149,20 @@ def other_kernels(dev):
     ms = timed(lambda: ops.quant_rows(nxt(ws), "e2m1", GROUP))
     out["weights_e2m1_per_group_fp32_32768x1920"] = {"ms": round(ms, 4), "GBps": round(n * 8 / ms / 1e6, 1),
                                                      "frac_of_8TBps": round(n * 8 / ms / 1e6 / HBM_PEAK_GBS, 3)}
+    del ws
+    # the consumers on the other side of the quantizers: matrix-core kernels, TFLOP/s
+    from fpqvar_amd import gemm
+    a = gemm.quantize_mx(xs[0])
+    w = gemm.quantize_mx(torch.randn(3 * COLS, COLS, device=dev, generator=g) * 0.02)
+    ms = timed(lambda: gemm.linear_fp4(*a, *w))
+    out["gemm_fp4_w4a4_mat_qkv_65536x1920x5760"] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * ROWS * COLS * 3 * COLS / ms / 1e9, 1)}
+    del a, w, xs
+    B, H, Lq, Lkv = 100, COLS // 64, 256, 680          # last scale step of a VAR-d30 256x256 batch
+    q = torch.nn.functional.normalize(torch.randn(B, Lq, H, 64, device=dev, generator=g), dim=-1).mul(8).half()
+    kk = torch.nn.functional.normalize(torch.randn(B, Lkv, H, 64, device=dev, generator=g), dim=-1).half()
+    vv = torch.randn(B, Lkv, H, 64, device=dev, generator=g).half()
+    ms = timed(lambda: ops.attention_blhc(q, kk, vv, 1.0))
+    out["attention_kv_cache_100x30_q256_kv680_c64"] = {"ms": round(ms, 4), "TFLOPs": round(4.0 * B * H * 64 * Lq * Lkv / ms / 1e9, 1)}
     return out
 
 
