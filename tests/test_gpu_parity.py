@@ -1406,3 +1406,31 @@ def test_attention_over_the_cache_matches_sdpa(dev, B, H, Lq, Lkv):
             assert out.shape == (B, Lq, H, 64) and out.dtype == torch.float16
             err = (out.float() - ref).abs().max().item()
             assert err <= 2e-3 * float(v_view.abs().max()), (scale, err)
+
+
+def test_attention_argument_checks_and_graph_capture(dev):
+    from fpqvar_amd import ops
+    q = torch.randn(2, 5, 3, 64, device=dev).half()
+    k = torch.randn(2, 9, 3, 64, device=dev).half()
+    with pytest.raises(RuntimeError):
+        ops.attention_blhc(q[..., :32], k[..., :32], k[..., :32], 1.0)          # head_dim 32
+    with pytest.raises(RuntimeError):
+        ops.attention_blhc(q, k[:, :0], k[:, :0], 1.0)                          # no keys
+    with pytest.raises(RuntimeError):
+        ops.attention_blhc(q.float(), k.float(), k.float(), 1.0)
+    with pytest.raises(RuntimeError):
+        ops.attention_blhc(q, k, k, 0.0)                                        # FPQ_ERR_ARG from the C ABI: scale must be > 0
+    assert ops.attention_blhc(q[:, :0], k, k, 1.0).shape == (2, 0, 3, 64)
+    # stream-ordered and capturable: replaying a hipGraph on new inputs reproduces the eager result
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.attention_blhc(q, k, k, 0.5)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = ops.attention_blhc(q, k, k, 0.5)
+    q.copy_(torch.randn_like(q))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ops.attention_blhc(q, k, k, 0.5))
