@@ -2,7 +2,7 @@
 """A/B two builds of libfpq_hip.so in ONE process on ONE box (box-to-box and run-to-run variance is +-7 %, larger than
 most kernel changes): alternates the two libraries over three rounds per shape and prints every burst.
 
-    python tools/ab_lib.py /path/libA.so /path/libB.so [fp4|fp6|quant]
+    python tools/ab_lib.py /path/libA.so /path/libB.so [fp4|fp6|quant|attn]
 Build the variants with the flags of __graft_entry__.HIP_FLAGS into files outside fpqvar_amd/ (on the GPU box the
 libraries must travel inside the repo snapshot, e.g. under tools/ab/ - git-ignored)."""
 import ctypes
@@ -38,6 +38,24 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     sp = stream_ptr(dev)
+    if what == "attn":      # attention over the KV cache at generation shapes (B, H, Lq, Lkv)
+        for B, H, Lq, Lkv in ((100, 30, 64, 155), (100, 30, 100, 255), (100, 30, 169, 424), (100, 30, 256, 680), (20, 36, 1024, 2240)):
+            q = torch.nn.functional.normalize(torch.randn(B, Lq, H, 64, device=dev), dim=-1).mul(8).half()
+            k = torch.nn.functional.normalize(torch.randn(B, Lkv, H, 64, device=dev), dim=-1).half()
+            v = torch.randn(B, Lkv, H, 64, device=dev).half()
+            out = torch.empty_like(q)
+
+            def call(lib):
+                f = lib.fpq_attention_blhc
+                f.argtypes = [V, V, V, V] + [ctypes.c_int64] * 9 + [ctypes.c_float, V]
+                return lambda: f(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, Lkv, H, 64, q.stride(0),
+                                 q.stride(1), k.stride(0), k.stride(1), 1.0, sp)
+            res = {"A": [], "B": []}
+            for _ in range(3):
+                for n in "AB":
+                    res[n].append(round(burst(call(libs[n])), 4))
+            print((B, H, Lq, Lkv), res, flush=True)
+        return
     for T, K, O in ((65536, 1920, 5760), (65536, 1920, 7680), (65536, 1920, 1920), (25600, 1920, 5760)):
         x = torch.randn(T, K, device=dev).half()
         w = torch.randn(O, K, device=dev) * 0.02
