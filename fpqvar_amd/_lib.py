@@ -40,6 +40,8 @@ _SIGS = {
     "fpq_attention_blhc": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64,
                                        _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float,
                                        _c.c_void_p]),
+    "fpq_gate_residual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64,
+                                      _c.c_void_p]),
     "fpq_kv_cache_step": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p,
                                       _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int,
                                       _c.c_void_p]),

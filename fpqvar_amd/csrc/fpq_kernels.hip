@@ -1752,6 +1752,41 @@ int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_
                               nullptr, stream);
 }
 
+// out = resid + y * gate[row / rows_per_gate, :], fp16 with one rounding per operation (the GEMM epilogues' tail as a
+// kernel of its own, for Linears that run elsewhere - e.g. fc2's fp16 GEMM)
+__global__ __launch_bounds__(kBlock) void gate_residual_kernel(const u32x4* y, const u32x4* __restrict__ gate,
+                                                              const u32x4* resid, u32x4* out, int64_t n_vec, int row_vec,
+                                                              int rows_per_gate) {
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = v / row_vec;
+    const int c = (int)(v - row * row_vec);
+    u32x4 a = __builtin_nontemporal_load(y + v);
+    const u32x4 g = gate[(row / rows_per_gate) * row_vec + c];
+    const u32x4 r = resid[v];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const fpq_h2_t p = __builtin_bit_cast(fpq_h2_t, (uint32_t)a[i]) * __builtin_bit_cast(fpq_h2_t, (uint32_t)g[i]);
+      a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(fpq_h2_t, (uint32_t)r[i]) + p);
+    }
+    out[v] = a;
+  }
+}
+
+int fpq_gate_residual(const void* y, const void* gate, const void* residual, void* out, int64_t rows, int64_t cols,
+                      int64_t rows_per_gate, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0 || rows_per_gate < 1 || rows_per_gate > 0x7FFFFFFF) return FPQ_ERR_ARG;
+  if (cols % 8 != 0 || cols / 8 > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!y || !gate || !residual || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)y | (uintptr_t)gate | (uintptr_t)residual | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  const int64_t n_vec = rows * (cols / 8);
+  const int64_t wgs = (n_vec + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(grid_for(wgs, 1 << 20)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const u32x4*)y, (const u32x4*)gate, (const u32x4*)residual, (u32x4*)out, n_vec, (int)(cols / 8),
+                     (int)rows_per_gate);
+  return check_launch();
+}
+
 // validates an optional epilogue descriptor and turns it into the kernels' form
 static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi* epi) {
   epi->gate = nullptr;

@@ -68,6 +68,25 @@ def quant_rows(x: torch.Tensor, table: str, cols: int, out_dtype: Optional[torch
     return out
 
 
+def gate_residual(y: torch.Tensor, gate: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    """residual + y.mul(gate) in one launch, bit-identical to the two torch ops (tr/basic_var.py:264,267): y and
+    residual fp16 [B, L, C], gate fp16 [B, 1, C] (gamma1 / gamma2 of the AdaLN block)."""
+    require_gpu(y, "gate_residual")
+    if y.dtype != torch.float16 or gate.dtype != torch.float16 or residual.dtype != torch.float16:
+        raise RuntimeError("gate_residual: y, gate and residual must be float16")
+    C = y.shape[-1]
+    rows = y.numel() // C if C else 0
+    g = gate.reshape(-1, C)
+    if residual.shape != y.shape or g.shape[0] == 0 or rows % g.shape[0] != 0 or C % 8 != 0:
+        raise RuntimeError(f"gate_residual: shapes {tuple(y.shape)} {tuple(gate.shape)} {tuple(residual.shape)} do not fit")
+    yc, gc, rc = _contig(y), _contig(g), _contig(residual)
+    out = torch.empty_like(yc)
+    with torch.cuda.device(y.device):
+        check(lib().fpq_gate_residual(yc.data_ptr(), gc.data_ptr(), rc.data_ptr(), out.data_ptr(), rows, C,
+                                      max(rows // g.shape[0], 1), stream_ptr(y.device)), "fpq_gate_residual")
+    return out.view(y.shape)
+
+
 def attention_blhc(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
     """fpq_attention_blhc: softmax(q k^T * scale) v for fp16 q [B, Lq, H, 64], k / v [B, Lkv, H, 64] (views with
     contiguous (H, 64) rows are taken as they are) -> [B, Lq, H, 64]; flash_attn_func(q, k, v, softmax_scale=scale)."""

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 113 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex, fpq_attention_blhc */
+#define FPQ_VERSION 114 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex, fpq_attention_blhc, fpq_gate_residual */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -321,6 +321,11 @@ typedef struct fpq_gemm_epilogue {
   const void* residual;  /* fp16 [tokens, outs] or NULL */
   int64_t rows_per_gate; /* consecutive token rows sharing a gate row (tokens per batch entry), >= 1 */
 } fpq_gemm_epilogue_t;
+/* The same tail as a call of its own, for a Linear that runs elsewhere (fc2's fp16 GEMM): out = residual +
+ * y * gate[row / rows_per_gate, :], all fp16 [rows, cols] (gate [ceil(rows / rows_per_gate), cols]), cols % 8 == 0,
+ * 16-byte aligned; out may be y or residual. */
+int fpq_gate_residual(const void* y, const void* gate, const void* residual, void* out, int64_t rows, int64_t cols,
+                      int64_t rows_per_gate, fpq_stream_t stream);
 int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
                        int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
                        const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);

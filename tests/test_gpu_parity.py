@@ -1434,3 +1434,17 @@ def test_attention_argument_checks_and_graph_capture(dev):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, ops.attention_blhc(q, k, k, 0.5))
+
+
+@pytest.mark.parametrize("B,L,C", ((100, 16, 1920), (3, 1, 8), (2, 333, 2304), (1, 5, 64)))
+def test_gate_residual_is_bitwise_the_two_torch_ops(dev, B, L, C):
+    from fpqvar_amd import ops
+    g = torch.Generator().manual_seed(B + L + C)
+    y = torch.randn(B, L, C, generator=g).half().to(dev)
+    gate = (torch.randn(B, 1, C, generator=g) * 0.5).half().to(dev)
+    x = (torch.randn(B, L, C, generator=g) * 3).half().to(dev)
+    assert_bits_equal(ops.gate_residual(y, gate, x), x + y.mul(gate), "gate_residual")
+    with pytest.raises(RuntimeError):
+        ops.gate_residual(y, gate.float(), x)
+    with pytest.raises(RuntimeError):
+        ops.gate_residual(y, gate, x[:, :0])

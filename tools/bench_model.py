@@ -210,7 +210,7 @@ def main():
                 kc, vc = caches[b].append(k, v)
                 a = attend(q, kc, vc) if path == "F" else ops.attention_blhc(q, kc, vc, hd ** -0.5).view(B, L, C)
                 if path == "F":
-                    x = x + Fn.linear(f_act(a), wq["proj"]).mul(g1)
+                    x = ops.gate_residual(Fn.linear(f_act(a), wq["proj"]), g1, x)
                 else:
                     x = q_proj(a.view(B * L, C), g1, x).view(B, L, C)
                 if path == "F":
@@ -218,7 +218,7 @@ def main():
                 else:
                     h = q_producer_linear(x, sc2, sh2, s_fc1, "fc1").view(B, L, HID)
                 h = Fn.gelu(h, approximate="tanh")
-                x = x + Fn.linear(f_fc2(h), wq["fc2"]).mul(g2)
+                x = ops.gate_residual(Fn.linear(f_fc2(h), wq["fc2"]), g2, x)
         return x
 
     res = {"workload": f"VAR-{args.model} transformer part, {depth} blocks x {len(PATCH_NUMS)} steps ({max_len} tokens), B={B} (CFG), {args.config.upper()} + FP6 KV cache, random weights",
