@@ -77,6 +77,10 @@ _SIGS = {
                                                                 _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
                                                                 _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int,
                                                                 _c.c_void_p]),
+    "fpq_adaln_rotate_quant_token_rows_codes_fp6": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                                                _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
+                                                                _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int,
+                                                                _c.c_void_p]),
     "fpq_adaln_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
                                                 _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float,
                                                 _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),

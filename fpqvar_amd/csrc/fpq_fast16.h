@@ -621,6 +621,7 @@ struct RotArgs {
   uint16_t* code_scales; // nullptr: `out` receives fake-quantized fp16 values.  Otherwise `out` receives packed
                          // hardware E2M1 codes (4 bytes per 8 elements), this array one fp16 scale per 128-group,
                          // and the staged table is the code table (fpq_gemm_fp4.h)
+  int code_bits;         // per-token code emission: 8 = E4M3 bytes (fpq_gemm_fp8.h), 6 = dense 6-bit E2M3 (fpq_gemm_fp6.h)
 };
 
 __device__ __forceinline__ float xlane_xor4(float v) {
@@ -1000,8 +1001,26 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
             cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
             cb[2 * k + 1] = lut[u >> (16 + a.shift)];
           }
-          const u32x2 o2 = {cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24), cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24)};
-          __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
+          if (r.code_bits == 6) {
+            // 8 six-bit codes = 48 bits per lane, rows packed densely: the four lanes of a quad own 24 contiguous
+            // bytes; lane q of the quad takes the (3 - q) upper 16-bit words of its own string and the q + 1 lower
+            // words of its right neighbour's, so that lanes 0..2 each store 8 aligned bytes (cols % 32 == 0: a quad
+            // is live or dead as a whole).
+            const uint64_t own = (uint64_t)(cb[0] | (cb[1] << 6) | (cb[2] << 12) | (cb[3] << 18)) |
+                                 ((uint64_t)(cb[4] | (cb[5] << 6) | (cb[6] << 12) | (cb[7] << 18)) << 24);
+            const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)own, 0xF9, 0xF, 0xF, false);   // quad_perm [1,2,3,3]
+            const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(own >> 32), 0xF9, 0xF, 0xF, false);
+            const uint64_t nb = ((uint64_t)nhi << 32) | nlo;
+            const int qp = lane & 3, sr = 16 * qp;
+            const uint64_t w = (own >> sr) | (nb << (48 - sr));
+            if (qp < 3) {
+              uint8_t* dst = (uint8_t*)out + row * (vpr * 6) + (int64_t)c * (LANES * 6) + 24 * (lane >> 2) + 8 * qp;
+              __builtin_nontemporal_store(u32x2{(uint32_t)w, (uint32_t)(w >> 32)}, (u32x2*)dst);
+            }
+          } else {
+            const u32x2 o2 = {cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24), cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24)};
+            __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
+          }
         } else {
           u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
           __builtin_nontemporal_store(o, out + row * vpr + v);

@@ -1138,6 +1138,7 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   const Lut16Tab& tab = code_scales ? lut16_mx_codes_e2m1() : h.tab;
   RotArgs r;
   r.code_scales = code_scales;
+  r.code_bits = 8;
   r.smooth = smooth;
   for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));   // torch.tensor(128).sqrt() is float32; autocast makes Q fp16
@@ -1163,13 +1164,14 @@ template <typename Tin, typename Tmod>
 int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out, int64_t rows, int64_t cols,
                               const AdaLnArgs& ad, const float* smooth, const uint32_t sign[4], int table_id,
                               hipStream_t st, int lanes_per_row, uint16_t* code_scales = nullptr,
-                              int token_mode = 0 /*1: per-token values, 2: per-token E4M3 codes*/,
+                              int token_mode = 0 /*1: per-token values, 2: per-token E4M3 codes, 3: per-token packed 6-bit codes*/,
                               const Lut16Tab* token_code_tab = nullptr) {
   const Lut16Host& h = lut16_host(table_id, table_id);
   if (!h.tab_valid) return FPQ_ERR_TABLE;
-  const Lut16Tab& tab = token_mode == 2 ? *token_code_tab : (code_scales && !token_mode ? lut16_mx_codes_e2m1() : h.tab);
+  const Lut16Tab& tab = token_mode >= 2 ? *token_code_tab : (code_scales && !token_mode ? lut16_mx_codes_e2m1() : h.tab);
   RotArgs r;
   r.code_scales = code_scales;
+  r.code_bits = token_mode == 3 ? 6 : 8;
   r.smooth = smooth;
   for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));
@@ -1194,7 +1196,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   if (token_mode) {   // one wavefront per row only (C <= 2560)
 #define FPQ_ADALN_TOK(M)                                                                                             \
   do {                                                                                                               \
-    if (token_mode == 2)                                                                                             \
+    if (token_mode >= 2)                                                                                             \
       hipLaunchKernelGGL((adaln_rotate_quant16_kernel<Tin, Tmod, 64, M, true, true>), g, dim3(kBlock), lds, st, x,  \
                          (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab);                       \
     else                                                                                                             \
@@ -1952,6 +1954,18 @@ static const Lut16Tab& lut16_codes6_e2m3() {
     return t;
   }();
   return *tab;
+}
+
+int fpq_adaln_rotate_quant_token_rows_codes_fp6(const void* x, uint8_t* codes, void* row_scales, int64_t rows, int64_t cols,
+                                                int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                                int64_t rows_per_batch, float eps, const float* smooth,
+                                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  if (rows > 0 && cols > 0 && !row_scales) return FPQ_ERR_ARG;
+  if (table_id != FPQ_E2M3) return FPQ_ERR_TABLE;
+  if (cols % 32 != 0) return FPQ_ERR_SHAPE;
+  if ((((uintptr_t)codes) & 7) != 0) return FPQ_ERR_ARG;
+  return adaln_rotate_quant_impl(x, codes, nullptr, nullptr, row_scales, rows, cols, in_dtype, scale, shift, mod_dtype,
+                                 rows_per_batch, eps, smooth, sign_mask_host, table_id, stream, 3, &lut16_codes6_e2m3());
 }
 
 int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,

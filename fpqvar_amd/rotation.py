@@ -216,7 +216,8 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
                              emit: str = "values"):
     """The fused producer for the per-token configurations (W6A6): LayerNorm, modulate, smooth, rotate, then
     fp6_quant_*_per_token_cuda with one scale per token row.  emit="values": fp16 [B, L, C];
-    emit="fp8": (codes uint8 [B*L, C], scales fp16 [B*L]) for gemm.linear_fp8.  C <= 2560."""
+    emit="fp8": (codes uint8 [B*L, C], scales fp16 [B*L]) for gemm.linear_fp8; emit="fp6" (table e2m3 only):
+    (dense 6-bit codes uint8 [B*L, C * 3 / 4], scales) for gemm.linear_fp6.  C <= 2560."""
     require_gpu(x, "adaln_rotate_quant_token")
     if x.dim() != 3:
         raise RuntimeError("adaln_rotate_quant_token: x must be [B, L, C]")
@@ -232,14 +233,19 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     rows = bsz * seq
     with torch.cuda.device(x.device):
-        if emit == "fp8":
-            codes = torch.empty((rows, c), dtype=torch.uint8, device=x.device)
+        if emit in ("fp8", "fp6"):
+            if emit == "fp6" and table != "e2m3":
+                raise RuntimeError("adaln_rotate_quant_token: emit='fp6' is the E2M3 operand format")
+            codes = torch.empty((rows, c if emit == "fp8" else c * 3 // 4), dtype=torch.uint8, device=x.device)
             scales = torch.empty((rows,), dtype=torch.float16, device=x.device)
-            check(lib().fpq_adaln_rotate_quant_token_rows_codes_fp8(
-                xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),
-                dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, TABLE_IDS[table], stream_ptr(x.device)),
-                "fpq_adaln_rotate_quant_token_rows_codes_fp8")
+            fn = (lib().fpq_adaln_rotate_quant_token_rows_codes_fp8 if emit == "fp8"
+                  else lib().fpq_adaln_rotate_quant_token_rows_codes_fp6)
+            check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),
+                     dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, TABLE_IDS[table], stream_ptr(x.device)),
+                  "fpq_adaln_rotate_quant_token_rows_codes_" + emit)
             return codes, scales
+        if emit != "values":
+            raise RuntimeError(f"adaln_rotate_quant_token: unknown emit {emit!r}")
         out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         check(lib().fpq_adaln_rotate_quant_token_rows(
             xc.data_ptr(), out.data_ptr(), None, None, None, rows, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),

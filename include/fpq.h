@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 114 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex, fpq_attention_blhc, fpq_gate_residual */
+#define FPQ_VERSION 115 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex, fpq_attention_blhc, fpq_gate_residual, ..._codes_fp6 producer */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -233,6 +233,12 @@ int fpq_adaln_rotate_quant_token_rows(const void* x, void* out, void* h_out, voi
                                       int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
                                       const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
 int fpq_adaln_rotate_quant_token_rows_codes_fp8(const void* x, uint8_t* codes, void* row_scales, int64_t rows,
+                                                int64_t cols, int in_dtype, const void* scale, const void* shift,
+                                                int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
+                                                const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
+/* ... and the _codes_fp6 form the operand format of fpq_gemm_fp6_rows (dense 6-bit E2M3 codes [rows, cols * 3 / 4] +
+ * fp16 row scales): table_id must be FPQ_E2M3, cols % 32 == 0, codes 8-byte aligned. */
+int fpq_adaln_rotate_quant_token_rows_codes_fp6(const void* x, uint8_t* codes, void* row_scales, int64_t rows,
                                                 int64_t cols, int in_dtype, const void* scale, const void* shift,
                                                 int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
                                                 const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);

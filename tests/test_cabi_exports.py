@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.fpq_version() == 114
+    assert lib.fpq_version() == 115
     assert lib.fpq_strerror(0) == b"ok"
     for code in range(-6, 0):
         assert lib.fpq_strerror(code)
@@ -99,4 +99,4 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
         _lib.lib()
     monkeypatch.undo()
-    assert _lib.lib().fpq_version() == 114
+    assert _lib.lib().fpq_version() == 115

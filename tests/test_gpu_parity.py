@@ -1322,6 +1322,13 @@ def test_adaln_rotate_quant_per_token(dev, C, x_dtype):
         codes, scales = rot.adaln_rotate_quant_token(x, scale, shift, table, smooth=s, emit="fp8")
         c2, s2 = gemm.quantize_fp8(y.reshape(B * L, C), table)
         assert torch.equal(scales, s2) and torch.equal(codes, c2), f"fp8 operands, {table}"
+        if table == "e2m3":
+            codes6, scales6 = rot.adaln_rotate_quant_token(x, scale, shift, table, smooth=s, emit="fp6")
+            c6, s6 = gemm.quantize_fp6(y.reshape(B * L, C))
+            assert codes6.shape == (B * L, C * 3 // 4) and torch.equal(scales6, s6) and torch.equal(codes6, c6), "fp6 operands"
+        else:
+            with pytest.raises(RuntimeError):
+                rot.adaln_rotate_quant_token(x, scale, shift, table, smooth=s, emit="fp6")
     with pytest.raises(RuntimeError):
         rot.adaln_rotate_quant_token(torch.zeros(1, 2, 4096, device=dev).half(), torch.zeros(1, 1, 4096, device=dev).half(),
                                      torch.zeros(1, 1, 4096, device=dev).half())

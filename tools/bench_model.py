@@ -87,8 +87,7 @@ def main():
     W6 = args.config == "w6a6"
     if W6:
         wq = {n: qu.fp6_quant_e2m3_per_token_cuda(w, 6) for n, w in w32.items()}
-        fp4 = {n: gemm.quantize_fp8(w32[n], "e2m3") for n in ("qkv", "fc1")}        # operands of the row-scaled GEMMs
-        fp4["proj"] = gemm.quantize_fp6(w32["proj"])
+        fp4 = {n: gemm.quantize_fp6(w32[n]) for n in ("qkv", "proj", "fc1")}        # operands of the row-scaled GEMMs
     else:
         wq = {n: qu.fp_quant_e2_per_group_cuda(w, 4, 128).half() for n, w in w32.items()}
         fp4 = {n: gemm.quantize_mx(w32[n]) for n in ("qkv", "proj", "fc1")}
@@ -126,7 +125,7 @@ def main():
 
     def q_producer_linear(t, sc, sh, sm, name):
         if W6:
-            return gemm.linear_fp8(*rot.adaln_rotate_quant_token(t, sc, sh, "e2m3", smooth=sm, emit="fp8"), *fp4[name])
+            return gemm.linear_fp6(*rot.adaln_rotate_quant_token(t, sc, sh, "e2m3", smooth=sm, emit="fp6"), *fp4[name])
         return gemm.linear_fp4(*rot.adaln_rotate_quant_mx(t, sc, sh, smooth=sm), *fp4[name])
 
     def q_proj(t2d, gate, resid):       # x + proj(a).mul(gamma1), gate and residual applied in the GEMM epilogue
