@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    {   // the other 16 keys of the sub-tiles live in lane l ^ 32: one v_permlane32_swap, no LDS round trip
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     const float m_new = fmaxf(m_run, mx);            // finite: every tile holds at least one real key
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
     const float mc = m_new * c;
