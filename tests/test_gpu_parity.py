@@ -1455,3 +1455,22 @@ def test_gate_residual_is_bitwise_the_two_torch_ops(dev, B, L, C):
         ops.gate_residual(y, gate.float(), x)
     with pytest.raises(RuntimeError):
         ops.gate_residual(y, gate, x[:, :0])
+
+
+def test_attention_fuzz_shapes(dev):
+    """Random small (B, H, Lq, Lkv): every remainder of Lq mod 32 / 128 and Lkv mod 64 gets exercised over the seeds."""
+    import random
+    from fpqvar_amd import ops
+    rnd = random.Random(7)
+    g = torch.Generator().manual_seed(7)
+    for _ in range(40):
+        B, H = rnd.randint(1, 3), rnd.randint(1, 9)
+        Lq, Lkv = rnd.choice((1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, rnd.randint(1, 300))), rnd.randint(1, 400)
+        q = torch.randn(B, Lq, H, 64, generator=g).half().to(dev)
+        k = torch.randn(B, Lkv, H, 64, generator=g).half().to(dev)
+        v = torch.randn(B, Lkv, H, 64, generator=g).half().to(dev)
+        ref = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2).float(), k.transpose(1, 2).float(),
+                                                               v.transpose(1, 2).float(), scale=0.125).transpose(1, 2)
+        out = ops.attention_blhc(q, k, v, 0.125)
+        err = (out.float() - ref).abs().max().item()
+        assert err <= 2e-3 * float(v.abs().max()), (B, H, Lq, Lkv, err)
