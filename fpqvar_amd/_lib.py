@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpq_hip.so")
 
 F16, F32, F64 = 0, 1, 2
+TENSOR_WORKSPACE_BYTES = 8192   # FPQ_TENSOR_WORKSPACE_BYTES
 TABLE_IDS = {"e2m1": 0, "e1m2": 1, "e3m0": 2, "e2m3": 3, "e3m2": 4,
              "e1m2_neg": 5, "e2m1_pos": 6, "int_neg": 7, "e2m3_pos": 8, "e2m1_neg": 9}
 _DTYPES = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
@@ -84,6 +85,8 @@ _SIGS = {
     "fpq_adaln_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
                                                 _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float,
                                                 _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),
+    "fpq_quant_tensor_argmin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
+                                            _c.c_void_p]),
     "fpq_absmax": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "fpq_quant_rows_codes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                          _c.c_int, _c.c_int, _c.c_void_p]),

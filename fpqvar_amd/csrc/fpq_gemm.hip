@@ -1,0 +1,261 @@
+// fpq_gemm.hip - the consumers on the far side of the quantizers and of the KV path:
+// FP4 / FP6 / FP8 matrix-core GEMMs on quantizer codes, attention over the cache, the gated residual tail.
+// Second translation unit of libfpq_hip.so; the quantizers (and the code-emitting kernels that live in the
+// fpq_gemm_*.h headers) are compiled in fpq_kernels.hip.
+#include "fpq_common.h"
+
+namespace {
+#include "fpq_fast16.h"
+#include "fpq_gemm_fp4.h"
+#include "fpq_gemm_fp8.h"
+#include "fpq_gemm_fp6.h"
+#include "fpq_attention.h"
+}  // namespace
+
+extern "C" {
+
+int fpq_attention_blhc(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t lq, int64_t lkv,
+                       int64_t heads, int64_t head_dim, int64_t q_batch_pitch, int64_t q_token_pitch,
+                       int64_t kv_batch_pitch, int64_t kv_token_pitch, float scale, fpq_stream_t stream) {
+  if (batch < 0 || lq < 0 || lkv < 0 || heads <= 0) return FPQ_ERR_ARG;
+  if (head_dim != 64) return FPQ_ERR_SHAPE;
+  if (batch == 0 || lq == 0) return FPQ_OK;
+  if (lkv == 0 || !(scale > 0.0f)) return FPQ_ERR_ARG;            // softmax over nothing
+  if (!q || !k || !v || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  if (q_batch_pitch % 8 != 0 || q_token_pitch % 8 != 0 || kv_batch_pitch % 8 != 0 || kv_token_pitch % 8 != 0)
+    return FPQ_ERR_SHAPE;
+  if (lq > 0x7FFFFFFF || lkv > 0x7FFFFFFF || batch * heads > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  AttnArgs a;
+  a.q = (const uint16_t*)q;
+  a.k = (const uint16_t*)k;
+  a.v = (const uint16_t*)v;
+  a.out = (uint16_t*)out;
+  a.q_batch = q_batch_pitch;
+  a.q_token = q_token_pitch;
+  a.kv_batch = kv_batch_pitch;
+  a.kv_token = kv_token_pitch;
+  a.batch = (int)batch;
+  a.heads = (int)heads;
+  a.lq = (int)lq;
+  a.lkv = (int)lkv;
+  a.q_tiles = (int)((lq + 127) / 128);
+  a.scale_log2e = scale * 1.4426950408889634f;
+  const int64_t groups = (batch * heads + 7) / 8;
+  const int64_t n_wg = groups * a.q_tiles * 8;
+  if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  hipLaunchKernelGGL(attn_fwd64_kernel, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                    int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                    fpq_stream_t stream) {
+  return fpq_gemm_fp4_mx_ex(a_codes, a_scales, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k, nullptr, stream);
+}
+
+int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream) {
+  return fpq_gemm_fp6_rows_ex(a_codes, a_scales, a_scale_dtype, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k,
+                              nullptr, stream);
+}
+
+int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
+                      int64_t k, fpq_stream_t stream) {
+  return fpq_gemm_fp8_rows_ex(a_codes, a_scales, a_scale_dtype, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k,
+                              nullptr, stream);
+}
+
+// out = resid + y * gate[row / rows_per_gate, :], fp16 with one rounding per operation (the GEMM epilogues' tail as a
+// kernel of its own, for Linears that run elsewhere - e.g. fc2's fp16 GEMM)
+__global__ __launch_bounds__(kBlock) void gate_residual_kernel(const u32x4* y, const u32x4* __restrict__ gate,
+                                                              const u32x4* resid, u32x4* out, int64_t n_vec, int row_vec,
+                                                              int rows_per_gate) {
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = v / row_vec;
+    const int c = (int)(v - row * row_vec);
+    u32x4 a = __builtin_nontemporal_load(y + v);
+    const u32x4 g = gate[(row / rows_per_gate) * row_vec + c];
+    const u32x4 r = resid[v];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const fpq_h2_t p = __builtin_bit_cast(fpq_h2_t, (uint32_t)a[i]) * __builtin_bit_cast(fpq_h2_t, (uint32_t)g[i]);
+      a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(fpq_h2_t, (uint32_t)r[i]) + p);
+    }
+    out[v] = a;
+  }
+}
+
+int fpq_gate_residual(const void* y, const void* gate, const void* residual, void* out, int64_t rows, int64_t cols,
+                      int64_t rows_per_gate, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0 || rows_per_gate < 1 || rows_per_gate > 0x7FFFFFFF) return FPQ_ERR_ARG;
+  if (cols % 8 != 0 || cols / 8 > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return FPQ_OK;
+  if (!y || !gate || !residual || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)y | (uintptr_t)gate | (uintptr_t)residual | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  const int64_t n_vec = rows * (cols / 8);
+  const int64_t wgs = (n_vec + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(grid_for(wgs, 1 << 20)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const u32x4*)y, (const u32x4*)gate, (const u32x4*)residual, (u32x4*)out, n_vec, (int)(cols / 8),
+                     (int)rows_per_gate);
+  return check_launch();
+}
+
+// validates an optional epilogue descriptor and turns it into the kernels' form
+static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi* epi) {
+  epi->gate = nullptr;
+  epi->resid = nullptr;
+  epi->rows_per_gate = 1;
+  if (!ep) return FPQ_OK;
+  if (ep->gate && (ep->rows_per_gate < 1 || ep->rows_per_gate > 0x7FFFFFFF)) return FPQ_ERR_ARG;
+  if ((((uintptr_t)ep->gate | (uintptr_t)ep->residual) & 15) != 0) return FPQ_ERR_ARG;
+  epi->gate = (const _Float16*)ep->gate;
+  epi->resid = (const _Float16*)ep->residual;
+  if (ep->gate) epi->rows_per_gate = (int)ep->rows_per_gate;
+  (void)tokens;
+  return FPQ_OK;
+}
+
+int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  GemmEpi epi;
+  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
+  if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (k % 128 != 0 || k > 128 * 64 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if (tokens == 0 || outs == 0) return FPQ_OK;
+  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  const int G = (int)(k / 128);
+  hipStream_t st = (hipStream_t)stream;
+  // Default: the LDS-DMA kernel with 128 x 128 tiles (three workgroups per CU); the register-staged kernel
+  // when its LDS image does not fit (very long K).
+  // FPQ_GEMM_CFG (experiments): 0..2 register-staged tilings, 10 / 20 LDS-DMA tilings (256x128, 128x128).
+  const char* env = getenv("FPQ_GEMM_CFG");
+  const int cfg = env ? atoi(env) : 20;
+#define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
+  do {                                                                                                               \
+    using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
+    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
+    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
+    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
+    if (w_scale_dtype == FPQ_F16)                                                                                    \
+      hipLaunchKernelGGL((gemm_fp4_kernel<_Float16, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),        \
+                         Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,   \
+                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((gemm_fp4_kernel<float, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),           \
+                         Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,      \
+                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                     \
+  } while (0)
+#define FPQ_GEMM_GLDS(MT, NT)                                                                                        \
+  do {                                                                                                               \
+    using Cfg = GemmGldsCfg<MT, NT>;                                                                                 \
+    const size_t lds = Cfg::lds(G);                                                                                  \
+    if (lds <= 160 * 1024) {                                                                                         \
+      const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                \
+      const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                            \
+      if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                   \
+      if (w_scale_dtype == FPQ_F16)                                                                                  \
+        hipLaunchKernelGGL((gemm_fp4_glds_kernel<_Float16, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,      \
+                           a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,                   \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
+      else                                                                                                           \
+        hipLaunchKernelGGL((gemm_fp4_glds_kernel<float, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,         \
+                           a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,                      \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
+      return check_launch();                                                                                         \
+    }                                                                                                                \
+  } while (0)
+  if (cfg == 10) FPQ_GEMM_GLDS(8, 4);
+  if (cfg == 20) FPQ_GEMM_GLDS(4, 4);
+#undef FPQ_GEMM_GLDS
+  if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
+  else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
+  else FPQ_GEMM_LAUNCH(4, 4, 2, 2);
+#undef FPQ_GEMM_LAUNCH
+  return check_launch();
+}
+
+int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  GemmEpi epi;
+  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
+  if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (tokens == 0 || outs == 0) return FPQ_OK;
+  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const char* env6 = getenv("FPQ_GEMM6_CFG");     // 0: 128 x 128 tiles, 1: 256 x 128 (default for tall problems)
+  const int cfg6 = env6 ? atoi(env6) : (tokens >= 4096 ? 1 : 0);
+#define FPQ_GO6(TA, TW, MT, NT)                                                                                     \
+  do {                                                                                                               \
+    using Cfg = GemmFp6Cfg<MT, NT>;                                                                                  \
+    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
+    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
+    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
+    hipLaunchKernelGGL((gemm_fp6_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
+                       a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
+                       (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                                              \
+  } while (0)
+#define FPQ_GO6T(MT, NT)                                                                                             \
+  do {                                                                                                               \
+    if (a_scale_dtype == FPQ_F16 && w_scale_dtype == FPQ_F16) FPQ_GO6(_Float16, _Float16, MT, NT);                   \
+    else if (a_scale_dtype == FPQ_F16) FPQ_GO6(_Float16, float, MT, NT);                                             \
+    else if (w_scale_dtype == FPQ_F16) FPQ_GO6(float, _Float16, MT, NT);                                             \
+    else FPQ_GO6(float, float, MT, NT);                                                                              \
+  } while (0)
+  if (cfg6 == 1) FPQ_GO6T(8, 4);
+  else FPQ_GO6T(4, 4);
+#undef FPQ_GO6T
+#undef FPQ_GO6
+  return check_launch();
+}
+
+int fpq_gemm_fp8_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  GemmEpi epi;
+  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
+  if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (tokens == 0 || outs == 0) return FPQ_OK;
+  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const char* env8 = getenv("FPQ_GEMM8_CFG");
+  const int cfg8 = env8 ? atoi(env8) : 0;
+#define FPQ_GO8(TA, TW, MT, NT)                                                                                     \
+  do {                                                                                                               \
+    using Cfg = GemmFp8Cfg<MT, NT>;                                                                                  \
+    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
+    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
+    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
+    hipLaunchKernelGGL((gemm_fp8_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
+                       a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
+                       (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                                              \
+  } while (0)
+#define FPQ_GO8T(MT, NT)                                                                                             \
+  do {                                                                                                               \
+    if (a_scale_dtype == FPQ_F16 && w_scale_dtype == FPQ_F16) FPQ_GO8(_Float16, _Float16, MT, NT);                   \
+    else if (a_scale_dtype == FPQ_F16) FPQ_GO8(_Float16, float, MT, NT);                                             \
+    else if (w_scale_dtype == FPQ_F16) FPQ_GO8(float, _Float16, MT, NT);                                             \
+    else FPQ_GO8(float, float, MT, NT);                                                                              \
+  } while (0)
+  if (cfg8 == 1) FPQ_GO8T(8, 4);
+  else FPQ_GO8T(4, 4);
+#undef FPQ_GO8T
+#undef FPQ_GO8
+  return check_launch();
+}
+
+}  // extern "C"

@@ -25,282 +25,9 @@
 //     the larger VALUE (the scan's `<=`), i.e. up in magnitude for xn > 0 and down
 //     for xn < 0.  tests/ prove it equal to the scan on every fp16 input and on fp32
 //     neighbourhoods of every midpoint; fpq_quant_nearest keeps the literal scan.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-
-#include "fpq.h"
+#include "fpq_common.h"
 
 namespace {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kBlock = 256;   // 4 wavefronts of 64
-constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident workgroups
-
-// ---------------------------------------------------------------------------------
-// Format descriptors (wave-uniform kernel arguments -> SGPRs)
-// ---------------------------------------------------------------------------------
-struct Fmt {
-  float kmin;       // smallest normal level 2^emin (levels below it are equally spaced)
-  float inv_step0;  // 1 / spacing below kmin
-  float step0;      // spacing below kmin = kmin / 2^M
-  float gmax;       // largest level
-  float limit;      // 102400 + gmax: beyond it the scan selects nothing
-  uint32_t half_add;   // 1 << (22 - M)
-  uint32_t keep_mask;  // ~((1 << (23 - M)) - 1)
-  int32_t zero_code;   // index of 0.0 in the sorted de-duplicated SYMMETRIC table
-  int32_t mshift;      // 23 - M
-  uint32_t kmin_code_base;  // (bits(kmin) >> mshift) - 2^M : level index = (bits>>mshift) - base
-  int32_t argmin;     // 1: torch.argmin semantics of the reference's pure-torch path (ties to the
-                      //    SMALLER value, NaN/Inf -> table[0], no reach limit) instead of the scan's
-  float preclamp;     // > 0: x = clamp(x, -preclamp, preclamp) first (the reference's clamp(x,-3,3))
-};
-
-struct TableInfo {
-  const char* name;
-  int symmetric;  // usable with fpq_quant_rows
-  float kmin;
-  int mbits;
-  float gmax;
-  int n_pos;  // number of non-negative levels (incl. 0)
-};
-
-// E2M1: bias 1 -> subnormal step .5 below 1.0.  E1M2: bias 1 -> step .25 everywhere.
-// E3M0: bias 3 -> smallest normal .25.  E2M3: bias 1.  E3M2: bias 3.
-// INT_NEG: integers 0..32 = fixed point, expressed as kmin = 32, M = 5 (step 1).
-const TableInfo kTables[FPQ_NUM_TABLES] = {
-    {"e2m1", 1, 1.0f, 1, 6.0f, 8},      {"e1m2", 1, 1.0f, 2, 1.75f, 8},
-    {"e3m0", 1, 0.25f, 0, 16.0f, 8},    {"e2m3", 1, 1.0f, 3, 7.5f, 32},
-    {"e3m2", 1, 0.25f, 2, 28.0f, 32},   {"e1m2_neg", 0, 1.0f, 2, 1.75f, 8},
-    {"e2m1_pos", 0, 1.0f, 1, 6.0f, 8},  {"int_neg", 0, 32.0f, 5, 32.0f, 33},
-    {"e2m3_pos", 0, 1.0f, 3, 7.5f, 32}, {"e2m1_neg", 0, 1.0f, 1, 6.0f, 8},
-};
-
-inline uint32_t f2u(float f) {
-  uint32_t u;
-  __builtin_memcpy(&u, &f, 4);
-  return u;
-}
-
-Fmt make_fmt(int id) {
-  const TableInfo& t = kTables[id];
-  Fmt f;
-  f.kmin = t.kmin;
-  f.step0 = t.kmin / (float)(1 << t.mbits);
-  f.inv_step0 = 1.0f / f.step0;
-  f.gmax = t.gmax;
-  f.limit = 102400.0f + t.gmax;
-  f.half_add = 1u << (22 - t.mbits);
-  f.keep_mask = ~((1u << (23 - t.mbits)) - 1u);
-  f.zero_code = t.n_pos - 1;
-  f.mshift = 23 - t.mbits;
-  f.kmin_code_base = (f2u(t.kmin) >> f.mshift) - (1u << t.mbits);
-  f.argmin = 0;
-  f.preclamp = 0.0f;
-  return f;
-}
-
-// positive levels of a table, ascending (host)
-int pos_levels(int id, float* out) {
-  const TableInfo& t = kTables[id];
-  int n = 0;
-  if (id == FPQ_INT_NEG) {
-    for (int v = 0; v <= 32; ++v) out[n++] = (float)v;
-    return n;
-  }
-  float step0 = t.kmin / (float)(1 << t.mbits);
-  for (int m = 0; m < (1 << t.mbits); ++m) out[n++] = m * step0;
-  for (float base = t.kmin; base <= t.gmax; base *= 2.0f)
-    for (int m = 0; m < (1 << t.mbits); ++m) {
-      float v = base * (1.0f + (float)m / (float)(1 << t.mbits));
-      if (v <= t.gmax) out[n++] = v;
-    }
-  return n;
-}
-
-// ---------------------------------------------------------------------------------
-// Device helpers
-// ---------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
-__host__ __device__ __forceinline__ uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
-
-__host__ __device__ __forceinline__ float h2f(uint32_t hbits) {
-  _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)hbits);
-  return (float)h;
-}
-__host__ __device__ __forceinline__ uint32_t f2h(float f) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // The value must exist as a rounded fp32 before it is narrowed: torch materialises
-  // the fp32 product and then casts (two roundings when x is fp32).  Without the
-  // barrier LLVM folds fmul + fptrunc into v_fma_mixlo_f16, which rounds once.
-  asm volatile("" : "+v"(f));
-#endif
-  _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round to nearest even
-  return (uint32_t)__builtin_bit_cast(uint16_t, h);
-}
-
-// Magnitude of the nearest level for r = |xn| (r >= 0 or NaN); neg01 = 1 when xn < 0
-// (a tie then resolves to the smaller magnitude).  NaN, Inf and r > limit give 0.
-__host__ __device__ __forceinline__ float quant_mag(float r, uint32_t neg01, const Fmt& f) {
-  // binades at or above kmin: keep M mantissa bits, round half up (or half down)
-  uint32_t nb = (fbits(r) + f.half_add - neg01) & f.keep_mask;
-  float qn = u2f(nb);
-  // below kmin: equally spaced levels
-  float t = r * f.inv_step0;  // exact (power of two)
-  float fl = __builtin_floorf(t);
-  float fr = t - fl;          // exact
-  bool up = neg01 ? (fr > 0.5f) : (fr >= 0.5f);
-  float qs = (fl + (up ? 1.0f : 0.0f)) * f.step0;
-  float q = (r >= f.kmin) ? qn : qs;
-  q = __builtin_fminf(q, f.gmax);
-  return (r <= f.limit) ? q : 0.0f;
-}
-
-// index of a level magnitude q (exactly a level) among the non-negative levels
-__device__ __forceinline__ int level_index(float q, const Fmt& f) {
-  int hi = (int)((fbits(q) >> f.mshift) - f.kmin_code_base);
-  int lo = (int)(q * f.inv_step0);
-  return (q >= f.kmin) ? hi : lo;
-}
-
-// --- dtype traits: T = storage type of x, all arithmetic in fp32 with T's roundings ---
-template <typename T>
-struct DT;
-template <>
-struct DT<_Float16> {
-  static constexpr int kVec = 8;  // elements per 16-byte lane load
-  static __device__ __forceinline__ float get(const u32x4& v, int i) {
-    uint32_t w = v[i >> 1];
-    return h2f((i & 1) ? (w >> 16) : (w & 0xFFFFu));
-  }
-  static __device__ __forceinline__ void put(u32x4& v, int i, float p) {
-    uint32_t h = f2h(p);
-    uint32_t w = v[i >> 1];
-    v[i >> 1] = (i & 1) ? ((w & 0x0000FFFFu) | (h << 16)) : ((w & 0xFFFF0000u) | h);
-  }
-  static __device__ __forceinline__ uint32_t absbits(float xf) { return f2h(xf) & 0x7FFFu; }
-  static __device__ __forceinline__ float from_absbits(uint32_t b) { return h2f(b); }
-  static __device__ __forceinline__ float round(float v) { return h2f(f2h(v)); }
-  static __device__ __forceinline__ bool bits_nan(uint32_t b) { return b > 0x7C00u; }
-};
-template <>
-struct DT<float> {
-  static constexpr int kVec = 4;
-  static __device__ __forceinline__ float get(const u32x4& v, int i) { return u2f(v[i]); }
-  static __device__ __forceinline__ void put(u32x4& v, int i, float p) { v[i] = fbits(p); }
-  static __device__ __forceinline__ uint32_t absbits(float xf) { return fbits(xf) & 0x7FFFFFFFu; }
-  static __device__ __forceinline__ float from_absbits(uint32_t b) { return u2f(b); }
-  static __device__ __forceinline__ float round(float v) { return v; }
-  static __device__ __forceinline__ bool bits_nan(uint32_t b) { return b > 0x7F800000u; }
-};
-
-template <typename T>
-__device__ __forceinline__ float load_scalar(const T* p) {
-  return (float)(*p);
-}
-template <typename T>
-__device__ __forceinline__ void store_scalar(T* p, float v) {
-  asm volatile("" : "+v"(v));  // see f2h
-  *p = (T)v;
-}
-
-// scale = (T)(absmax / gmax), returned widened to fp32
-template <typename T>
-__device__ __forceinline__ float scale_of(uint32_t amax_bits, float gmax) {
-  return DT<T>::round(DT<T>::from_absbits(amax_bits) / gmax);
-}
-
-// One element of a symmetric-table row.  s = scale (already rounded to T).
-template <typename T>
-__device__ __forceinline__ float quant_sym(float xf, float s, const Fmt& f) {
-  float xn = DT<T>::round(xf / s);
-  uint32_t neg = (xn < 0.0f) ? 1u : 0u;
-  if (f.argmin) {
-    // tr/quant_utils.py:209-230: first minimal index = the smaller value on a tie, i.e. down in
-    // magnitude for xn > 0 and up for xn < 0; an all-NaN / all-Inf distance row gives index 0
-    float r = fabsf(xn);
-    Fmt g = f;
-    g.limit = __builtin_inff();
-    float qm = quant_mag(r, neg ^ 1u, g);
-    float q = (neg && qm != 0.0f) ? -qm : qm;
-    if (!(r < __builtin_inff())) q = -f.gmax;
-    return q * s;
-  }
-  float qm = quant_mag(fabsf(xn), neg, f);
-  float q = (neg && qm != 0.0f) ? -qm : qm;  // the table's zero is +0.0
-  return q * s;                              // fp32 product; 0*inf and 0*nan poison the row
-}
-
-// One element of a dual-format row (neg table for x <= 0, pos table for x > 0).
-template <typename T>
-__device__ __forceinline__ float quant_dual(float xf, float sn, float sp, const Fmt& fn, const Fmt& fp) {
-  bool isn = xf <= 0.0f, isp = xf > 0.0f;  // NaN: neither
-  if (fn.argmin) {
-    // fp_quant_e1m2_neg_e2m1_pos_per_group (tr/quant_utils.py:381-412), the pure-torch twin: BOTH halves of
-    // every element go through quantize_to_nearest_grid (the other half's input is 0), argmin takes the first
-    // minimal index (the smaller value on a tie) and index 0 for a NaN / +-Inf input - so a group without
-    // negatives (scale_neg = 0, 0/0) contributes table_neg[0] = -gmax_neg to every element, as in the reference.
-    Fmt gn = fn, gp = fp;
-    gn.limit = gp.limit = __builtin_inff();
-    const float a = DT<T>::round((isn ? xf : 0.0f) / sn);   // <= 0 or NaN
-    const float b = DT<T>::round((isp ? xf : 0.0f) / sp);   // >= 0 or NaN
-    const float ra = fabsf(a);
-    float qa = quant_mag(ra, 0u, gn);                        // tie -> smaller value = larger magnitude
-    qa = (qa != 0.0f) ? -qa : 0.0f;
-    if (!(ra < __builtin_inff())) qa = -fn.gmax;
-    float qb = quant_mag(b, 1u, gp);                         // tie -> smaller value
-    if (!(fabsf(b) < __builtin_inff())) qb = 0.0f;           // table_pos[0]
-    const float q = qa + qb;
-    return q * (isn ? sn : sp);
-  }
-  float qn = 0.0f, qp = 0.0f;
-  if (isn) {
-    float xn = DT<T>::round(xf / sn);
-    float qm = quant_mag(fabsf(xn), 1u, fn);
-    qn = (qm != 0.0f) ? -qm : 0.0f;
-  }
-  if (isp) {
-    float xn = DT<T>::round(xf / sp);
-    qp = quant_mag(xn, 0u, fp);
-  }
-  float a = qn * sn;
-  float b = qp * sp;
-  return a + b;
-}
-
-// clamp to +-clip with torch.clamp(Tensor bounds) NaN rules
-__device__ __forceinline__ float clamp_like_torch(float xf, float clip, bool clip_nan) {
-  if (clip_nan) return __builtin_nanf("");
-  if (xf != xf) return xf;
-  return fminf(fmaxf(xf, -clip), clip);
-}
-
-template <int LANES>
-__device__ __forceinline__ uint32_t lanes_max(uint32_t v) {
-#pragma unroll
-  for (int m = LANES / 2; m >= 1; m >>= 1) {
-    uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
-    v = v > o ? v : o;
-  }
-  return v;
-}
-
-struct DualArgs {
-  Fmt fneg, fpos;
-  const void* clip_absmax;  // device scalar or nullptr
-  float clip_strength;
-  uint32_t* nan_flag;       // nullptr, or device word that is OR-ed with 1 when an input element is NaN
-};
-
-template <typename T>
-__device__ __forceinline__ float clip_value(const DualArgs& d, bool* is_nan) {
-  float am = load_scalar<T>((const T*)d.clip_absmax);
-  float c = DT<T>::round(d.clip_strength * am);
-  *is_nan = (c != c);
-  return c;
-}
 
 // ---------------------------------------------------------------------------------
 // Kernel 1: rows of <= 1 KiB - LPR lanes of one wavefront own a row, one 16-byte
@@ -391,17 +118,6 @@ __global__ __launch_bounds__(kBlock) void rows_subwave_kernel(const u32x4* __res
 // row, up to MAXC 16-byte vectors per lane kept in registers between the
 // reduction (shuffles + LDS) and the rounding; longer rows are re-read (L2).
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t* sh) {
-  v = lanes_max<64>(v);
-  const int w = threadIdx.x >> 6;
-  __syncthreads();  // protect sh from the previous use
-  if ((threadIdx.x & 63) == 0) sh[w] = v;
-  __syncthreads();
-  uint32_t r = sh[0];
-#pragma unroll
-  for (int i = 1; i < kBlock / 64; ++i) r = r > sh[i] ? r : sh[i];
-  return r;
-}
 
 template <typename Tin, typename Tout, bool DUAL, int MAXC>
 __global__ __launch_bounds__(kBlock) void rows_block_kernel(const Tin* __restrict__ x,
@@ -656,10 +372,9 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 }
 
 #include "fpq_fast16.h"
-#include "fpq_gemm_fp4.h"
-#include "fpq_gemm_fp8.h"
+#include "fpq_gemm_fp4.h"   // the code-emitting quantizer kernels live beside their consumers;
+#include "fpq_gemm_fp8.h"   // the GEMM templates themselves are instantiated in fpq_gemm.hip
 #include "fpq_gemm_fp6.h"
-#include "fpq_attention.h"
 
 // ---------------------------------------------------------------------------------
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
@@ -836,6 +551,72 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(const T* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------
+// Per-tensor quantizer (BASELINE.json config 1; search/baseline/plot_weight_distribution_for_motivation.py:285-294):
+//     scale = x.abs().max() / max|table|      both 0-dim -> float32 whatever x's dtype
+//     out   = table[argmin |T(x / scale) - table|] * scale        float32
+// Two launches, no memset, no atomics: (1) every workgroup writes the maximum of its slice to `partials`,
+// (2) every workgroup of the elementwise launch reduces the <= kMaxBlocks partials (L2-resident) to the same
+// scale and quantizes its tile with the argmin rules of quant_sym; workgroup 0 also stores the scale.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void absmax_partials_kernel(const T* __restrict__ x, int64_t n,
+                                                                uint32_t* __restrict__ partials) {
+  __shared__ uint32_t sh[kBlock / 64];
+  constexpr int V = DT<T>::kVec;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const bool aligned = ((uintptr_t)x & 15) == 0;
+  const int64_t nv = aligned ? n / V : 0;
+  const u32x4* xv = (const u32x4*)x;
+  uint32_t m = 0;
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += stride) {
+    const u32x4 r = xv[v];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const uint32_t ab = DT<T>::absbits(DT<T>::get(r, i));
+      m = m > ab ? m : ab;
+    }
+  }
+  for (int64_t i = nv * V + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint32_t ab = DT<T>::absbits(load_scalar<T>(x + i));
+    m = m > ab ? m : ab;
+  }
+  m = block_max(m, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void tensor_argmin_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t n,
+                                                              const uint32_t* __restrict__ partials, int n_partials,
+                                                              float* __restrict__ scale_out, Fmt f) {
+  __shared__ uint32_t sh[kBlock / 64];
+  constexpr int V = DT<T>::kVec;
+  uint32_t m = 0;
+  for (int i = threadIdx.x; i < n_partials; i += kBlock) {
+    const uint32_t p = partials[i];
+    m = m > p ? m : p;
+  }
+  m = block_max(m, sh);
+  const float s = DT<T>::from_absbits(m) / f.gmax;   // float32 division of two 0-dim tensors
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+  const int64_t nv = aligned ? n / V : 0;
+  const u32x4* xv = (const u32x4*)x;
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += stride) {
+    const u32x4 r = __builtin_nontemporal_load(xv + v);
+    float p[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) p[i] = quant_sym<T>(DT<T>::get(r, i), s, f);
+#pragma unroll
+    for (int i = 0; i < V; i += 4)
+      __builtin_nontemporal_store(u32x4{fbits(p[i]), fbits(p[i + 1]), fbits(p[i + 2]), fbits(p[i + 3])},
+                                  (u32x4*)(out + v * V + i));
+  }
+  for (int64_t i = nv * V + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    out[i] = quant_sym<T>(load_scalar<T>(x + i), s, f);
+}
+
+// ---------------------------------------------------------------------------------
 // Codewords: one workgroup per row (any cols); code = index in the sorted
 // de-duplicated symmetric table.
 // ---------------------------------------------------------------------------------
@@ -979,15 +760,6 @@ __global__ __launch_bounds__(kBlock) void rows_decode_kernel(const uint8_t* __re
   }
 }
 
-// ---------------------------------------------------------------------------------
-// Host-side launch helpers
-// ---------------------------------------------------------------------------------
-inline int grid_for(int64_t work_items_of_block, int64_t cap = kMaxBlocks) {
-  int64_t g = work_items_of_block < 1 ? 1 : work_items_of_block;
-  return (int)(g > cap ? cap : g);
-}
-
-inline int check_launch() { return hipGetLastError() == hipSuccess ? FPQ_OK : FPQ_ERR_LAUNCH; }
 
 template <typename Tin, typename Tout, bool DUAL>
 int launch_rows(const void* x, void* out, int64_t rows, int64_t cols, const Fmt& fs, const DualArgs& dual,
@@ -1461,40 +1233,6 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
                               (hipStream_t)stream);
 }
 
-int fpq_attention_blhc(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t lq, int64_t lkv,
-                       int64_t heads, int64_t head_dim, int64_t q_batch_pitch, int64_t q_token_pitch,
-                       int64_t kv_batch_pitch, int64_t kv_token_pitch, float scale, fpq_stream_t stream) {
-  if (batch < 0 || lq < 0 || lkv < 0 || heads <= 0) return FPQ_ERR_ARG;
-  if (head_dim != 64) return FPQ_ERR_SHAPE;
-  if (batch == 0 || lq == 0) return FPQ_OK;
-  if (lkv == 0 || !(scale > 0.0f)) return FPQ_ERR_ARG;            // softmax over nothing
-  if (!q || !k || !v || !out) return FPQ_ERR_ARG;
-  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
-  if (q_batch_pitch % 8 != 0 || q_token_pitch % 8 != 0 || kv_batch_pitch % 8 != 0 || kv_token_pitch % 8 != 0)
-    return FPQ_ERR_SHAPE;
-  if (lq > 0x7FFFFFFF || lkv > 0x7FFFFFFF || batch * heads > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-  AttnArgs a;
-  a.q = (const uint16_t*)q;
-  a.k = (const uint16_t*)k;
-  a.v = (const uint16_t*)v;
-  a.out = (uint16_t*)out;
-  a.q_batch = q_batch_pitch;
-  a.q_token = q_token_pitch;
-  a.kv_batch = kv_batch_pitch;
-  a.kv_token = kv_token_pitch;
-  a.batch = (int)batch;
-  a.heads = (int)heads;
-  a.lq = (int)lq;
-  a.lkv = (int)lkv;
-  a.q_tiles = (int)((lq + 127) / 128);
-  a.scale_log2e = scale * 1.4426950408889634f;
-  const int64_t groups = (batch * heads + 7) / 8;
-  const int64_t n_wg = groups * a.q_tiles * 8;
-  if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-  hipLaunchKernelGGL(attn_fwd64_kernel, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
-  return check_launch();
-}
-
 int fpq_kv_cache_step(void* cache, int64_t batch, int64_t max_len, int64_t row_elems, int64_t quant_start,
                       int64_t quant_stop, const void* new_k, const void* new_v, int64_t new_batch_pitch,
                       int64_t new_token_pitch, int64_t new_start, int64_t n_new, int64_t group, int table_id,
@@ -1734,138 +1472,6 @@ int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t
   return check_launch();
 }
 
-int fpq_gemm_fp4_mx(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
-                    int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
-                    fpq_stream_t stream) {
-  return fpq_gemm_fp4_mx_ex(a_codes, a_scales, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k, nullptr, stream);
-}
-
-int fpq_gemm_fp6_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
-                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
-                      int64_t k, fpq_stream_t stream) {
-  return fpq_gemm_fp6_rows_ex(a_codes, a_scales, a_scale_dtype, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k,
-                              nullptr, stream);
-}
-
-int fpq_gemm_fp8_rows(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
-                      const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs,
-                      int64_t k, fpq_stream_t stream) {
-  return fpq_gemm_fp8_rows_ex(a_codes, a_scales, a_scale_dtype, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k,
-                              nullptr, stream);
-}
-
-// out = resid + y * gate[row / rows_per_gate, :], fp16 with one rounding per operation (the GEMM epilogues' tail as a
-// kernel of its own, for Linears that run elsewhere - e.g. fc2's fp16 GEMM)
-__global__ __launch_bounds__(kBlock) void gate_residual_kernel(const u32x4* y, const u32x4* __restrict__ gate,
-                                                              const u32x4* resid, u32x4* out, int64_t n_vec, int row_vec,
-                                                              int rows_per_gate) {
-  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * kBlock) {
-    const int64_t row = v / row_vec;
-    const int c = (int)(v - row * row_vec);
-    u32x4 a = __builtin_nontemporal_load(y + v);
-    const u32x4 g = gate[(row / rows_per_gate) * row_vec + c];
-    const u32x4 r = resid[v];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const fpq_h2_t p = __builtin_bit_cast(fpq_h2_t, (uint32_t)a[i]) * __builtin_bit_cast(fpq_h2_t, (uint32_t)g[i]);
-      a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(fpq_h2_t, (uint32_t)r[i]) + p);
-    }
-    out[v] = a;
-  }
-}
-
-int fpq_gate_residual(const void* y, const void* gate, const void* residual, void* out, int64_t rows, int64_t cols,
-                      int64_t rows_per_gate, fpq_stream_t stream) {
-  if (rows < 0 || cols < 0 || rows_per_gate < 1 || rows_per_gate > 0x7FFFFFFF) return FPQ_ERR_ARG;
-  if (cols % 8 != 0 || cols / 8 > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-  if (rows == 0 || cols == 0) return FPQ_OK;
-  if (!y || !gate || !residual || !out) return FPQ_ERR_ARG;
-  if ((((uintptr_t)y | (uintptr_t)gate | (uintptr_t)residual | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
-  const int64_t n_vec = rows * (cols / 8);
-  const int64_t wgs = (n_vec + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(gate_residual_kernel, dim3(grid_for(wgs, 1 << 20)), dim3(kBlock), 0, (hipStream_t)stream,
-                     (const u32x4*)y, (const u32x4*)gate, (const u32x4*)residual, (u32x4*)out, n_vec, (int)(cols / 8),
-                     (int)rows_per_gate);
-  return check_launch();
-}
-
-// validates an optional epilogue descriptor and turns it into the kernels' form
-static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi* epi) {
-  epi->gate = nullptr;
-  epi->resid = nullptr;
-  epi->rows_per_gate = 1;
-  if (!ep) return FPQ_OK;
-  if (ep->gate && (ep->rows_per_gate < 1 || ep->rows_per_gate > 0x7FFFFFFF)) return FPQ_ERR_ARG;
-  if ((((uintptr_t)ep->gate | (uintptr_t)ep->residual) & 15) != 0) return FPQ_ERR_ARG;
-  epi->gate = (const _Float16*)ep->gate;
-  epi->resid = (const _Float16*)ep->residual;
-  if (ep->gate) epi->rows_per_gate = (int)ep->rows_per_gate;
-  (void)tokens;
-  return FPQ_OK;
-}
-
-int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
-                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
-                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
-  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
-  GemmEpi epi;
-  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
-  if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
-  if (k % 128 != 0 || k > 128 * 64 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-  if (tokens == 0 || outs == 0) return FPQ_OK;
-  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
-  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
-  const int G = (int)(k / 128);
-  hipStream_t st = (hipStream_t)stream;
-  // Default: the LDS-DMA kernel with 128 x 128 tiles (three workgroups per CU); the register-staged kernel
-  // when its LDS image does not fit (very long K).
-  // FPQ_GEMM_CFG (experiments): 0..2 register-staged tilings, 10 / 20 LDS-DMA tilings (256x128, 128x128).
-  const char* env = getenv("FPQ_GEMM_CFG");
-  const int cfg = env ? atoi(env) : 20;
-#define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
-  do {                                                                                                               \
-    using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
-    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
-    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
-    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
-    if (w_scale_dtype == FPQ_F16)                                                                                    \
-      hipLaunchKernelGGL((gemm_fp4_kernel<_Float16, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),        \
-                         Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,   \
-                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                     \
-    else                                                                                                             \
-      hipLaunchKernelGGL((gemm_fp4_kernel<float, MT, NT, WR, WC>), dim3((unsigned)n_wg), dim3(Cfg::NTHR),           \
-                         Cfg::lds(G), st, a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,      \
-                         (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                     \
-  } while (0)
-#define FPQ_GEMM_GLDS(MT, NT)                                                                                        \
-  do {                                                                                                               \
-    using Cfg = GemmGldsCfg<MT, NT>;                                                                                 \
-    const size_t lds = Cfg::lds(G);                                                                                  \
-    if (lds <= 160 * 1024) {                                                                                         \
-      const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                \
-      const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                            \
-      if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                   \
-      if (w_scale_dtype == FPQ_F16)                                                                                  \
-        hipLaunchKernelGGL((gemm_fp4_glds_kernel<_Float16, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,      \
-                           a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,                   \
-                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
-      else                                                                                                           \
-        hipLaunchKernelGGL((gemm_fp4_glds_kernel<float, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,         \
-                           a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,                      \
-                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
-      return check_launch();                                                                                         \
-    }                                                                                                                \
-  } while (0)
-  if (cfg == 10) FPQ_GEMM_GLDS(8, 4);
-  if (cfg == 20) FPQ_GEMM_GLDS(4, 4);
-#undef FPQ_GEMM_GLDS
-  if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
-  else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
-  else FPQ_GEMM_LAUNCH(4, 4, 2, 2);
-#undef FPQ_GEMM_LAUNCH
-  return check_launch();
-}
-
 // host: OCP E4M3 byte of a value that is exactly representable (every level of the symmetric tables is)
 static uint8_t e4m3_of(float v) {
   if (v == 0.0f) return 0;
@@ -2002,84 +1608,6 @@ int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_
   return check_launch();
 }
 
-int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
-                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
-                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
-  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
-  GemmEpi epi;
-  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
-  if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-  if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
-    return FPQ_ERR_DTYPE;
-  if (tokens == 0 || outs == 0) return FPQ_OK;
-  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
-  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const char* env6 = getenv("FPQ_GEMM6_CFG");     // 0: 128 x 128 tiles, 1: 256 x 128 (default for tall problems)
-  const int cfg6 = env6 ? atoi(env6) : (tokens >= 4096 ? 1 : 0);
-#define FPQ_GO6(TA, TW, MT, NT)                                                                                     \
-  do {                                                                                                               \
-    using Cfg = GemmFp6Cfg<MT, NT>;                                                                                  \
-    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
-    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
-    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
-    hipLaunchKernelGGL((gemm_fp6_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
-                       a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
-                       (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                                              \
-  } while (0)
-#define FPQ_GO6T(MT, NT)                                                                                             \
-  do {                                                                                                               \
-    if (a_scale_dtype == FPQ_F16 && w_scale_dtype == FPQ_F16) FPQ_GO6(_Float16, _Float16, MT, NT);                   \
-    else if (a_scale_dtype == FPQ_F16) FPQ_GO6(_Float16, float, MT, NT);                                             \
-    else if (w_scale_dtype == FPQ_F16) FPQ_GO6(float, _Float16, MT, NT);                                             \
-    else FPQ_GO6(float, float, MT, NT);                                                                              \
-  } while (0)
-  if (cfg6 == 1) FPQ_GO6T(8, 4);
-  else FPQ_GO6T(4, 4);
-#undef FPQ_GO6T
-#undef FPQ_GO6
-  return check_launch();
-}
-
-int fpq_gemm_fp8_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
-                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
-                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
-  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
-  GemmEpi epi;
-  if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
-  if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-  if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
-    return FPQ_ERR_DTYPE;
-  if (tokens == 0 || outs == 0) return FPQ_OK;
-  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
-  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const char* env8 = getenv("FPQ_GEMM8_CFG");
-  const int cfg8 = env8 ? atoi(env8) : 0;
-#define FPQ_GO8(TA, TW, MT, NT)                                                                                     \
-  do {                                                                                                               \
-    using Cfg = GemmFp8Cfg<MT, NT>;                                                                                  \
-    const int64_t n_col = (outs + Cfg::BN - 1) / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                  \
-    const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                              \
-    if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                     \
-    hipLaunchKernelGGL((gemm_fp8_rows_kernel<TA, TW, MT, NT>), dim3((unsigned)n_wg), dim3(256), Cfg::lds(), st,     \
-                       a_codes, (const TA*)a_scales, w_codes, (const TW*)w_scales, (const _Float16*)bias,            \
-                       (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                                              \
-  } while (0)
-#define FPQ_GO8T(MT, NT)                                                                                             \
-  do {                                                                                                               \
-    if (a_scale_dtype == FPQ_F16 && w_scale_dtype == FPQ_F16) FPQ_GO8(_Float16, _Float16, MT, NT);                   \
-    else if (a_scale_dtype == FPQ_F16) FPQ_GO8(_Float16, float, MT, NT);                                             \
-    else if (w_scale_dtype == FPQ_F16) FPQ_GO8(float, _Float16, MT, NT);                                             \
-    else FPQ_GO8(float, float, MT, NT);                                                                              \
-  } while (0)
-  if (cfg8 == 1) FPQ_GO8T(8, 4);
-  else FPQ_GO8T(4, 4);
-#undef FPQ_GO8T
-#undef FPQ_GO8
-  return check_launch();
-}
-
 int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream) {
   if (n < 0 || !out) return FPQ_ERR_ARG;
   if (dtype != FPQ_F16 && dtype != FPQ_F32) return FPQ_ERR_DTYPE;
@@ -2093,6 +1621,34 @@ int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stre
     hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3(g), dim3(kBlock), 0, st, (const _Float16*)x, n, (uint32_t*)out);
   else
     hipLaunchKernelGGL(absmax_kernel<float>, dim3(g), dim3(kBlock), 0, st, (const float*)x, n, (uint32_t*)out);
+  return check_launch();
+}
+
+int fpq_quant_tensor_argmin(const void* x, float* out, float* scale_out, void* workspace, int64_t n, int table_id,
+                            int in_dtype, fpq_stream_t stream) {
+  if (n < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (!scale_out || !workspace || (((uintptr_t)workspace | (uintptr_t)scale_out) & 3) != 0) return FPQ_ERR_ARG;
+  if (n > 0 && (!x || !out)) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Fmt f = make_fmt(table_id);
+  f.argmin = 1;
+  constexpr int64_t per_block = (int64_t)kBlock * 16;
+  const int g1 = grid_for((n + per_block - 1) / per_block, FPQ_TENSOR_WORKSPACE_BYTES / 4);   // also 1 when n == 0
+  const int V = in_dtype == FPQ_F16 ? 8 : 4;
+  const int g2 = grid_for((n / V + 2 * kBlock - 1) / (2 * kBlock) + 1, 1 << 16);
+  if (in_dtype == FPQ_F16) {
+    hipLaunchKernelGGL(absmax_partials_kernel<_Float16>, dim3(g1), dim3(kBlock), 0, st, (const _Float16*)x, n,
+                       (uint32_t*)workspace);
+    hipLaunchKernelGGL(tensor_argmin_kernel<_Float16>, dim3(g2), dim3(kBlock), 0, st, (const _Float16*)x, out, n,
+                       (const uint32_t*)workspace, g1, scale_out, f);
+  } else {
+    hipLaunchKernelGGL(absmax_partials_kernel<float>, dim3(g1), dim3(kBlock), 0, st, (const float*)x, n,
+                       (uint32_t*)workspace);
+    hipLaunchKernelGGL(tensor_argmin_kernel<float>, dim3(g2), dim3(kBlock), 0, st, (const float*)x, out, n,
+                       (const uint32_t*)workspace, g1, scale_out, f);
+  }
   return check_launch();
 }
 

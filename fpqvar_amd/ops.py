@@ -174,6 +174,24 @@ def quant_rows_neg_reverse(x: torch.Tensor, table: str, cols: int) -> torch.Tens
     return out
 
 
+def quant_tensor_argmin(x: torch.Tensor, table: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One scale for the whole tensor, argmin lookup (fpq_quant_tensor_argmin): (float32 result, 0-dim float32 scale)."""
+    require_gpu(x, "quant_tensor_argmin")
+    if x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_tensor_argmin: x must be float16 or float32, got {x.dtype}")
+    if x.numel() == 0:
+        raise RuntimeError("max(): Expected reduction dim to be specified for input.numel() == 0")   # as x.abs().max()
+    xc = _contig(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.TENSOR_WORKSPACE_BYTES // 4 + 1, dtype=torch.int32, device=x.device)   # maxima + the scale
+    scale = ws[-1:].view(torch.float32)
+    with torch.cuda.device(x.device):
+        check(lib().fpq_quant_tensor_argmin(xc.data_ptr(), out.data_ptr(), scale.data_ptr(), ws.data_ptr(), xc.numel(),
+                                            TABLE_IDS[table], dtype_id(x.dtype), stream_ptr(x.device)),
+              "fpq_quant_tensor_argmin")
+    return out, scale.reshape(())
+
+
 def absmax(x: torch.Tensor) -> torch.Tensor:
     """0-dim max|x| in x's dtype (NaN-propagating)."""
     require_gpu(x, "absmax")

@@ -75,6 +75,23 @@ def fp_quant_e1_per_group(x, n_bits, group_size=128):
     return ops.quant_rows_argmin(x, "e1m2", group_size, clamp3=True)
 
 
+# ---- per tensor (BASELINE.json config 1) ----
+# search/baseline/plot_weight_distribution_for_motivation.py:285-294: ONE scale = x.abs().max() / 6 (float32, a 0-dim
+# tensor), argmin lookup, returns (output float32, scale).  The script only spells the E2M1 one; the E1M2 / E3M0
+# twins follow the same four lines with this library's tables.
+
+def fp_quant_e2_per_tensor(x):
+    return ops.quant_tensor_argmin(x, "e2m1")
+
+
+def fp_quant_e1_per_tensor(x):
+    return ops.quant_tensor_argmin(x, "e1m2")
+
+
+def fp_quant_e3_per_tensor(x):
+    return ops.quant_tensor_argmin(x, "e3m0")
+
+
 # ---- FP4, per group of `group_size` consecutive elements (tr/quant_utils.py:265-282,313-330,361-378) ----
 
 def fp_quant_e3_per_group_cuda(x, n_bits, group_size=128):

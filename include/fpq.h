@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 115 /* 0.1.1 + fpq_kv_cache_step, fpq_gemm_*_ex, fpq_attention_blhc, fpq_gate_residual, ..._codes_fp6 producer */
+#define FPQ_VERSION 120 /* 0.1.2: + fpq_quant_tensor_argmin (round 2) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -247,6 +247,18 @@ int fpq_adaln_rotate_quant_token_rows_codes_fp6(const void* x, uint8_t* codes, v
  * as ONE scalar of `dtype` to `out`.  `out` must hold 4 bytes; it is zeroed on the
  * stream first (hipMemsetAsync) and then combined with device atomics. */
 int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream);
+
+/* Per-tensor quantizer of the reference's pure-torch path (BASELINE.json config 1):
+ *   replaces fp_quant_e2_per_tensor   search/baseline/plot_weight_distribution_for_motivation.py:285-294
+ *     scale = x.abs().max() / max|table|     (two 0-dim tensors: float32 for F16 and F32 input alike)
+ *     out   = table[argmin_j |T(x / scale) - table[j]|] * scale      (float32; T = x's dtype)
+ * with torch.argmin's rules (first minimal index = the smaller value on a tie, NaN / +-Inf -> table[0]).
+ * x: n elements F16 or F32; out: float32 [n]; scale_out: ONE float32 (the function's second result);
+ * workspace: FPQ_TENSOR_WORKSPACE_BYTES of device scratch (per-workgroup maxima; no memset, no atomics).
+ * Two launches (maxima, then the elementwise pass).  n == 0 stores scale 0. */
+#define FPQ_TENSOR_WORKSPACE_BYTES 8192
+int fpq_quant_tensor_argmin(const void* x, float* out, float* scale_out, void* workspace, int64_t n, int table_id,
+                            int in_dtype, fpq_stream_t stream);
 
 /* Codeword output (build-defined; the reference's kernel never emits codes,
  * quant_kernel.cu:18,49).  code = index into the sorted, de-duplicated table

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FPQ_VERSION = int(re.search(r"#define FPQ_VERSION (\d+)", open(os.path.join(ROOT, "include", "fpq.h")).read()).group(1))
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.fpq_version() == 115
+    assert lib.fpq_version() == FPQ_VERSION
     assert lib.fpq_strerror(0) == b"ok"
     for code in range(-6, 0):
         assert lib.fpq_strerror(code)
@@ -50,6 +51,9 @@ def test_version_and_errors(lib):
     assert lib.fpq_quant_nearest(None, None, None, 4, 15, 0, None) == -2
     assert lib.fpq_quant_nearest(None, None, None, 0, 15, 1, None) == 0
     assert lib.fpq_quant_rows_codes(None, None, None, 4, 128, 3, 0, 1, None) == -3   # FP6 codes cannot be nibble-packed
+    assert lib.fpq_quant_tensor_argmin(None, None, None, None, 4, 0, 1, None) == -1  # no scale / workspace
+    assert lib.fpq_quant_tensor_argmin(None, None, None, None, 4, 5, 1, None) == -4  # half table
+    assert lib.fpq_quant_tensor_argmin(None, None, None, None, 4, 0, 2, None) == -2  # f64
 
 
 def test_tables_match_oracle(lib):
@@ -99,4 +103,4 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
         _lib.lib()
     monkeypatch.undo()
-    assert _lib.lib().fpq_version() == 115
+    assert _lib.lib().fpq_version() == FPQ_VERSION

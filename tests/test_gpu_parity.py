@@ -436,6 +436,10 @@ def test_full_size_metric_shape(dev, qu):
         q = ops.quant_nearest(xn, tab).view(xs.shape)
         want[lo:lo + 8192] = (q * scale).view(8192, 1920).to(torch.float16)
     assert_bits_equal(got, want, "full size vs unfused GPU sequence")
+    # the CPU oracle on row slices from both ends, the middle and around the injected all-zero group
+    for lo in (0, 16, 32768, 65536 - 64):
+        rows = slice(lo, lo + 64)
+        assert_bits_equal(got[rows], orc.per_group_kernel_sem(x[rows].cpu(), "e2m1", 128), f"full size rows {lo}.. vs oracle")
     # properties: every output is one of the 15 levels of its group; levels used are sane
     g = got.view(-1, 128).float()
     s = (x.view(-1, 128).abs().max(dim=-1, keepdim=True)[0] / 6.0).float()
