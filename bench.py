@@ -8,64 +8,174 @@ replacement through the C ABI), input and output resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU.  The path is
-embarrassingly parallel over 128-element groups, so each rank quantizes its own
-[65536 x 1920] shard with no data-path collective ("scaling": "weak"); the only
-collectives are the timing barrier and the MAX over ranks of the elapsed time.
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: WORLD_SIZE is set), or
+`python bench.py --gpus N` starts them itself - as a CHILD process (torch.distributed.run), before this process
+has touched a GPU - relays the child's output and exits with its return code.  A rank whose WORLD_SIZE differs
+from --gpus refuses to run.  The path is embarrassingly parallel over 128-element groups, so each rank quantizes
+its own [65536 x 1920] shards with no data-path collective ("scaling": "weak"); the only collectives of the timed
+region are the barrier and the MAX over ranks of the elapsed time.
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  Exit code 0 only when every part ran; a collective that blocks in the secondary
+(weight calibration) measurement is reported in the line AND by exit code 3.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 ROWS, COLS, GROUP = 65536, 1920, 128
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_ELEM = 4              # fp16 read + fp16 write (SURVEY.md section 8d)
-NBUF = 4                        # rotating buffer pairs, see main()
+NBUF = 4                        # rotating buffer pairs, see GpuPlatform.hot_path
+WATCHDOG_S = 240.0
+CALIB_DEPTH = 30                # VAR-d30 (BASELINE.json config 4)
+EXIT_COLLECTIVE_TIMEOUT = 3
 
 
-def cpu_baseline(sample_rows: int = 8192):
-    """The reference's pure-torch CPU path (tr/quant_utils.py:209-230,298-310:
-    abs -> max -> div -> |x - grid| -> argmin -> gather -> mul), restated in
-    oracle/fpq_oracle.py and validated against the reference's own output on the
-    golden vectors, timed on this box's host cores on a bounded sample.  torch's
-    intra-op pool is tried at all cores and at 32 threads (oversubscribing a
-    [N,15] elementwise graph with hundreds of threads is slower, not faster);
-    the better one is reported with the thread count actually used."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args, script, argv):
+    """`bench.py --gpus N` without a launcher: start N ranks as a child process and hand its exit code back.
+    Nothing here touches the GPU (no HIP call, no torch.cuda.is_available()), and the child is a fresh process,
+    never an exec of this one."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------ platform seam
+class GpuPlatform:
+    """Everything bench.py needs from the machine: device, collective backend, synchronisation, the hot-path step and
+    its timer.  tests/test_bench_contract.py swaps in a CPU / gloo stand-in to rehearse the control flow (launcher,
+    rank checks, collectives, JSON line) without a GPU; the numbers then mean nothing and say so in `data`."""
+    backend = "nccl"          # = RCCL on ROCm
+    data = "synthetic"
+
+    def __init__(self, local_rank):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.dev = torch.device("cuda", local_rank)
+
+    def init_dist(self, dist):
+        dist.init_process_group(self.backend, device_id=self.dev)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def empty_cache(self):
+        self.torch.cuda.empty_cache()
+
+    def hot_path(self, rank):
+        """NBUF distinct input/output pairs (NBUF x 503 MB) used round-robin: every step streams its tensor from HBM
+        and back; nothing is re-served by the 256 MiB Infinity Cache, as it would be if one 252 MB input were
+        quantized over and over (that variant runs ~12 % faster with cached loads and is NOT what is reported)."""
+        torch = self.torch
+        from fpqvar_amd import _lib
+        lib = _lib.lib()
+        xs, outs = [], []
+        for b in range(NBUF):
+            torch.manual_seed(rank * NBUF + b)   # buffer 0 of rank 0 = seed 0 = the SURVEY.md 8d primary input
+            xs.append(torch.randn(ROWS, COLS, device=self.dev).half())
+            outs.append(torch.empty(ROWS, COLS, device=self.dev, dtype=torch.float16))
+        self._keep = (xs, outs)
+        n_rows = xs[0].numel() // GROUP
+        self.stream = torch.cuda.current_stream(self.dev)
+        sp = self.stream.cuda_stream
+        ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in zip(xs, outs)]
+        counter = [0]
+
+        def step():
+            xp, op = ptrs[counter[0] % NBUF]
+            counter[0] += 1
+            st = lib.fpq_quant_rows(xp, op, n_rows, GROUP, _lib.TABLE_IDS["e2m1"], _lib.F16, _lib.F16, sp)
+            if st != 0:
+                _lib.check(st, "fpq_quant_rows")
+
+        return step, xs[0].numel(), xs[0]
+
+    def release_hot_path(self):
+        self._keep = None
+        self.empty_cache()
+
+    def timer(self):
+        """HIP events on the stream the kernel is launched on."""
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = self.stream
+        return (lambda: ev0.record(stream)), (lambda: ev1.record(stream)), (lambda: ev0.elapsed_time(ev1))
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(sample_rows: int = 8192, budget_s: float = 28.0):
+    """The reference's pure-torch CPU path (tr/quant_utils.py:209-230,298-310: abs -> max -> div -> |x - grid| ->
+    argmin -> gather -> mul), restated in oracle/fpq_oracle.py and validated against the reference's own output on the
+    golden vectors, timed on this box's host cores on a bounded sample of the metric's workload, in fp32 AND fp16
+    (SURVEY.md 8d).  Per dtype: one warm-up run, then the minimum of >= 5 runs (more while the time budget lasts).
+    torch's intra-op pool is tried at all cores and at 32 threads (oversubscribing a [N,15] elementwise graph with
+    hundreds of threads is slower, not faster); the better one is reported with the thread count actually used."""
+    import torch
     from oracle import fpq_oracle as orc
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(sample_rows, COLS, generator=g)          # fp32, as the CPU path is used on weights
+    x32 = torch.randn(sample_rows, COLS, generator=g)
     all_cores = os.cpu_count() or 1
-    best, best_threads, runs_done = float("inf"), all_cores, 0
-    deadline = time.perf_counter() + 25.0
-    for threads in sorted({all_cores, min(32, all_cores)}, reverse=True):
+    t_start = time.perf_counter()
+
+    def measure(x, threads, min_runs, deadline):
         torch.set_num_threads(threads)
-        for run in range(4):
-            if run > 1 and time.perf_counter() > deadline:
-                break
+        orc.per_group_argmin_sem(x.clone(), "e2m1", GROUP, clamp3=False)       # warm-up, discarded
+        best, runs = float("inf"), 0
+        while runs < min_runs or (runs < 12 and time.perf_counter() < deadline):
             xi = x.clone()
             t0 = time.perf_counter()
             orc.per_group_argmin_sem(xi, "e2m1", GROUP, clamp3=False)
-            dt = time.perf_counter() - t0
-            if run > 0 and dt < best:
-                best, best_threads = dt, threads
-            runs_done += 1
-    res = {"value": round(x.numel() / best / 1e9, 5), "unit": "Gelem/s", "cores": best_threads, "kind": "port",
-           "sample": f"fp32 [{sample_rows}x{COLS}] g={GROUP} E2M1, torch-op restatement of the reference CPU path "
-                     f"(argmin over a [N,15] distance tensor), best of {runs_done} runs over thread counts "
-                     f"{{{all_cores},{min(32, all_cores)}}}, first run of each discarded"}
-    try:   # second figure: the scalar C restatement of the kernel-semantics path, one core
+            best = min(best, time.perf_counter() - t0)
+            runs += 1
+        return best, runs
+
+    out = {}
+    thread_opts = sorted({all_cores, min(32, all_cores)}, reverse=True)
+    for name, x in (("f32", x32), ("f16", x32.half())):
+        # pick the thread count on 2 quick runs each, then >= 5 timed runs at the better one
+        trial = {t: measure(x, t, 2, 0.0)[0] for t in thread_opts}
+        threads = min(trial, key=trial.get)
+        share = budget_s * (0.5 if name == "f32" else 1.0)
+        best, runs = measure(x, threads, 5, t_start + share)
+        best = min(best, trial[threads])
+        out[name] = {"Gelem_s": round(x.numel() / best / 1e9, 5), "cores": threads, "runs": runs + 2}
+    res = {"value": out["f32"]["Gelem_s"], "unit": "Gelem/s", "cores": out["f32"]["cores"], "kind": "port",
+           "sample": f"[{sample_rows}x{COLS}] g={GROUP} E2M1 of the metric's randn input, torch-op restatement of the "
+                     f"reference CPU path (argmin over a [N,15] distance tensor); value = fp32 (the dtype the reference "
+                     f"uses this path on); warm-up + min of >= 5 runs per dtype at the better of {thread_opts} threads",
+           "f32": out["f32"], "f16": out["f16"]}
+    try:   # third figure: the scalar C restatement of the kernel-semantics path, one core
         from oracle import c_oracle as co
-        xh = x[:1024].half()
+        xh = x32[:1024].half()
         co.rows(xh, orc.TABLES["e2m1"], GROUP)
         t0 = time.perf_counter()
         co.rows(xh, orc.TABLES["e2m1"], GROUP)
@@ -79,6 +189,7 @@ def cpu_baseline(sample_rows: int = 8192):
 def unfused_gpu_sequence(x, steps=3):
     """The reference's GPU op sequence (tr/quant_utils.py:313-330) as torch-ROCm ops
     around the L0 scan kernel: the 'before' picture on the same GPU."""
+    import torch
     from fpqvar_amd import ops
     tab = torch.tensor([-6.0, -4.0, -3.0, -2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
 
@@ -102,8 +213,9 @@ def unfused_gpu_sequence(x, steps=3):
 
 
 def other_kernels(dev):
-    """Secondary measurements on the same GPU (not the headline metric): the other
-    kernels of the path at the BASELINE shapes, each with its own byte denominator."""
+    """Secondary measurements on the same GPU (not the headline metric): the other kernels of the path at the
+    BASELINE shapes, each with its own byte denominator (DESIGN.md section 4 quotes THESE figures)."""
+    import torch
     from fpqvar_amd import ops, rotation as rot
     out = {}
 
@@ -122,112 +234,161 @@ def other_kernels(dev):
             best = min(best, e0.elapsed_time(e1) / iters)
         return best
 
+    def hbm(name, ms, nbytes):
+        out[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1),
+                     "frac_of_8TBps": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 3)}
+
+    def guarded(name, fn):
+        try:
+            fn()
+        except Exception as e:   # one broken secondary kernel must not hide the others
+            out[name] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+
     g = torch.Generator(device=dev).manual_seed(1)
-    hs = [torch.nn.functional.gelu(torch.randn(ROWS, 4 * COLS, device=dev, generator=g), approximate="tanh").half()
-          for _ in range(2)]
     k = [0]
 
     def nxt(lst):
         k[0] += 1
         return lst[k[0] % len(lst)]
 
-    ms = timed(lambda: ops.quant_rows_dual(nxt(hs), "e1m2_neg", "e2m1_pos", GROUP, 1.0))
-    n = hs[0].numel()
-    out["dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680"] = {"ms": round(ms, 4), "GBps": round(n * 4 / ms / 1e6, 1),
-                                                      "frac_of_8TBps": round(n * 4 / ms / 1e6 / HBM_PEAK_GBS, 3)}
-    del hs
-    xs = [torch.randn(ROWS, COLS, device=dev, generator=g).half() for _ in range(3)]
-    n = xs[0].numel()
-    ms = timed(lambda: rot.rotate_quant(nxt(xs), "e2m1"))
-    out["fused_rotate_quant_e2m1_fp16_65536x1920"] = {"ms": round(ms, 4), "GBps": round(n * 4 / ms / 1e6, 1),
-                                                      "frac_of_8TBps": round(n * 4 / ms / 1e6 / HBM_PEAK_GBS, 3)}
-    ms = timed(lambda: ops.quant_rows(nxt(xs), "e2m3", COLS, torch.float16))
-    out["fp6_e2m3_per_token_fp16_65536x1920"] = {"ms": round(ms, 4), "GBps": round(n * 4 / ms / 1e6, 1),
-                                                 "frac_of_8TBps": round(n * 4 / ms / 1e6 / HBM_PEAK_GBS, 3)}
-    ws = [torch.randn(ROWS // 2, COLS, device=dev, generator=g) * 0.02 for _ in range(3)]
-    n = ws[0].numel()
-    ms = timed(lambda: ops.quant_rows(nxt(ws), "e2m1", GROUP))
-    out["weights_e2m1_per_group_fp32_32768x1920"] = {"ms": round(ms, 4), "GBps": round(n * 8 / ms / 1e6, 1),
-                                                     "frac_of_8TBps": round(n * 8 / ms / 1e6 / HBM_PEAK_GBS, 3)}
-    del ws
-    # the consumers on the other side of the quantizers: matrix-core kernels, TFLOP/s
-    from fpqvar_amd import gemm
-    a = gemm.quantize_mx(xs[0])
-    w = gemm.quantize_mx(torch.randn(3 * COLS, COLS, device=dev, generator=g) * 0.02)
-    ms = timed(lambda: gemm.linear_fp4(*a, *w))
-    out["gemm_fp4_w4a4_mat_qkv_65536x1920x5760"] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * ROWS * COLS * 3 * COLS / ms / 1e9, 1)}
-    del a, w, xs
-    B, H, Lq, Lkv = 100, COLS // 64, 256, 680          # last scale step of a VAR-d30 256x256 batch
-    q = torch.nn.functional.normalize(torch.randn(B, Lq, H, 64, device=dev, generator=g), dim=-1).mul(8).half()
-    kk = torch.nn.functional.normalize(torch.randn(B, Lkv, H, 64, device=dev, generator=g), dim=-1).half()
-    vv = torch.randn(B, Lkv, H, 64, device=dev, generator=g).half()
-    ms = timed(lambda: ops.attention_blhc(q, kk, vv, 1.0))
-    out["attention_kv_cache_100x30_q256_kv680_c64"] = {"ms": round(ms, 4), "TFLOPs": round(4.0 * B * H * 64 * Lq * Lkv / ms / 1e9, 1)}
+    def fc2_inputs():
+        return [torch.nn.functional.gelu(torch.randn(ROWS, 4 * COLS, device=dev, generator=g), approximate="tanh").half()
+                for _ in range(2)]
+
+    def dual_fp4():
+        hs = fc2_inputs()
+        hbm("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680",
+            timed(lambda: ops.quant_rows_dual(nxt(hs), "e1m2_neg", "e2m1_pos", GROUP, 1.0)), hs[0].numel() * 4)
+
+    def dual_fp6():
+        hs = fc2_inputs()
+        n = hs[0].numel()
+        hbm("dual_fc2_intneg_e2m3pos_per_group_fp16_65536x7680",
+            timed(lambda: ops.quant_rows_dual(nxt(hs), "int_neg", "e2m3_pos", GROUP, None)), n * 4)
+        hbm("dual_fc2_intneg_e2m3pos_per_token_fp16_65536x7680",
+            timed(lambda: ops.quant_rows_dual(nxt(hs), "int_neg", "e2m3_pos", 4 * COLS, None)), n * 4)
+
+    def act16():
+        xs = [torch.randn(ROWS, COLS, device=dev, generator=g).half() for _ in range(3)]
+        n = xs[0].numel()
+        hbm("fused_rotate_quant_e2m1_fp16_65536x1920", timed(lambda: rot.rotate_quant(nxt(xs), "e2m1")), n * 4)
+        hbm("fp6_e2m3_per_token_fp16_65536x1920", timed(lambda: ops.quant_rows(nxt(xs), "e2m3", COLS, torch.float16)), n * 4)
+        # the complete producer (LayerNorm + AdaLN modulate + smooth + rotate + quant): B = 100 conditioned rows of a
+        # d30 batch, L = 655 tokens each (= 65500 rows)
+        B, L = 100, 655
+        xa = [xs[i][:B * L].view(B, L, COLS) for i in range(3)]
+        scale = (torch.randn(B, 1, COLS, device=dev, generator=g) * 0.3).half()
+        shift = (torch.randn(B, 1, COLS, device=dev, generator=g) * 0.3).half()
+        s = torch.rand(COLS, device=dev, generator=g) + 0.5
+        hbm("adaln_rotate_quant_e2m1_fp16_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant(nxt(xa), scale, shift, "e2m1", smooth=s)), B * L * COLS * 4)
+
+    def weights():
+        ws = [torch.randn(ROWS // 2, COLS, device=dev, generator=g) * 0.02 for _ in range(3)]
+        n = ws[0].numel()
+        hbm("weights_e2m1_per_group_fp32_to_fp32_32768x1920", timed(lambda: ops.quant_rows(nxt(ws), "e2m1", GROUP)), n * 8)
+        hbm("weights_e2m1_per_group_fp32_to_fp16_32768x1920",
+            timed(lambda: ops.quant_rows(nxt(ws), "e2m1", GROUP, torch.float16)), n * 6)
+        hbm("weights_e2m3_per_channel_fp32_to_fp16_32768x1920",
+            timed(lambda: ops.quant_rows(nxt(ws), "e2m3", COLS, torch.float16)), n * 6)
+
+    def consumers():
+        # the consumers on the other side of the quantizers: matrix-core kernels, TFLOP/s
+        from fpqvar_amd import gemm
+        x = torch.randn(ROWS, COLS, device=dev, generator=g).half()
+        a = gemm.quantize_mx(x)
+        w = gemm.quantize_mx(torch.randn(3 * COLS, COLS, device=dev, generator=g) * 0.02)
+        ms = timed(lambda: gemm.linear_fp4(*a, *w))
+        out["gemm_fp4_w4a4_mat_qkv_65536x1920x5760"] = {"ms": round(ms, 4),
+                                                        "TFLOPs": round(2.0 * ROWS * COLS * 3 * COLS / ms / 1e9, 1)}
+
+    guarded("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4)
+    guarded("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6)
+    guarded("activations_fp16_65536x1920", act16)
+    guarded("weights_fp32_32768x1920", weights)
+    guarded("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", consumers)
     return out
 
 
-def weight_calibration(dev, dist, world, rank, depth=30, iters=3):
+# ------------------------------------------------------------------------------------------------ config 4
+def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=3):
     """BASELINE.json config 4: every Linear weight of VAR-d30 (1.327 G fp32 elements, synthetic randn*0.02) quantized
     per-group(128) E2M1 -> fp16, layers partitioned over the ranks (fpqvar_amd.calibrate.partition), each rank
     materialising and quantizing only its own share ("ms": no collective on the data path, max over ranks), and, at
     N > 1, the same followed by the ONE all-gather that leaves every rank with the whole quantized model
     ("ms_with_all_gather": calibrate.calibrate_sharded, fp16 exchange over RCCL).  Strong scaling (the model is fixed).
-    Secondary measurement, never the headline value."""
+    Secondary measurement, never the headline value.  `stage[0]` names what is running (for the watchdog); every
+    failure is reported as {"error": ...}, never swallowed."""
+    import torch
+    depth = CALIB_DEPTH if depth is None else depth
+    dev = plat.dev
     dt, dt_g = float("nan"), float("nan")
     total = 0
-    ok = True
+    err = None
+    own, shapes, cal = {}, {}, None
     try:
+        stage[0] = "local quantization"
         from fpqvar_amd import calibrate as cal
-        quantize = cal.default_weight_quantizer()      # fp32 -> per-group E2M1 -> fp16 in one launch
         shapes = cal.var_linear_shapes(depth)
         sizes = [(n, o * i) for n, (o, i) in shapes.items()]
         total = sum(sz for _, sz in sizes)
         mine = cal.partition(sizes, world)[rank]
         torch.manual_seed(1000 + rank)
         own = {n: torch.randn(*shapes[n], device=dev) * 0.02 for n in mine}
-        for n in mine[:4]:
-            quantize(n, own[n])
-        torch.cuda.synchronize()
+        local = cal.LocalShard(own, shapes)            # segment table + output slab, built once (not timed)
+        local.quantize()
+        plat.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            outs = [quantize(n, own[n]) for n in mine]
-        torch.cuda.synchronize()
+            local.quantize()                           # ONE launch over all of this rank's layers
+        plat.synchronize()
         dt = (time.perf_counter() - t0) / iters
-        del outs
-    except Exception:      # secondary measurement: never take the headline line down with it
-        ok = False
+        del local
+    except Exception as e:
+        err = f"local quantization: {e!r}"[:300]
     if dist is not None:   # every rank reaches these collectives, whatever happened above
-        flag = torch.tensor([1.0 if ok else 0.0, dt if dt == dt else 1e30], device=dev, dtype=torch.float64)
+        stage[0] = "all_reduce of the local status"
+        flag = torch.tensor([0.0 if err else 1.0, dt if dt == dt else 1e30], device=dev, dtype=torch.float64)
         mn = flag.clone()
         dist.all_reduce(mn, op=dist.ReduceOp.MIN)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        ok, dt = bool(mn[0].item() > 0.5), float(flag[1].item())
-        if ok:             # all ranks are healthy: time the gathered form (same code path on every rank)
+        all_ok, dt = bool(mn[0].item() > 0.5), float(flag[1].item())
+        if not all_ok and err is None:
+            err = "local quantization failed on another rank"
+        if all_ok:         # all ranks are healthy: time the gathered form (same code path on every rank)
             try:
-                weights = {n: (own[n] if n in own else torch.empty(shapes[n], device=dev)) for n in shapes}
-                cal.calibrate_sharded(weights, gather=True, exchange="fp16")
-                torch.cuda.synchronize()
+                stage[0] = "sharded calibration + all_gather_into_tensor"
+                plan = cal.ShardedCalibration(shapes, own, group=None)   # slab + segment table, built once (not timed)
+                plan.run()
+                plat.synchronize()
                 dist.barrier()
                 t0 = time.perf_counter()
                 for _ in range(iters):
-                    cal.calibrate_sharded(weights, gather=True, exchange="fp16")
-                torch.cuda.synchronize()
+                    plan.run()
+                plat.synchronize()
                 dist.barrier()
                 t = torch.tensor([(time.perf_counter() - t0) / iters], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_g = float(t.item())
-                del weights
-            except Exception:
-                dt_g = float("nan")
+                del plan
+            except Exception as e:
+                err = f"gathered calibration: {e!r}"[:300]
+    stage[0] = "done"
     try:
-        del own
-        torch.cuda.empty_cache()
+        own.clear()
+        plat.empty_cache()
     except Exception:
         pass
-    if rank != 0 or not ok or not (dt < 1e29) or total == 0:
+    if rank != 0:
         return None
-    res = {"workload": f"VAR-d{depth} all-Linear weights fp32 -> per-group(128) E2M1 -> fp16, layers sharded over the ranks",
+    if err is not None or not (dt < 1e29) or total == 0:
+        return {"error": err or "no timing"}
+    res = {"workload": f"VAR-d{depth} all-Linear weights fp32 -> per-group(128) E2M1 -> fp16, layers sharded over the ranks, "
+                       "one launch per rank over a segment table",
            "elements": total, "n_gpus": world, "ms": round(dt * 1e3, 3), "Gelem_s": round(total / dt / 1e9, 1),
+           "GBps_at_6B_per_elem": round(total * 6 / dt / 1e9, 1),
+           "frac_of_8TBps_per_gpu": round(total * 6 / dt / 1e9 / world / HBM_PEAK_GBS, 3),
            "scaling": "strong"}
     if dt_g == dt_g:
         res["ms_with_all_gather"] = round(dt_g * 1e3, 3)
@@ -237,28 +398,31 @@ def weight_calibration(dev, dist, world, rank, depth=30, iters=3):
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (null if none)."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(p):
-        try:
-            with open(p) as f:
-                return json.load(f).get("traffic_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+    """HBM bytes per launch of the headline kernel.  NOT measured by this process (rocprofv3 counters cannot be read
+    from inside the run): the figure of the committed rocprofv3 --pmc passes of this same command, with its source."""
+    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                with open(p) as f:
+                    return json.load(f).get("traffic_bytes_per_launch"), f"profiles/{name}"
+            except Exception:
+                continue
+    return None, None
 
 
-def build_result(args, world, x, elapsed, kernel_ms, calib):
+def build_result(args, world, elems, elapsed, kernel_ms, calib, rccl_ranks, data):
     """The contract line (everything the timed region determines)."""
-    elems = x.numel()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * elems / (elapsed / args.steps) / 1e9
     achieved = elems * BYTES_PER_ELEM / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic()
     res = {
         "metric": "Gelements/s + achieved HBM GB/s, per-group FP4 quant [65536x1920,g=128]",
         "value": round(value, 3),
         "unit": "Gelem/s",
         "n_gpus": world,
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5),
@@ -266,14 +430,17 @@ def build_result(args, world, x, elapsed, kernel_ms, calib):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f16",
-        "data": "synthetic",
+        "data": data,
         "config": {"workload": "fp16 [65536x1920] randn, per-group(128) FP4 E2M1 fake-quant, fp16 out; "
                                f"{NBUF} distinct tensors per GPU used round-robin (cold HBM every step); "
                                "one shard of this shape per GPU, no data-path collective",
                    "rows": ROWS, "cols": COLS, "group": GROUP, "format": "fp_e2 (E2M1)",
                    "parallelism": f"shard{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                        "from an earlier run (gfx950 FETCH_SIZE x2 correction applied); a constant, not a "
+                                        "measurement of this timed region") if traffic_src else None,
                      "kernel": "rows16_lut_subwave_kernel<16 lanes/group, U=2>",
                      "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes": elems * BYTES_PER_ELEM},
@@ -283,110 +450,91 @@ def build_result(args, world, x, elapsed, kernel_ms, calib):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None, script=None, platform_factory=GpuPlatform):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    script = script or os.path.abspath(__file__)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, script, argv))     # parent: start the ranks, relay, hand the code back
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank "
+                         f"run as a {args.gpus}-GPU figure")
+    import torch
+    plat = platform_factory(local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        plat.init_dist(dist)
+        rccl_ranks = dist.get_world_size()
+        if rccl_ranks != world:
+            raise SystemExit(f"bench.py: the process group has {rccl_ranks} ranks, WORLD_SIZE says {world}")
 
-    from fpqvar_amd import _lib
-    lib = _lib.lib()
-
-    # NBUF distinct input/output pairs (NBUF x 503 MB) used round-robin: every step streams
-    # its tensor from HBM and back; nothing is re-served by the 256 MiB Infinity Cache, as it
-    # would be if one 252 MB input were quantized over and over (that variant runs ~12 % faster
-    # with cached loads and is NOT what is reported).
-    xs, outs = [], []
-    for b in range(NBUF):
-        torch.manual_seed(rank * NBUF + b)   # buffer 0 of rank 0 = seed 0 = the SURVEY.md 8d primary input
-        xs.append(torch.randn(ROWS, COLS, device=dev).half())
-        outs.append(torch.empty(ROWS, COLS, device=dev, dtype=torch.float16))
-    x = xs[0]
-    n_rows = x.numel() // GROUP
-    stream = torch.cuda.current_stream(dev)
-    sp = stream.cuda_stream
-    ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in zip(xs, outs)]
-    counter = [0]
-
-    def step():
-        xp, op = ptrs[counter[0] % NBUF]
-        counter[0] += 1
-        st = lib.fpq_quant_rows(xp, op, n_rows, GROUP, _lib.TABLE_IDS["e2m1"], _lib.F16, _lib.F16, sp)
-        if st != 0:
-            _lib.check(st, "fpq_quant_rows")
-
+    step, elems, x0 = plat.hot_path(rank)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    plat.synchronize()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    plat.synchronize()
+    start, stop, elapsed_ms = plat.timer()
     t0 = time.perf_counter()
-    ev0.record(stream)            # same stream the kernel is launched on
+    start()                       # same stream the kernel is launched on
     for _ in range(args.steps):
         step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
+    stop()
+    plat.synchronize()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    plat.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps        # average launch duration, HIP events
+    kernel_ms = elapsed_ms() / args.steps                 # average launch duration, HIP events
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=plat.dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def headline(calib):
+        return build_result(args, world, elems, elapsed, kernel_ms, calib, rccl_ranks, plat.data)
+
     # The sharded calibration (with its all-gather at N > 1) is a secondary measurement taken AFTER the timed region.
-    # Should a collective in it ever block, a watchdog prints the headline line without it and ends the process, so
-    # that the driver still gets its JSON line.
-    import threading
-    calib_box, calib_done = {}, threading.Event()
+    # Should a collective in it block, the watchdog reports that IN the line and ends the process with a non-zero
+    # exit code: a hang is never reported as success.
+    calib_done, stage = threading.Event(), ["starting"]
 
-    def _headline(calib):
-        return build_result(args, world, x, elapsed, kernel_ms, calib)
-
-    def _watchdog():
-        if not calib_done.wait(240.0):
+    def watchdog():
+        if not calib_done.wait(WATCHDOG_S):
             if rank == 0:
-                print(json.dumps(_headline(None)), flush=True)
-            os._exit(0)
+                print(json.dumps(headline({"error": f"timeout after {WATCHDOG_S:.0f} s in {stage[0]}"})), flush=True)
+            os._exit(EXIT_COLLECTIVE_TIMEOUT)
 
     if world > 1:
-        threading.Thread(target=_watchdog, daemon=True).start()
-    calib = weight_calibration(dev, dist, world, rank)
+        threading.Thread(target=watchdog, daemon=True).start()
+    calib = weight_calibration(plat, dist, world, rank, stage)
     calib_done.set()
 
     if rank == 0:
-        res = _headline(calib)
+        res = headline(calib)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["unfused_gpu"] = unfused_gpu_sequence(x)
+                res["unfused_gpu"] = unfused_gpu_sequence(x0)
             except Exception as e:  # extra information only
-                res["unfused_gpu"] = {"error": str(e)[:200]}
+                res["unfused_gpu"] = {"error": repr(e)[:200]}
+            del x0
+            plat.release_hot_path()
             try:
-                del xs, outs
-                torch.cuda.empty_cache()
-                res["other_kernels"] = other_kernels(dev)
+                res["other_kernels"] = other_kernels(plat.dev)
             except Exception as e:
-                res["other_kernels"] = {"error": str(e)[:200]}
+                res["other_kernels"] = {"error": repr(e)[:200]}
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if dist is not None:

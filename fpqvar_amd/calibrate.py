@@ -6,19 +6,25 @@ The reference quantizes the weight of every Linear once, on one GPU, inside
 (evaluate_fp_quant_transform_rotate.py:131).  Every layer - every 128-group, in
 fact - is independent, so here the layers are partitioned over the ranks of a
 ``torch.distributed`` group (one process per GPU, RCCL over xGMI), each rank
-quantizes its share with the fused HIP kernels, and ONE all-gather hands every rank
-the complete quantized model.  There is no other collective on this path.
+quantizes its share, and ONE all-gather hands every rank the complete quantized
+model.  There is no other collective on this path.
+
+Data layout: ONE slab ``[world, width]`` of the exchange dtype per rank, ``width`` = the largest
+shard.  A rank's layers are quantized by ONE launch over a device-resident segment table
+(``fpq_quant_rows_segments``: fp32 in -> per-group fake-quant -> fp16 out, i.e. the reference's fp32
+quantization followed by ``.half()``) that writes straight into the rank's own slot of the slab;
+``all_gather_into_tensor`` (in place: the input is that slot) fills the other slots; the result
+tensors are views of the slab.  No staging copy, no per-layer launch, no list-form gather.
 
 Exchange formats:
   * ``"fp16"``  - the de-quantized fp16 weights themselves (what the reference keeps
                   after ``.half()``): 2 B/element on the wire.
   * ``"codes"`` - 4-bit codes (two per byte) + one fp32 scale per 128-group =
                   0.53 B/element; decoded locally with ``fpq_dequant_rows_codes``.
-                  Per-group FP4 tables only.  Bit-identical to ``"fp16"``.
+                  Per-group FP4 E2M1 only.  Bit-identical to ``"fp16"``.
 
-The quantizer is injected (``quantize=``) so that the partition / packing /
-collective logic is testable on CPU with gloo; the default is the HIP path and
-raises without a GPU.
+A quantizer can be injected (``quantize=``) so that the partition / slab / collective logic is
+testable on CPU with gloo; the default is the HIP path and raises without a GPU.
 """
 from __future__ import annotations
 
@@ -27,6 +33,9 @@ from typing import Callable, Dict, List, Mapping, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+_GROUP = 128
+_FP_TABLES = {"fp_e1": "e1m2", "fp_e2": "e2m1", "fp_e3": "e3m0", "fp6_e2m3": "e2m3", "fp6_e3m2": "e3m2"}
 
 
 def var_linear_shapes(depth: int) -> "OrderedDict[str, Tuple[int, int]]":
@@ -52,22 +61,23 @@ def partition(sizes: Sequence[Tuple[str, int]], world: int) -> List[List[str]]:
         r = min(range(world), key=lambda k: (load[k], k))
         out[r].append(sizes[i][0])
         load[r] += sizes[i][1]
+    pos = {s[0]: i for i, s in enumerate(sizes)}
     for names in out:
-        names.sort(key=lambda n: [s[0] for s in sizes].index(n))
+        names.sort(key=pos.__getitem__)
     return out
 
 
 def default_weight_quantizer(weight_quant: str = "per_group", weight_fp_type: str = "fp_e2", w_bit: int = 4,
                              out_dtype: torch.dtype = torch.float16) -> Callable[[str, torch.Tensor], torch.Tensor]:
     """The from_float dispatch for FP formats (tr/quant_utils.py:794-855), fused with
-    the driver's later ``.half()``: out = fp16(fp32 quantized weight)."""
+    the driver's later ``.half()``: out = fp16(fp32 quantized weight).  One layer per call."""
     from . import ops
-    table = {"fp_e1": "e1m2", "fp_e2": "e2m1", "fp_e3": "e3m0", "fp6_e2m3": "e2m3", "fp6_e3m2": "e3m2"}[weight_fp_type]
+    table = _FP_TABLES[weight_fp_type]
     assert (w_bit == 6) == weight_fp_type.startswith("fp6")
 
     def quantize(name: str, w: torch.Tensor) -> torch.Tensor:
         if weight_quant == "per_group":
-            return ops.quant_rows(w, table, 128, out_dtype)
+            return ops.quant_rows(w, table, _GROUP, out_dtype)
         if weight_quant == "per_channel" and weight_fp_type.startswith("fp6"):
             return ops.quant_rows(w, table, w.shape[-1], out_dtype)
         raise NotImplementedError(f"weight_quant={weight_quant} with {weight_fp_type}")
@@ -81,6 +91,129 @@ def _world(group) -> Tuple[int, int]:
     return 0, 1
 
 
+class LocalShard:
+    """A set of fp32 layers (this rank's share) quantized per group of 128 by ONE launch.
+
+    `weights`: name -> fp32 GPU tensor (numel % 128 == 0).  `out`: optional 1-D tensor of `out_dtype` with room for
+    all of them back to back (e.g. this rank's slot of the all-gather slab); allocated when omitted.  The segment
+    table (input pointer, output pointer, group count per layer) is uploaded once here; `quantize()` is then a single
+    C-ABI call with no host work besides the launch."""
+
+    def __init__(self, weights: Mapping[str, torch.Tensor], shapes: Optional[Mapping[str, Tuple[int, ...]]] = None,
+                 weight_fp_type: str = "fp_e2", out: Optional[torch.Tensor] = None,
+                 out_dtype: torch.dtype = torch.float16):
+        from . import _lib
+        self._lib = _lib
+        self.table_id = _lib.TABLE_IDS[_FP_TABLES[weight_fp_type]]
+        self.names = list(weights.keys())
+        self.shapes = {n: tuple(shapes[n]) if shapes is not None else tuple(weights[n].shape) for n in self.names}
+        self.out_dtype = out_dtype
+        self._inputs = []
+        self.offsets: Dict[str, int] = {}
+        total = 0
+        for n in self.names:
+            w = weights[n]
+            _lib.require_gpu(w, f"LocalShard({n})")
+            if w.dtype != torch.float32:
+                raise RuntimeError(f"LocalShard: {n} must be float32 (the reference quantizes the fp32 weight), got {w.dtype}")
+            if w.numel() % _GROUP != 0:
+                raise RuntimeError(f"LocalShard: {n} has {w.numel()} elements, not a multiple of the group size {_GROUP}")
+            w = w if w.is_contiguous() else w.contiguous()
+            if w.data_ptr() % 16 != 0:
+                w = w.clone()
+            self._inputs.append(w)
+            self.offsets[n] = total
+            total += w.numel()
+        self.total = total
+        dev = self._inputs[0].device if self._inputs else (out.device if out is not None else torch.device("cuda"))
+        self.device = dev
+        if out is None:
+            out = torch.empty(total, dtype=out_dtype, device=dev)
+        if out.dtype != out_dtype or out.dim() != 1 or out.numel() < total or not out.is_contiguous() or \
+                out.data_ptr() % 16 != 0:
+            raise RuntimeError("LocalShard: `out` must be a contiguous, 16-byte aligned 1-D tensor of the output dtype "
+                               "with room for every layer")
+        self.slab = out
+        esz = out.element_size()
+        rows = [w.numel() // _GROUP for w in self._inputs]
+        self.max_rows = max(rows) if rows else 0
+        desc = [[w.data_ptr(), out.data_ptr() + self.offsets[n] * esz, r] for n, w, r in zip(self.names, self._inputs, rows)]
+        self._table = torch.tensor(desc, dtype=torch.int64).reshape(-1, 3).to(dev) if desc else None
+
+    def quantize(self) -> torch.Tensor:
+        """Enqueue the launch on the current stream; returns the slab."""
+        if self._table is None:
+            return self.slab
+        lib, _lib = self._lib.lib(), self._lib
+        with torch.cuda.device(self.device):
+            _lib.check(lib.fpq_quant_rows_segments(self._table.data_ptr(), len(self.names), self.max_rows, _GROUP,
+                                                   self.table_id, _lib.F32, _lib.dtype_id(self.out_dtype),
+                                                   _lib.stream_ptr(self.device)), "fpq_quant_rows_segments")
+        return self.slab
+
+    def views(self) -> Dict[str, torch.Tensor]:
+        return {n: self.slab[self.offsets[n]:self.offsets[n] + _numel(self.shapes[n])].view(self.shapes[n])
+                for n in self.names}
+
+
+def _numel(shape) -> int:
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+class _Plan:
+    """Who owns what and where it lives in the [world, width] slab (identical on every rank)."""
+
+    def __init__(self, shapes: Mapping[str, Tuple[int, ...]], world: int):
+        self.names = list(shapes.keys())
+        self.shapes = {n: tuple(shapes[n]) for n in self.names}
+        self.numel = {n: _numel(self.shapes[n]) for n in self.names}
+        self.owners = partition([(n, self.numel[n]) for n in self.names], world)
+        self.width = max(sum(self.numel[n] for n in names) for names in self.owners) if self.names else 0
+        self.width = (self.width + 7) // 8 * 8           # keep every slot 16-byte aligned in fp16
+        self.where: Dict[str, Tuple[int, int]] = {}
+        for r, names in enumerate(self.owners):
+            off = 0
+            for n in names:
+                self.where[n] = (r, off)
+                off += self.numel[n]
+
+
+class ShardedCalibration:
+    """calibrate_sharded's HIP path as a reusable object: slab and segment table are built once, `run()` is one
+    launch + (world > 1) one in-place all_gather_into_tensor.  `weights` needs entries for the layers THIS rank owns
+    only (``plan_owners(shapes, world)[rank]``)."""
+
+    def __init__(self, shapes: Mapping[str, Tuple[int, ...]], weights: Mapping[str, torch.Tensor], group=None,
+                 weight_fp_type: str = "fp_e2"):
+        self.group = group
+        self.rank, self.world = _world(group)
+        self.plan = _Plan(shapes, self.world)
+        mine = self.plan.owners[self.rank]
+        ref = next((weights[n] for n in mine), None)
+        if ref is None:
+            ref = next(iter(weights.values()))
+        self.slab = torch.empty((self.world, self.plan.width), dtype=torch.float16, device=ref.device)
+        self.local = LocalShard(OrderedDict((n, weights[n]) for n in mine), self.plan.shapes, weight_fp_type,
+                                out=self.slab[self.rank])
+
+    def run(self) -> Dict[str, torch.Tensor]:
+        self.local.quantize()
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.slab.view(-1), self.slab[self.rank], group=self.group)   # THE collective
+        return self.views()
+
+    def views(self) -> Dict[str, torch.Tensor]:
+        p = self.plan
+        return {n: self.slab[p.where[n][0], p.where[n][1]:p.where[n][1] + p.numel[n]].view(p.shapes[n]) for n in p.names}
+
+
+def plan_owners(shapes: Mapping[str, Tuple[int, ...]], world: int) -> List[List[str]]:
+    return _Plan(shapes, world).owners
+
+
 def calibrate_sharded(weights: Mapping[str, torch.Tensor],
                       quantize: Optional[Callable[[str, torch.Tensor], torch.Tensor]] = None,
                       group=None, exchange: str = "fp16", gather: bool = True
@@ -90,84 +223,80 @@ def calibrate_sharded(weights: Mapping[str, torch.Tensor],
     `weights` must hold the same names/shapes on every rank (the values of layers a
     rank does not own are never read).  Returns name -> quantized tensor for all
     layers (gather=True) or for the local share only.
+
+    quantize=None: the HIP path (per-group(128) E2M1, fp32 -> fp16), one launch for the whole share.
+    quantize=f(name, w): any per-layer quantizer (tests inject a CPU one); its results are copied into the slab.
     """
     rank, world = _world(group)
-    names = list(weights.keys())
-    sizes = [(n, int(weights[n].numel())) for n in names]
-    plan = partition(sizes, world)
-    mine = plan[rank]
-    if quantize is None:
-        quantize = default_weight_quantizer()
-
     if exchange == "codes":
-        return _calibrate_codes(weights, plan, rank, world, group, gather)
+        if quantize is not None:
+            raise ValueError("exchange='codes' is the built-in per-group E2M1 path: it cannot take a custom `quantize`")
+        return _calibrate_codes(weights, rank, world, group, gather)
     if exchange != "fp16":
         raise ValueError(f"unknown exchange format {exchange!r}")
+    shapes = OrderedDict((n, tuple(w.shape)) for n, w in weights.items())
+    if quantize is None:
+        sc = ShardedCalibration(shapes, weights, group)
+        if gather:
+            return sc.run()
+        sc.local.quantize()
+        return sc.local.views()
 
+    plan = _Plan(shapes, world)
+    mine = plan.owners[rank]
     local = OrderedDict((n, quantize(n, weights[n])) for n in mine)
     if not gather or world == 1:
-        return dict(local)
-
+        return {n: local[n] for n in (mine if not gather else plan.names)}
     ref = next(iter(weights.values()))
     dtype = next(iter(local.values())).dtype if local else torch.float16
-    numel = {n: s for n, s in sizes}
-    shard = [sum(numel[n] for n in plan[r]) for r in range(world)]
-    width = max(shard)
-    send = torch.zeros(width, dtype=dtype, device=ref.device)
-    off = 0
+    slab = torch.empty((world, plan.width), dtype=dtype, device=ref.device)
     for n, q in local.items():
-        send[off:off + q.numel()] = q.reshape(-1)
-        off += q.numel()
-    recv = [torch.empty(width, dtype=dtype, device=ref.device) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)          # the one collective of this path
-    out: Dict[str, torch.Tensor] = {}
-    for r in range(world):
-        off = 0
-        for n in plan[r]:
-            out[n] = recv[r][off:off + numel[n]].view(weights[n].shape)
-            off += numel[n]
-    return {n: out[n] for n in names}
+        off = plan.where[n][1]
+        slab[rank, off:off + plan.numel[n]] = q.reshape(-1)
+    dist.all_gather_into_tensor(slab.view(-1), slab[rank], group=group)          # the one collective of this path
+    return {n: slab[plan.where[n][0], plan.where[n][1]:plan.where[n][1] + plan.numel[n]].view(plan.shapes[n])
+            for n in plan.names}
 
 
-def _calibrate_codes(weights, plan, rank, world, group, gather):
+def _calibrate_codes(weights, rank, world, group, gather):
     from . import ops
     names = list(weights.keys())
+    numel = {n: int(weights[n].numel()) for n in names}
+    plan = partition([(n, numel[n]) for n in names], world)
     mine = plan[rank]
     ref = next(iter(weights.values()))
     table = "e2m1"
-    numel = {n: int(weights[n].numel()) for n in names}
     for n in names:
-        assert numel[n] % 128 == 0
+        if numel[n] % _GROUP != 0:
+            raise RuntimeError(f"calibrate_sharded(exchange='codes'): {n} is not a multiple of {_GROUP} elements")
     code_bytes = {n: numel[n] // 2 for n in names}
-    n_scales = {n: numel[n] // 128 for n in names}
+    n_scales = {n: numel[n] // _GROUP for n in names}
     local_codes, local_scales = OrderedDict(), OrderedDict()
     for n in mine:
-        c, s = ops.quant_rows_codes(weights[n].float(), table, 128, pack_nibbles=True)
+        c, s = ops.quant_rows_codes(weights[n].float(), table, _GROUP, pack_nibbles=True)
         local_codes[n], local_scales[n] = c.reshape(-1), s.reshape(-1)
     if not gather or world == 1:
-        return {n: ops.dequant_rows_codes(local_codes[n].view(-1, 64), local_scales[n], table, 128,
+        return {n: ops.dequant_rows_codes(local_codes[n].view(-1, 64), local_scales[n], table, _GROUP,
                                           torch.float16, True).view(weights[n].shape) for n in mine}
     wc = max(sum(code_bytes[n] for n in plan[r]) for r in range(world))
+    wc = (wc + 15) // 16 * 16
     ws = max(sum(n_scales[n] for n in plan[r]) for r in range(world))
-    send = torch.zeros(wc + 4 * ws, dtype=torch.uint8, device=ref.device)
-    off = 0
+    slab = torch.empty((world, wc + 4 * ws), dtype=torch.uint8, device=ref.device)
+    off, soff = 0, wc
     for n in mine:
-        send[off:off + code_bytes[n]] = local_codes[n]
+        slab[rank, off:off + code_bytes[n]] = local_codes[n]
         off += code_bytes[n]
-    soff = wc
-    for n in mine:
         b = local_scales[n].contiguous().view(torch.uint8)
-        send[soff:soff + b.numel()] = b
+        slab[rank, soff:soff + b.numel()] = b
         soff += b.numel()
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    dist.all_gather_into_tensor(slab.view(-1), slab[rank], group=group)
     out = {}
     for r in range(world):
         off, soff = 0, wc
         for n in plan[r]:
-            codes = recv[r][off:off + code_bytes[n]].view(-1, 64)
-            scales = recv[r][soff:soff + 4 * n_scales[n]].view(torch.float32)
-            out[n] = ops.dequant_rows_codes(codes, scales, table, 128, torch.float16, True).view(weights[n].shape)
+            codes = slab[r, off:off + code_bytes[n]].view(-1, 64)
+            scales = slab[r, soff:soff + 4 * n_scales[n]].view(torch.float32)
+            out[n] = ops.dequant_rows_codes(codes, scales, table, _GROUP, torch.float16, True).view(weights[n].shape)
             off += code_bytes[n]
             soff += 4 * n_scales[n]
     return {n: out[n] for n in names}

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 }
 
 #include "fpq_fast16.h"
+#include "fpq_fast32.h"
 #include "fpq_gemm_fp4.h"   // the code-emitting quantizer kernels live beside their consumers;
 #include "fpq_gemm_fp8.h"   // the GEMM templates themselves are instantiated in fpq_gemm.hip
 #include "fpq_gemm_fp6.h"
@@ -1060,6 +1061,27 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   return go(rows16_lut_block_kernel<DUAL, 8, true>, rows16_lut_block_kernel<DUAL, 8, false>);
 }
 
+// ---- fp32 rows of 128 (weights): fpq_fast32.h -------------------------------------------------
+inline bool fast32_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int table_id) {
+  return in_dtype == FPQ_F32 && cols == 128 && kTables[table_id].symmetric && (((uintptr_t)x | (uintptr_t)out) & 15) == 0 &&
+         !getenv("FPQ_NO_FAST32");
+}
+
+// one tensor (segs == nullptr, `one` by value) or a device-resident segment table (grid.y = segment)
+inline int launch_fast32(const Seg32* segs, int n_segs, const Seg32& one, int64_t max_rows, int table_id, int out_dtype,
+                         hipStream_t st) {
+  constexpr int U = 4;
+  const Lut32Args a = lut32_args(table_id);
+  const int64_t tiles = (max_rows * 32 + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  if (tiles > 0x7FFFFFFF || n_segs > 65535) return FPQ_ERR_SHAPE;
+  const dim3 grid((unsigned)tiles, (unsigned)n_segs);
+  if (out_dtype == FPQ_F16)
+    hipLaunchKernelGGL((groups32_lut_kernel<_Float16, U>), grid, dim3(kBlock), 0, st, segs, one, a);
+  else
+    hipLaunchKernelGGL((groups32_lut_kernel<float, U>), grid, dim3(kBlock), 0, st, segs, one, a);
+  return check_launch();
+}
+
 // ---- F2: hardware-nibble codes + FP4 MFMA GEMM ---------------------------------------
 inline const Lut16Tab& lut16_mx_codes_e2m1() {
   static const Lut16Tab* tab = [] {
@@ -1227,10 +1249,27 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
     return launch_fast16<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
   if (fast16_block_eligible(x, out, cols, in_dtype, out_dtype))
     return launch_fast16_block<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
+  if (fast32_eligible(x, out, cols, in_dtype, table_id)) {
+    const Seg32 one = {x, out, rows};
+    return launch_fast32(nullptr, 1, one, rows, table_id, out_dtype, (hipStream_t)stream);
+  }
   DualArgs dual = {};
   dual.nan_flag = nullptr;
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,
                               (hipStream_t)stream);
+}
+
+int fpq_quant_rows_segments(const fpq_segment_t* segments_device, int n_segments, int64_t max_rows, int64_t cols,
+                            int table_id, int in_dtype, int out_dtype, fpq_stream_t stream) {
+  static_assert(sizeof(fpq_segment_t) == sizeof(Seg32), "fpq_segment_t and the kernels' Seg32 share one layout");
+  if (n_segments < 0 || max_rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F32 || (out_dtype != FPQ_F16 && out_dtype != FPQ_F32)) return FPQ_ERR_DTYPE;
+  if (cols != 128) return FPQ_ERR_SHAPE;
+  if (n_segments == 0 || max_rows == 0) return FPQ_OK;
+  if (!segments_device || (((uintptr_t)segments_device) & 7) != 0) return FPQ_ERR_ARG;
+  const Seg32 none = {nullptr, nullptr, 0};
+  return launch_fast32((const Seg32*)segments_device, n_segments, none, max_rows, table_id, out_dtype, (hipStream_t)stream);
 }
 
 int fpq_kv_cache_step(void* cache, int64_t batch, int64_t max_len, int64_t row_elems, int64_t quant_start,

@@ -69,6 +69,36 @@ def dequantize_mx(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
     return (q.view(codes.shape[0], -1, 128) * scales.float().unsqueeze(-1)).reshape(codes.shape[0], -1)
 
 
+class _ScaledOperandModule(torch.nn.Module):
+    """Base of the matrix-core Linears.  The quantization scales are fp32 in the reference (the weight is quantized in
+    fp32, tr/quant_utils.py:828-837); the driver's `var.half()` (evaluate_fp_quant_transform_rotate.py:131) must not
+    round them to fp16 - floating-point casts applied to the module (half(), to(dtype), float()) leave `w_scales`
+    alone, device moves still apply."""
+
+    def _apply(self, fn, recurse=True):
+        keep = self._buffers.get("w_scales")
+        super()._apply(fn, recurse)
+        moved = self._buffers.get("w_scales")
+        if keep is not None and moved is not None and moved.dtype != keep.dtype:
+            self._buffers["w_scales"] = keep.to(device=moved.device)
+        return self
+
+
+def _check_operand(what: str, codes: torch.Tensor, scales: torch.Tensor, rows: int, row_bytes: int, n_scales: int,
+                   device) -> None:
+    """Shapes, dtypes and placement of a (codes, scales) operand BEFORE the kernel sees the pointers: a truncated or
+    inconsistent operand is a Python error here, not an out-of-bounds read on the GPU."""
+    if codes.dtype != torch.uint8 or not codes.is_contiguous() or codes.device != device:
+        raise RuntimeError(f"{what}: codes must be a contiguous uint8 tensor on {device}")
+    if codes.numel() != rows * row_bytes:
+        raise RuntimeError(f"{what}: codes hold {codes.numel()} bytes, expected {rows} x {row_bytes}")
+    if scales.dtype not in (torch.float16, torch.float32) or not scales.is_contiguous() or scales.device != device:
+        raise RuntimeError(f"{what}: scales must be a contiguous float16 / float32 tensor on {device}")
+    if scales.numel() != n_scales:
+        raise RuntimeError(f"{what}: {scales.numel()} scales, expected {n_scales}")
+
+
+
 def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
                bias: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -76,9 +106,13 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     AdaLN block's `residual + y.mul(gate)` (tr/basic_var.py:264) is applied in the epilogue, bit-identical to the two
     torch ops on the plain result."""
     require_gpu(a_codes, "linear_fp4")
+    if a_codes.dim() != 2 or w_codes.dim() != 2:
+        raise RuntimeError("linear_fp4: codes must be [rows, K / 2]")
     tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
-    if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16:
+    if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16 or k % 128 != 0:
         raise RuntimeError("linear_fp4: operand shapes / activation scale dtype mismatch")
+    _check_operand("linear_fp4(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), a_codes.device)
+    _check_operand("linear_fp4(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), a_codes.device)
     ep, keep, out = _epilogue("linear_fp4", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
     with torch.cuda.device(a_codes.device):
@@ -89,7 +123,7 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     return out
 
 
-class FP4Linear(torch.nn.Module):
+class FP4Linear(_ScaledOperandModule):
     """Drop-in for QuantizedLinear in the W4A4 per-group `fp_e2` configuration that runs on the FP4
     matrix cores instead of simulating FP4 in fp16: weights are stored as hardware E2M1 codes + one
     fp32 scale per 128 input channels (4.25 bits per weight instead of 16), the
@@ -161,9 +195,13 @@ def linear_fp8(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP8 matrix cores (row-scaled operands); optional
     fused `residual + y.mul(gate)` as in linear_fp4."""
     require_gpu(a_codes, "linear_fp8")
+    if a_codes.dim() != 2 or w_codes.dim() != 2:
+        raise RuntimeError("linear_fp8: codes must be [rows, K]")
     tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1]
     if w_codes.shape[1] != k:
         raise RuntimeError("linear_fp8: operand shapes mismatch")
+    _check_operand("linear_fp8(activation)", a_codes, a_scales, tokens, k, tokens, a_codes.device)
+    _check_operand("linear_fp8(weight)", w_codes, w_scales, outs, k, outs, a_codes.device)
     ep, keep, out = _epilogue("linear_fp8", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
     with torch.cuda.device(a_codes.device):
@@ -174,7 +212,7 @@ def linear_fp8(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     return out
 
 
-class FP8Linear(torch.nn.Module):
+class FP8Linear(_ScaledOperandModule):
     """Drop-in for QuantizedLinear in the per_channel / per_token configurations (W6A6 `fp6_e2m3` / `fp6_e3m2`,
     run.sh:7) on the FP8 matrix cores: same quantization decisions as the reference (e4m3(code) * scale == its
     fake-quantized tensors), weights stored as one byte per element + one fp32 scale per output channel."""
@@ -239,9 +277,13 @@ def linear_fp6(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP6 matrix cores (row-scaled operands); optional
     fused `residual + y.mul(gate)` as in linear_fp4."""
     require_gpu(a_codes, "linear_fp6")
+    if a_codes.dim() != 2 or w_codes.dim() != 2:
+        raise RuntimeError("linear_fp6: codes must be [rows, K * 3 / 4]")
     tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 4 // 3
-    if w_codes.shape[1] != a_codes.shape[1]:
+    if w_codes.shape[1] != a_codes.shape[1] or a_codes.shape[1] % 3 != 0:
         raise RuntimeError("linear_fp6: operand shapes mismatch")
+    _check_operand("linear_fp6(activation)", a_codes, a_scales, tokens, a_codes.shape[1], tokens, a_codes.device)
+    _check_operand("linear_fp6(weight)", w_codes, w_scales, outs, a_codes.shape[1], outs, a_codes.device)
     ep, keep, out = _epilogue("linear_fp6", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
     with torch.cuda.device(a_codes.device):
@@ -252,7 +294,7 @@ def linear_fp6(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     return out
 
 
-class FP6Linear(torch.nn.Module):
+class FP6Linear(_ScaledOperandModule):
     """FP8Linear with 6-bit packed operands, for E2M3 activations x E2M3 weights (run.sh:7): 0.75 byte per weight."""
 
     def __init__(self, w_codes, w_scales, bias, in_features, out_features):

@@ -298,6 +298,14 @@ def dequant_rows_codes(codes: torch.Tensor, scales: torch.Tensor, table: str, co
                        out_dtype: torch.dtype, pack_nibbles: bool = False) -> torch.Tensor:
     require_gpu(codes, "dequant_rows_codes")
     rows = scales.numel()
+    row_bytes = (cols + 1) // 2 if pack_nibbles else cols
+    if codes.dtype != torch.uint8 or not codes.is_contiguous():
+        raise RuntimeError("dequant_rows_codes: codes must be a contiguous uint8 tensor")
+    if scales.device != codes.device or not scales.is_contiguous() or scales.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("dequant_rows_codes: scales must be a contiguous float16 / float32 tensor on the codes' device")
+    if cols <= 0 or codes.numel() != rows * row_bytes:
+        raise RuntimeError(f"dequant_rows_codes: {codes.numel()} code bytes do not match {rows} rows of {cols} "
+                           f"{'nibble-packed ' if pack_nibbles else ''}codes ({rows * row_bytes} bytes)")
     out = torch.empty((rows, cols), dtype=out_dtype, device=codes.device)
     with torch.cuda.device(codes.device):
         check(lib().fpq_dequant_rows_codes(codes.data_ptr(), scales.data_ptr(), out.data_ptr(), rows, cols,

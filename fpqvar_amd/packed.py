@@ -140,6 +140,38 @@ def save_packed(path: str, layers: Mapping[str, PackedWeight], extra: Optional[M
     return sum(t.numel() * t.element_size() for t in tensors.values())
 
 
+def _validate_entry(path, name, h, keys, f) -> None:
+    """Header against tensor sizes: a truncated or inconsistent file is refused here, before any kernel gets a
+    pointer whose extent it would trust."""
+    for k in ("table", "cols", "shape", "out_dtype", "rotate_block", "rotate_seed"):
+        if k not in h:
+            raise RuntimeError(f"{path}: layer {name}: header field {k!r} is missing")
+    if h["table"] not in FP4_TABLES + FP6_TABLES or h["out_dtype"] not in ("float16", "float32"):
+        raise RuntimeError(f"{path}: layer {name}: unknown table / dtype {h['table']!r} / {h['out_dtype']!r}")
+    if f"{name}.codes" not in keys or f"{name}.scales" not in keys:
+        raise RuntimeError(f"{path}: layer {name}: codes / scales tensor missing")
+    cols, numel = int(h["cols"]), 1
+    for d in h["shape"]:
+        numel *= int(d)
+    if cols <= 0 or numel % cols != 0:
+        raise RuntimeError(f"{path}: layer {name}: shape {h['shape']} is not a whole number of rows of {cols}")
+    rows = numel // cols
+    four = h["table"] in FP4_TABLES
+    if not four and cols % 4 != 0:
+        raise RuntimeError(f"{path}: layer {name}: 6-bit rows need a multiple of 4 columns")
+    row_bytes = (cols + 1) // 2 if four else cols * 3 // 4
+    cs, ss = f.get_slice(f"{name}.codes"), f.get_slice(f"{name}.scales")
+    n_codes, n_scales = 1, 1
+    for d in cs.get_shape():
+        n_codes *= int(d)
+    for d in ss.get_shape():
+        n_scales *= int(d)
+    if cs.get_dtype() != "U8" or n_codes != rows * row_bytes:
+        raise RuntimeError(f"{path}: layer {name}: codes hold {n_codes} {cs.get_dtype()} values, expected {rows * row_bytes} bytes")
+    if ss.get_dtype() not in ("F16", "F32") or n_scales != rows:
+        raise RuntimeError(f"{path}: layer {name}: {n_scales} {ss.get_dtype()} scales, expected {rows}")
+
+
 def load_packed(path: str, device="cpu") -> Dict[str, PackedWeight]:
     from safetensors import safe_open
     out: Dict[str, PackedWeight] = {}
@@ -150,6 +182,7 @@ def load_packed(path: str, device="cpu") -> Dict[str, PackedWeight]:
         header = json.loads(meta["layers"])
         keys = set(f.keys())
         for name, h in header.items():
+            _validate_entry(path, name, h, keys, f)
             out[name] = PackedWeight(
                 f.get_tensor(f"{name}.codes"), f.get_tensor(f"{name}.scales"), h["table"], int(h["cols"]),
                 tuple(h["shape"]), h["out_dtype"], int(h["rotate_block"]), int(h["rotate_seed"]),

@@ -65,8 +65,7 @@ def fp_quant_e2_per_group(x, n_bits, group_size=128):
     """No +-3 clamp here (commented out in the reference, :302).  The reference divides
     its argument in place through a view; this version leaves x untouched."""
     assert n_bits == 4
-    if not x.is_contiguous():
-        raise RuntimeError("view size is not compatible with input tensor's size and stride")
+    _require_input_viewable(x, group_size)
     return ops.quant_rows_argmin(x, "e2m1", group_size, clamp3=False)
 
 
@@ -179,13 +178,30 @@ def fp6_quant_int_neg_e2m3_pos_per_group_cuda(x, n_bits, group_size=128):
 
 def fp6_quant_int_neg_e2m3_pos_per_token_cuda(x, n_bits):
     assert n_bits == 6
-    _require_viewable(x)
+    _require_viewable(x, dual=True)
     return ops.quant_rows_dual(x, "int_neg", "e2m3_pos", x.shape[-1], None)
 
 
-def _require_viewable(x):
-    # the per-token reference functions call x.view(-1) after the division
-    # (tr/quant_utils.py:510,527,633): a non-contiguous input raises there too
+def _meta(x):
+    return torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device="meta")
+
+
+def _require_viewable(x, dual=False):
+    """The per-token reference functions flatten the RESULT of `x / scale` with .view(-1) (tr/quant_utils.py:510,
+    527,633-634).  Whether that works is decided by the strides torch gives that result: a dense but permuted x
+    (the BHLc attention layout) keeps its permutation and the view raises; a merely sliced x (k / v taken as
+    qkv.unbind(2) views, tr/basic_var.py:187-194) yields a contiguous quotient and the view works.  The same torch
+    ops on meta tensors (no memory, no launch) decide it here, with torch's own RuntimeError."""
+    if x.is_contiguous():
+        return
+    xm = _meta(x)
+    sm = torch.empty(tuple(x.shape[:-1]) + (1,), dtype=x.dtype, device="meta")
+    if dual:   # :614-646 normalises torch.where(x <= 0, x, zeros_like(x))
+        xm = torch.where(xm <= 0, xm, torch.zeros_like(xm))
+    (xm / sm).view(-1)
+
+
+def _require_input_viewable(x, group_size):
+    """fp_quant_e2_per_group views its ARGUMENT as (-1, group_size) (tr/quant_utils.py:302): torch's own stride rule."""
     if not x.is_contiguous():
-        raise RuntimeError("view size is not compatible with input tensor's size and stride "
-                           "(per-token FP6 quantizers need a contiguous input, as in the reference)")
+        _meta(x).view(-1, group_size)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 120 /* 0.1.2: + fpq_quant_tensor_argmin (round 2) */
+#define FPQ_VERSION 120 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments (round 2) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -247,6 +247,22 @@ int fpq_adaln_rotate_quant_token_rows_codes_fp6(const void* x, uint8_t* codes, v
  * as ONE scalar of `dtype` to `out`.  `out` must hold 4 bytes; it is zeroed on the
  * stream first (hipMemsetAsync) and then combined with device atomics. */
 int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream);
+
+/* Many tensors, ONE launch (weight calibration: every Linear a rank owns, QuantizedLinear.from_float's
+ * fp_quant_e{1,2,3}_per_group_cuda / fp6_quant_*_per_group_cuda on the fp32 weight, tr/quant_utils.py:828-855,
+ * with the driver's later var.half() as the F16 output form).  Same results as fpq_quant_rows per segment.
+ * segments_device: DEVICE-resident array of n_segments descriptors (the caller uploads it once and reuses it);
+ * every segment is `rows` contiguous rows of `cols` elements, x and out 16-byte aligned; segments may have
+ * different row counts, max_rows = the largest (sizes the grid: grid.y = segment, workgroups beyond a shorter
+ * segment's end exit at once).  This version: cols == 128, in_dtype F32, out_dtype F16 or F32, n_segments <= 65535.
+ * The descriptors' pointers are NOT validated (they live on the device): the caller guarantees them. */
+typedef struct {
+  const void* x;
+  void* out;
+  int64_t rows;
+} fpq_segment_t;
+int fpq_quant_rows_segments(const fpq_segment_t* segments_device, int n_segments, int64_t max_rows, int64_t cols,
+                            int table_id, int in_dtype, int out_dtype, fpq_stream_t stream);
 
 /* Per-tensor quantizer of the reference's pure-torch path (BASELINE.json config 1):
  *   replaces fp_quant_e2_per_tensor   search/baseline/plot_weight_distribution_for_motivation.py:285-294

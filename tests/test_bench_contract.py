@@ -47,44 +47,120 @@ def test_bench_prints_one_contract_line():
     assert res["value"] > 400
 
 
-def _calib_worker(rank, world, port, q):
-    import torch
-    import torch.distributed as dist
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import bench
-        from fpqvar_amd import calibrate as cal
-        from oracle import fpq_oracle as orc
-        # the HIP quantizer and the CUDA synchronisation points are replaced: this checks bench.py's control flow
-        # (every rank reaches every collective, the gathered form is timed at N > 1), not the kernels
-        cal.default_weight_quantizer = lambda *a, **k: (lambda name, w: orc.per_group_kernel_sem(w, "e2m1", 128).half())
-        torch.cuda.synchronize = lambda *a, **k: None
-        torch.cuda.empty_cache = lambda *a, **k: None
-        res = bench.weight_calibration(torch.device("cpu"), dist, world, rank, depth=2, iters=1)
-        q.put((rank, res))
-    finally:
-        dist.destroy_process_group()
+# ---- the N > 1 control flow, rehearsed on CPU: `bench.py --gpus 2` starts two ranks as a child process, the ranks
+# meet over gloo, every rank reaches every collective, rank 0 prints ONE line with n_gpus == 2.  The platform
+# (device, backend, the hot-path step) and the two HIP calibration classes are replaced by stand-ins in a launcher
+# script of the test's own: this checks bench.py's launcher / rank checks / collectives / JSON line, not the kernels.
+_REHEARSAL = '''
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch
+import bench
+from fpqvar_amd import calibrate as cal
+from oracle import fpq_oracle as orc
 
 
-def test_sharded_calibration_control_flow_gloo_world2():
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_calib_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=180) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert got[1] is None                                  # only rank 0 reports
-    r0 = got[0]
-    assert r0["n_gpus"] == 2 and r0["scaling"] == "strong" and r0["elements"] == 2 * 12 * 128 * 128
-    assert r0["ms"] > 0 and r0["ms_with_all_gather"] > 0 and r0["gathered_bytes_per_rank"] == 2 * r0["elements"]
+def _q(name, w):
+    return orc.per_group_kernel_sem(w, "e2m1", 128).half()
+
+
+class StubLocal:
+    def __init__(self, weights, shapes=None, *a, **k):
+        self.w = weights
+
+    def quantize(self):
+        self.out = {{n: _q(n, w) for n, w in self.w.items()}}
+
+
+class StubSharded:
+    def __init__(self, shapes, weights, group=None, *a, **k):
+        self.shapes, self.own = shapes, weights
+
+    def run(self):
+        if os.environ.get("REHEARSAL_HANG") and int(os.environ.get("RANK", "0")) == 1:
+            time.sleep(3600)                       # rank 1 never reaches the all-gather
+        full = {{n: (self.own[n] if n in self.own else torch.full(self.shapes[n], float("nan"))) for n in self.shapes}}
+        return cal.calibrate_sharded(full, quantize=_q, exchange="fp16")
+
+
+class CpuPlatform:
+    backend = "gloo"
+    data = "REHEARSAL on CPU with stand-ins: the numbers mean nothing"
+
+    def __init__(self, local_rank):
+        self.torch, self.dev = torch, torch.device("cpu")
+
+    def init_dist(self, dist):
+        dist.init_process_group("gloo")
+
+    def synchronize(self):
+        pass
+
+    def empty_cache(self):
+        pass
+
+    def hot_path(self, rank):
+        return (lambda: time.sleep(0.001)), bench.ROWS * bench.COLS, torch.zeros(1)
+
+    def release_hot_path(self):
+        pass
+
+    def timer(self):
+        t = [0.0, 0.0]
+        return (lambda: t.__setitem__(0, time.perf_counter())), (lambda: t.__setitem__(1, time.perf_counter())), \\
+               (lambda: (t[1] - t[0]) * 1e3)
+
+
+cal.LocalShard, cal.ShardedCalibration = StubLocal, StubSharded
+bench.CALIB_DEPTH = 1
+bench.WATCHDOG_S = float(os.environ.get("REHEARSAL_WATCHDOG_S", "240"))
+bench.main(script=os.path.abspath(__file__), platform_factory=CpuPlatform)
+'''
+
+
+def _rehearse(tmp_path, args, env_extra=None, timeout=300):
+    script = tmp_path / "bench_rehearsal.py"
+    script.write_text(_REHEARSAL.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                          env=env)
+
+
+def test_bench_gpus2_launches_two_ranks_gloo(tmp_path):
+    out = _rehearse(tmp_path, ["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["steps"] == 3 and res["warmup"] == 1
+    assert res["scaling"] == "weak" and res["config"]["parallelism"] == "shard2"
+    assert "REHEARSAL" in res["data"]
+    assert res["value"] > 0 and abs(res["roofline"]["frac"] - res["roofline"]["achieved"] / res["roofline"]["peak"]) < 1e-3
+    assert (res["roofline"]["traffic"] is None) == (res["roofline"]["traffic_source"] is None)
+    assert res["roofline"]["traffic_source"] is None or "profiles/" in res["roofline"]["traffic_source"]
+    wc = res["weight_calibration"]
+    assert "error" not in wc, wc
+    assert wc["n_gpus"] == 2 and wc["scaling"] == "strong" and wc["elements"] == 12 * 64 * 64
+    assert wc["ms"] > 0 and wc["ms_with_all_gather"] > 0 and wc["gathered_bytes_per_rank"] == 2 * wc["elements"]
+    assert "cpu_baseline" not in res           # N = 1 only
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
+    out = _rehearse(tmp_path, ["--gpus", "2", "--steps", "1", "--warmup", "0"],
+                    {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and not out.stdout.strip()
+    out = _rehearse(tmp_path, ["--gpus", "0"])
+    assert out.returncode != 0
+
+
+def test_bench_reports_a_blocked_collective_as_failure(tmp_path):
+    """A rank that never reaches the all-gather: the line carries the error and the exit code is non-zero."""
+    out = _rehearse(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "0"],
+                    {"REHEARSAL_HANG": "1", "REHEARSAL_WATCHDOG_S": "8"}, timeout=240)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(lines[0])
+    assert "timeout" in res["weight_calibration"]["error"] and "all_gather" in res["weight_calibration"]["error"]
+    assert res["n_gpus"] == 2

@@ -1,0 +1,135 @@
+"""Behaviour at the edges of the drop-in boundary (round-1 review items): layouts the reference accepts, float casts
+of the matrix-core modules, operand validation.  Needs a real MI355X: run with ``-m gpu``."""
+import copy
+
+import pytest
+import torch
+
+from oracle import fpq_oracle as orc
+from tests.conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("kv_bit", (6, 4))
+def test_kv_cache_update_takes_the_references_unbind_views(dev, kv_bit):
+    """tr/basic_var.py:187-194 caches `k`, `v` as they come out of `qkv.view(B, L, 3, H, c).unbind(2)` - sliced, not
+    dense - and quantizes them at the next step: `k / scale` is contiguous there, so the reference runs; so must we."""
+    from fpqvar_amd import kv_cache as kv, quant_utils as qu
+    g = torch.Generator().manual_seed(17)
+    B, L, H, c = 3, 6, 30, 64
+    qkv = torch.randn(B, L, 3 * H * c, generator=g).half()
+    _, ck, cv = qkv.to(dev).view(B, L, 3, H, c).unbind(2)
+    assert not ck.is_contiguous()
+    k = torch.randn(B, 2, H, c, generator=g).half()
+    v = torch.randn(B, 2, H, c, generator=g).half()
+    ck_cpu, cv_cpu = qkv.view(B, L, 3, H, c).unbind(2)[1:]
+    want_fn = (lambda t: orc.per_token_kernel_sem(t.contiguous(), "e2m3")) if kv_bit == 6 else \
+              (lambda t: orc.per_group_kernel_sem(t.contiguous(), "e2m1", 128))
+    nk, nv = kv.update_kv_cache(ck, cv, k.to(dev), v.to(dev), True, kv_bit, 1)
+    assert_bits_equal(nk, torch.cat((want_fn(ck_cpu), k), 1), f"k, kv_bit {kv_bit}")
+    assert_bits_equal(nv, torch.cat((want_fn(cv_cpu), v), 1), f"v, kv_bit {kv_bit}")
+    # the dual per-token quantizer follows the same rule (tr/quant_utils.py:614-646)
+    assert_bits_equal(qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(ck, 6),
+                      orc.dual_per_token_kernel_sem(ck_cpu.contiguous(), "int_neg", "e2m3_pos"), "dual per-token on a view")
+    # the permuted (BHLc) layout still raises for the per-token forms, exactly as the reference's .view(-1) does
+    bhlc = qkv.to(dev).view(B, L, 3, H, c).permute(2, 0, 3, 1, 4)[1]
+    with pytest.raises(RuntimeError):
+        kv.quantize_kv(bhlc, 6)
+    with pytest.raises(RuntimeError):
+        qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(bhlc, 6)
+    # ... and the argmin per-group function views its ARGUMENT: the sliced view raises there (x.view(-1, 128))
+    with pytest.raises(RuntimeError):
+        qu.fp_quant_e2_per_group(ck, 4, 128)
+
+
+def test_half_leaves_the_quantization_scales_in_fp32(dev):
+    """evaluate_fp_quant_transform_rotate.py:131 calls var.half() after quantize_VAR: the matrix-core Linears keep
+    their fp32 weight scales (code * fp32 scale is what the reference's fp32 weight quantization produced)."""
+    from fpqvar_amd import gemm, quant_linear as ql
+
+    class FFN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.fc2 = torch.nn.Linear(256, 512), torch.nn.Linear(512, 256)
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mat_qkv, self.proj = torch.nn.Linear(256, 768, bias=False), torch.nn.Linear(256, 256)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.ffn, self.attn = FFN(), Attn()
+            for m in (self.ffn.fc1, self.attn.mat_qkv):
+                m.weight.data.mul_(1e-4)          # scales ~1e-6: far below fp16's normal range
+
+    cfg4 = dict(weight_quant="per_group", act_quant="per_group", w_bit=4, a_bit=4, act_quant_sym=True, activation_fp_quant=True,
+                weight_fp_quant=True, act_fp_type="fp_e2", weight_fp_type="fp_e2", fc2_fp_type="fp_e1m2_neg_e2m1_pos")
+    cfg6 = dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True, activation_fp_quant=True,
+                weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3", fc2_fp_type="fp6_int_neg_e2m3_pos")
+    x = torch.randn(40, 256, device=dev).half()
+    for kind, cfg, flag in (("fp4", cfg4, "real_fp4"), ("fp6", cfg6, "real_fp6")):
+        base = Toy().to(dev)
+        plain = ql.quantize_VAR(copy.deepcopy(base), **{flag: True}, **cfg)
+        halved = ql.quantize_VAR(copy.deepcopy(base), **{flag: True}, **cfg).half()
+        n_checked = 0
+        for a, b in zip(plain.modules(), halved.modules()):
+            if isinstance(a, (gemm.FP4Linear, gemm.FP8Linear, gemm.FP6Linear)):
+                assert b.w_scales.dtype == torch.float32, kind
+                assert torch.equal(a.w_scales, b.w_scales) and torch.equal(a.w_codes, b.w_codes)
+                assert b.bias is None or b.bias.dtype == torch.float16
+                assert torch.equal(a(x), b(x)), kind
+                n_checked += 1
+        assert n_checked >= 3, kind
+        moved = halved.float().to("cpu")
+        for m in moved.modules():
+            if isinstance(m, (gemm.FP4Linear, gemm.FP8Linear, gemm.FP6Linear)):
+                assert m.w_scales.dtype == torch.float32 and m.w_scales.device.type == "cpu"
+
+
+def test_code_operands_are_validated_before_the_kernel(dev):
+    from fpqvar_amd import gemm, ops, packed
+    x = torch.randn(64, 256, device=dev)
+    codes, scales = ops.quant_rows_codes(x, "e2m1", 128, pack_nibbles=True)
+    ops.dequant_rows_codes(codes, scales, "e2m1", 128, torch.float16, True)
+    for bad_codes, bad_scales in ((codes[:-1], scales), (codes, scales[:-1]), (codes.to(torch.int16), scales),
+                                  (codes, scales.double()), (codes[:, ::2], scales), (codes, scales.cpu())):
+        with pytest.raises(RuntimeError):
+            ops.dequant_rows_codes(bad_codes, bad_scales, "e2m1", 128, torch.float16, True)
+    with pytest.raises(RuntimeError):
+        ops.dequant_rows_codes(codes, scales, "e2m1", 128, torch.float16, False)    # not packed: twice the bytes expected
+    p = packed.PackedWeight(codes[:10].contiguous(), scales, "e2m1", 128, (64, 256))
+    with pytest.raises(RuntimeError):
+        p.dequantize()
+    a = gemm.quantize_mx(torch.randn(16, 256, device=dev).half())
+    w = gemm.quantize_mx(torch.randn(24, 256, device=dev))
+    gemm.linear_fp4(*a, *w)
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp4(a[0], a[1][:-1], *w)
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp4(a[0], a[1], w[0], w[1].reshape(-1)[:-1])
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp4(a[0].cpu(), a[1], *w)
+    a8 = gemm.quantize_fp8(torch.randn(16, 256, device=dev).half())
+    w8 = gemm.quantize_fp8(torch.randn(24, 256, device=dev))
+    gemm.linear_fp8(*a8, *w8)
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp8(a8[0], a8[1][:-1], *w8)
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp8(a8[0][:, :128], a8[1], *w8)
+
+
+def test_calibrate_codes_exchange_rejects_a_custom_quantizer(dev):
+    from fpqvar_amd import calibrate as cal
+    w = {"a": torch.randn(4, 128, device=dev)}
+    with pytest.raises(ValueError):
+        cal.calibrate_sharded(w, quantize=lambda n, t: t.half(), exchange="codes")

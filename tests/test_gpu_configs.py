@@ -97,3 +97,127 @@ def test_config2_d16_mat_qkv_weights(dev, qu, block):
     from fpqvar_amd import calibrate as cal
     got16 = cal.default_weight_quantizer()("blocks.%d.attn.mat_qkv" % block, w.to(dev))
     assert_bits_equal(got16, want.half(), f"config 2 block {block}, fused .half()")
+
+
+# ---- config 4's kernel: fp32 weights, groups of 128, the fast path (fpq_fast32.h) and the one-launch segment form ----
+SYM = ("e2m1", "e1m2", "e3m0", "e2m3", "e3m2")
+
+
+def _boundary_groups(table):
+    """Groups whose scale is exactly 1 (max |x| = max|table|) and whose elements sit on, and +-1..4 ulp around, every
+    level and every rounding boundary, both signs: the approximate division of the fast path must hand exactly
+    these to the IEEE path."""
+    tab = torch.unique(orc.TABLES[table])
+    gmax = float(tab.abs().max())
+    pts = torch.cat([tab, (tab[:-1] + tab[1:]) / 2])
+    pts = pts[pts.abs() < gmax]
+    vals = []
+    for k in range(-4, 5):
+        vals.append((pts.view(torch.int32) + k).view(torch.float32))
+    vals = torch.cat(vals)
+    vals = vals[torch.isfinite(vals) & (vals.abs() < gmax)]
+    n = (vals.numel() + 126) // 127
+    out = torch.zeros(n, 128)
+    out[:, 0] = gmax
+    flat = out[:, 1:].reshape(-1)
+    flat[:vals.numel()] = vals
+    out[:, 1:] = flat.view(n, 127)
+    return out
+
+
+@pytest.mark.parametrize("out_dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("table", SYM)
+def test_fast32_groups_vs_oracle(dev, table, out_dtype):
+    from fpqvar_amd import ops
+    g = torch.Generator().manual_seed(41)
+    parts = [torch.randn(300, 128, generator=g) * 0.02,
+             torch.randn(200, 128, generator=g) * torch.exp(torch.randn(200, 128, generator=g)),
+             _boundary_groups(table), _boundary_groups(table) * 0.0371, _boundary_groups(table) * 3.0e-20,
+             _boundary_groups(table) * 1.7e19]
+    edge = torch.randn(16, 128, generator=g)
+    edge[0] = 0.0                                  # all-zero group: 0/0 -> +0
+    edge[1, 5] = float("nan")
+    edge[2, 7] = float("inf")
+    edge[3, 9] = float("-inf")
+    edge[4] *= 1e-41                               # subnormal group: scale underflows
+    edge[5] *= 1e-38
+    edge[6] *= 3e38 / 6                            # scale near the top of the range
+    edge[7, ::2] = -0.0
+    edge[8] = 1e-45                                # smallest subnormal everywhere
+    edge[9, 1:] = 0.0                              # a single non-zero element
+    edge[10] = -edge[10].abs()                     # single-sign groups
+    edge[11] = edge[11].abs()
+    edge[12] *= 1e-30                              # below 2^-90: IEEE path by the range check
+    edge[13] *= 1e30
+    parts.append(edge)
+    x = torch.cat(parts)
+    want = orc.per_group_kernel_sem(x, table, 128).to(out_dtype)
+    got = ops.quant_rows(x.to(dev), table, 128, out_dtype)
+    assert_bits_equal(got, want, f"fast32 {table} -> {out_dtype}")
+    # ragged tail of the grid (not a multiple of the 32-group tile) and a one-group tensor
+    for rows in (1, 31, 33):
+        assert_bits_equal(ops.quant_rows(x[:rows].to(dev), table, 128, out_dtype), want[:rows], f"fast32 {table} rows={rows}")
+
+
+def test_fast32_equals_ieee_path_on_64m_weights(dev):
+    """Fast path (approximate division + verification) against the generic kernel (IEEE division) on 2^26 random
+    weights per distribution, on the GPU: bit-equal, i.e. every value the approximation cannot decide was caught."""
+    import os
+    from fpqvar_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    for table in ("e2m1", "e2m3"):
+        for kind in ("weights", "uniform"):
+            x = torch.randn(1 << 26, device=dev, generator=g) * 0.02 if kind == "weights" else \
+                (torch.rand(1 << 26, device=dev, generator=g) * 2 - 1)
+            fast = ops.quant_rows(x, table, 128, torch.float16)
+            os.environ["FPQ_NO_FAST32"] = "1"
+            try:
+                slow = ops.quant_rows(x, table, 128, torch.float16)
+            finally:
+                del os.environ["FPQ_NO_FAST32"]
+            assert bool((fast.view(torch.int16) == slow.view(torch.int16)).all()), f"{table} {kind}"
+            rows = slice(0, 64 * 128)
+            assert_bits_equal(fast[rows], orc.per_group_kernel_sem(x[rows].cpu(), table, 128).half(), f"{table} {kind} vs oracle")
+
+
+def test_one_launch_over_a_segment_table(dev):
+    """LocalShard: layers of different sizes, one launch, results are views of one slab, bit-equal to the oracle."""
+    from fpqvar_amd import calibrate as cal
+    g = torch.Generator().manual_seed(9)
+    shapes = {"a.qkv": (384, 128), "a.proj": (128, 128), "a.fc1": (512, 256), "a.fc2": (128, 512), "tiny": (1, 128),
+              "odd": (3, 5, 128)}
+    w = {n: torch.randn(*s, generator=g) * 0.02 for n, s in shapes.items()}
+    w["a.proj"][0, :128] = 0.0
+    for table, fp_type in (("e2m1", "fp_e2"), ("e2m3", "fp6_e2m3")):
+        for out_dtype in (torch.float16, torch.float32):
+            shard = cal.LocalShard({n: t.to(dev) for n, t in w.items()}, weight_fp_type=fp_type, out_dtype=out_dtype)
+            shard.quantize()
+            views = shard.views()
+            assert list(views) == list(shapes)
+            for n in shapes:
+                assert views[n].shape == shapes[n] and views[n].data_ptr() >= shard.slab.data_ptr()
+                assert_bits_equal(views[n], orc.per_group_kernel_sem(w[n], table, 128).to(out_dtype), f"segment {n} {table}")
+    # a non-contiguous input is made contiguous (as the reference's reshape would), an empty share is a no-op
+    t = torch.randn(128, 256, generator=g)
+    shard = cal.LocalShard({"t": t.to(dev).t()})
+    shard.quantize()
+    assert_bits_equal(shard.views()["t"], orc.per_group_kernel_sem(t.t().contiguous(), "e2m1", 128).half(), "transposed")
+    assert cal.LocalShard({}, out=torch.empty(8, dtype=torch.float16, device=dev)).quantize().numel() == 8
+    with pytest.raises(RuntimeError):
+        cal.LocalShard({"h": torch.zeros(128, device=dev, dtype=torch.float16)})
+    with pytest.raises(RuntimeError):
+        cal.LocalShard({"r": torch.zeros(100, device=dev)})
+
+
+def test_sharded_calibration_object_world1(dev):
+    from fpqvar_amd import calibrate as cal
+    shapes = cal.var_linear_shapes(2)
+    shapes = {n: (o // 16, 128) for n, (o, i) in shapes.items()}          # small layers, groups of 128
+    g = torch.Generator().manual_seed(3)
+    w = {n: torch.randn(*s, generator=g) * 0.02 for n, s in shapes.items()}
+    sc = cal.ShardedCalibration(shapes, {n: t.to(dev) for n, t in w.items()})
+    got = sc.run()
+    for n in shapes:
+        assert_bits_equal(got[n], orc.per_group_kernel_sem(w[n], "e2m1", 128).half(), n)
+    again = sc.run()                                 # reusable: same slab, same views
+    assert all(again[n].data_ptr() == got[n].data_ptr() for n in shapes)

@@ -58,3 +58,38 @@ def test_dequantize_needs_the_gpu_library():
         p.dequantize()          # CPU tensors: the product path has no CPU fallback
     with pytest.raises(RuntimeError, match="E2M1"):
         packed.PackedWeight(torch.zeros(2, 96, dtype=torch.uint8), torch.ones(2), "e2m3", 128, (2, 128)).fp4_operands()
+
+
+def test_container_rejects_truncated_or_inconsistent_layers(tmp_path):
+    """load_packed checks the header against the tensor sizes: a file whose codes / scales do not cover the shape it
+    claims is refused at load time, not handed to a kernel that would read past the allocation."""
+    import json
+    from safetensors.torch import save_file
+    g = torch.Generator().manual_seed(2)
+    good = {"table": "e2m1", "cols": 128, "shape": [8, 384], "out_dtype": "float16", "rotate_block": 0, "rotate_seed": 0}
+    codes, scales = torch.randint(0, 255, (24, 64), generator=g, dtype=torch.uint8), torch.rand(24, generator=g)
+
+    def write(name, header, tensors):
+        path = str(tmp_path / name)
+        save_file(tensors, path, metadata={"format": packed.FORMAT, "layers": json.dumps({"l": header})})
+        return path
+
+    assert list(packed.load_packed(write("ok.safetensors", good, {"l.codes": codes, "l.scales": scales}))) == ["l"]
+    cases = {
+        "short_codes": (good, {"l.codes": codes[:20], "l.scales": scales}),
+        "short_scales": (good, {"l.codes": codes, "l.scales": scales[:5]}),
+        "bigger_shape": (dict(good, shape=[16, 384]), {"l.codes": codes, "l.scales": scales}),
+        "wrong_cols": (dict(good, cols=100), {"l.codes": codes, "l.scales": scales}),
+        "codes_dtype": (good, {"l.codes": codes.to(torch.int16), "l.scales": scales}),
+        "scales_dtype": (good, {"l.codes": codes, "l.scales": scales.double()}),
+        "unknown_table": (dict(good, table="e5m2"), {"l.codes": codes, "l.scales": scales}),
+        "no_scales": (good, {"l.codes": codes}),
+        "six_bit_as_nibbles": (dict(good, table="e2m3"), {"l.codes": codes, "l.scales": scales}),
+    }
+    for name, (header, tensors) in cases.items():
+        with pytest.raises(RuntimeError):
+            packed.load_packed(write(name + ".safetensors", header, tensors))
+    missing = dict(good)
+    del missing["cols"]
+    with pytest.raises(RuntimeError, match="cols"):
+        packed.load_packed(write("missing.safetensors", missing, {"l.codes": codes, "l.scales": scales}))
