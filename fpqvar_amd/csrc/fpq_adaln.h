@@ -1,0 +1,366 @@
+// fpq_adaln.h - the complete producer of tr/basic_var.py:263 / :266 for fp16 activations, second generation:
+//     h  = half( fma( LN(x), A, B ) ),   A = half(scale + 1) * s,  B = shift * s      (fp32; LN without affine)
+//     x1 = half( FWHT128( c_h * (h * D) ) )
+//     q  = per-group(128) quant(x1)
+// Included by fpq_kernels.hip after fpq_fast16.h (whose quantizer, butterfly and reductions it uses).
+//
+// What the counters said about the first generation (adaln_rotate_quant16_kernel, profiles/r02_pmc_adaln_before.txt):
+// 41 VALU instructions per element, but the vector pipe only 38 % busy; 134-140 VGPRs = 3 wavefronts per SIMD, each
+// walking its rows strictly load -> reduce -> compute -> store, 42 % of the wavefront-cycles waiting on memory.
+// Latency-bound, not throughput-bound.  Hence:
+//   * a workgroup owns ROWS consecutive rows of ONE batch entry and stages the modulation of that entry - already
+//     folded with the smoothing vector: A, B above - in LDS once; the per-element modulate is one fma instead of
+//     add, mul, add, mul plus two 16-byte modulation loads and their conversions per vector;
+//   * rows stay packed fp16 in registers (16 VGPRs per row instead of 32 + 16): LayerNorm reads them through
+//     v_dot2_f32_f16 (sum, sum of squares) and v_fma_mix_f32 (normalise) - the widening rides on the arithmetic;
+//   * the rotation's sign vector is folded into the staged modulation, the first butterfly stage reads the packed
+//     halves directly (fwht128_h_n): no sign flips and no fp16 -> fp32 conversions in the row loop;
+//   * the NEXT row's loads are issued before the current row is processed (software prefetch);
+//   * wavefront sums are DPP + v_permlane16/32_swap: no LDS round trip, no address arithmetic;
+//   * straight-line code: the launch picks MAXC = ceil(vectors per row / 64) exactly, so only the LAST vector of a
+//     lane can fall outside the row; it is loaded from a clamped address and zeroed, and its store is the one
+//     exec-masked branch of the row loop.  Vectors go through the stages two at a time (stage-major source order:
+//     two independent dependency chains per wavefront for the in-order issue to interleave).
+// (Tried and dropped: scaling by c_h in front of the butterfly, where it would ride on the fp16 -> fp32 widening.
+//  The butterfly of raw fp16 values is nearly always EXACT in fp32 - 11-bit inputs of similar magnitude - while
+//  19-bit inputs are not: rotated values went from <= 1 to 3 fp16 ulp off the fp64 product.)
+// LayerNorm statistics: one pass (E[x^2] - mean^2) with a centred second pass for rows where that cancels; fp32
+// rounding of the folded modulate differs from torch's three separate ops by a few 2^-24 - the parity contract of this entry point
+// is the fuzzy one of SURVEY.md section 7 (tests/test_gpu_parity.py::test_adaln_rotate_quant_fused: h within half an
+// fp16 ulp + 4e-6 relative, rotated values and quantization bit-exact given h).
+#pragma once
+
+// D = (float)half_lo(w) * b + c   /   (float)half_hi(w) * b + c
+__device__ __forceinline__ float fma_h_lo(uint32_t w, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fma_h_hi(uint32_t w, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+  return d;
+}
+
+// sum over the 64 lanes, result in every lane: 4 DPP adds inside the rows of 16, then the rows trade sums
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  auto r = __builtin_amdgcn_permlane16_swap(fbits(v), fbits(v), false, false);
+  v = u2f(r[0]) + u2f(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(fbits(v), fbits(v), false, false);
+  return u2f(r[0]) + u2f(r[1]);
+}
+
+// two sums at once (the steps interleave)
+__device__ __forceinline__ void wave_sum2_dpp(float& a, float& b) {
+#define FPQ_DPP_ADD(ctrl)                                                                         \
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), ctrl, 0xF, 0xF, true));   \
+  b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), ctrl, 0xF, 0xF, true));
+  FPQ_DPP_ADD(0xB1) FPQ_DPP_ADD(0x4E) FPQ_DPP_ADD(0x141) FPQ_DPP_ADD(0x140)
+#undef FPQ_DPP_ADD
+  auto ra = __builtin_amdgcn_permlane16_swap(fbits(a), fbits(a), false, false);
+  auto rb = __builtin_amdgcn_permlane16_swap(fbits(b), fbits(b), false, false);
+  a = u2f(ra[0]) + u2f(ra[1]);
+  b = u2f(rb[0]) + u2f(rb[1]);
+  ra = __builtin_amdgcn_permlane32_swap(fbits(a), fbits(a), false, false);
+  rb = __builtin_amdgcn_permlane32_swap(fbits(b), fbits(b), false, false);
+  a = u2f(ra[0]) + u2f(ra[1]);
+  b = u2f(rb[0]) + u2f(rb[1]);
+}
+
+typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
+
+template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false>
+__global__ __launch_bounds__(kBlock) void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
+                                                           u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
+                                                           int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab,
+                                                           int rows_per_wg, int wgs_per_batch) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  constexpr bool MOD16 = sizeof(Tmod) == 2;
+  constexpr int W = kBlock / 64;
+  const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
+  const int lut_entries = 1 << (16 - a.shift);
+  // four planes of vpr x 16 bytes behind the table: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
+  // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
+  u32x4* const planes = (u32x4*)(lut + ((lut_entries + 7) & ~7));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x / wgs_per_batch;
+  const int chunk = blockIdx.x % wgs_per_batch;
+  const int64_t L = ad.rows_per_batch;
+  const int64_t row0 = b * L + (int64_t)chunk * rows_per_wg;
+  int64_t n_here = L - (int64_t)chunk * rows_per_wg;
+  if (n_here > rows_per_wg) n_here = rows_per_wg;
+  if (row0 + n_here > rows) n_here = rows - row0;
+
+  // vector c of this lane is vector c * 64 + lane of the row; only c = MAXC - 1 can lie outside
+  const bool last_live = (MAXC - 1) * 64 + lane < vpr;
+  int vidx[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) vidx[c] = c * 64 + lane;
+  if (!last_live) vidx[MAXC - 1] = vpr - 1;      // any valid address: the value is zeroed, the store masked
+
+  auto load_row = [&](u32x4 (&dst)[MAXC], int64_t row) {
+    const u32x4* p = x + row * vpr;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) dst[c] = __builtin_nontemporal_load(p + vidx[c]);
+  };
+  u32x4 cur[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) cur[c] = u32x4{0, 0, 0, 0};
+  if (wave < n_here) load_row(cur, row0 + wave);   // requested before the staging below
+
+  // ---- stage the table and the folded modulation of batch entry b ----
+  for (int i = threadIdx.x; i < lut_entries; i += kBlock) lut[i] = tab.e[i];
+  for (int v = threadIdx.x; v < vpr; v += kBlock) {
+    const int64_t col = (int64_t)v * 8;
+    float sc[8], sh[8];
+    if constexpr (MOD16) {
+      const u32x4 ws = *(const u32x4*)((const _Float16*)ad.scale + b * ad.cols + col);
+      const u32x4 wh = *(const u32x4*)((const _Float16*)ad.shift + b * ad.cols + col);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t s1p = pk_add_f16(ws[k], 0x3C003C00u);   // scale.add(1) is an fp16 op in the reference
+        sc[2 * k] = h2f(s1p & 0xFFFFu);
+        sc[2 * k + 1] = h2f(s1p >> 16);
+        sh[2 * k] = h2f(wh[k] & 0xFFFFu);
+        sh[2 * k + 1] = h2f(wh[k] >> 16);
+      }
+    } else {
+      const u32x4* ap = (const u32x4*)((const float*)ad.scale + b * ad.cols + col);
+      const u32x4* bp = (const u32x4*)((const float*)ad.shift + b * ad.cols + col);
+      const u32x4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sc[k] = u2f(a0[k]) + 1.0f;
+        sc[4 + k] = u2f(a1[k]) + 1.0f;
+        sh[k] = u2f(b0[k]);
+        sh[4 + k] = u2f(b1[k]);
+      }
+    }
+    if (r.smooth) {
+      const u32x4* sp = (const u32x4*)(r.smooth + col);
+      const u32x4 s0 = sp[0], s1 = sp[1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sc[k] *= u2f(s0[k]);
+        sh[k] *= u2f(s0[k]);
+        sc[4 + k] *= u2f(s1[k]);
+        sh[4 + k] *= u2f(s1[k]);
+      }
+    }
+    // the rotation's sign vector D rides on the modulation: half(-t) == -half(t), so h * D = half(fma(ln, A*D, B*D))
+    const int j0 = (v * 8) & 127;
+    const uint32_t dbits = (r.sign[j0 >> 5] >> (j0 & 31)) & 0xFFu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t flip = ((dbits >> k) & 1u) << 31;
+      sc[k] = u2f(fbits(sc[k]) ^ flip);
+      sh[k] = u2f(fbits(sh[k]) ^ flip);
+    }
+    planes[v] = u32x4{fbits(sc[0]), fbits(sc[1]), fbits(sc[2]), fbits(sc[3])};
+    planes[vpr + v] = u32x4{fbits(sc[4]), fbits(sc[5]), fbits(sc[6]), fbits(sc[7])};
+    planes[2 * vpr + v] = u32x4{fbits(sh[0]), fbits(sh[1]), fbits(sh[2]), fbits(sh[3])};
+    planes[3 * vpr + v] = u32x4{fbits(sh[4]), fbits(sh[5]), fbits(sh[6]), fbits(sh[7])};
+  }
+  __syncthreads();
+
+  const int lg = lane & 15;
+  const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
+  uint32_t sx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sx[k] = (((sb >> (2 * k)) & 1u) << 15) | (((sb >> (2 * k + 1)) & 1u) << 31);
+  const float inv_c = 1.0f / (float)ad.cols;
+  const h2v_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+
+  for (int i = wave; i < n_here; i += W) {   // no barrier below: wavefronts run their rows independently
+    const int64_t row = row0 + i;
+    if (!last_live) cur[MAXC - 1] = u32x4{0, 0, 0, 0};
+    u32x4 nxt[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) nxt[c] = u32x4{0, 0, 0, 0};
+    if (i + W < n_here) load_row(nxt, row + W);      // wave-uniform: prefetch of this wavefront's next row
+
+    // ---- LayerNorm statistics: sum and sum of squares in one pass over the packed row (v_dot2_f32_f16: exact
+    // products, fp32 accumulation; the zeroed padding vector adds nothing), var = E[x^2] - mean^2.  That
+    // subtraction cancels when |mean| >> sigma: rows with mean^2 >= 64 var (6 of the 24 bits gone; also NaN / Inf
+    // rows) take the centred second pass instead - wave-uniform branch, rare.
+    float a1[MAXC], a2[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) a1[c] = a2[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const uint32_t xw = cur[c][k];   // NOT __builtin_bit_cast(h2v_t, cur[c][k]): hipcc 7.2 then reads element 0 for every k
+        const h2v_t xv = __builtin_bit_cast(h2v_t, xw);
+        a1[c] = __builtin_amdgcn_fdot2(xv, ones, a1[c], false);
+        a2[c] = __builtin_amdgcn_fdot2(xv, xv, a2[c], false);
+      }
+    float s1 = a1[0], s2 = a2[0];
+#pragma unroll
+    for (int c = 1; c < MAXC; ++c) {
+      s1 += a1[c];
+      s2 += a2[c];
+    }
+    wave_sum2_dpp(s1, s2);
+    const float mean = s1 * inv_c;
+    float var = __builtin_fmaf(-mean, mean, s2 * inv_c);
+    if (!(mean * mean < 64.0f * var)) {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) a2[c] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const float d0 = fma_h_lo(cur[c][k], 1.0f, -mean), d1 = fma_h_hi(cur[c][k], 1.0f, -mean);
+          a2[c] = __builtin_fmaf(d0, d0, a2[c]);
+          a2[c] = __builtin_fmaf(d1, d1, a2[c]);
+        }
+      if (!last_live) a2[MAXC - 1] = 0.0f;            // the zeroed padding vector is not part of the row
+      s2 = a2[0];
+#pragma unroll
+      for (int c = 1; c < MAXC; ++c) s2 += a2[c];
+      var = wave_sum_dpp(s2) * inv_c;
+    }
+    // rstd = 1 / sqrt(var + eps): v_rsq_f32 (1 ulp) + one Newton step, ~2^-23 relative - four instructions instead of
+    // the IEEE sqrt and division sequences (~25); what it feeds is rounded to fp16
+    const float ve = var + ad.eps;
+    float rstd = __builtin_amdgcn_rsqf(ve);
+    rstd = __builtin_fmaf(rstd * __builtin_fmaf(-ve * rstd, rstd, 1.0f), 0.5f, rstd);
+    const float nm = -mean * rstd;
+
+    // ---- modulate, rotate, quantize: vectors two at a time, stage by stage ----
+    u32x4 ys[TOKEN ? MAXC : 1];   // per-token scale: the rotated row waits here for the row maximum
+    uint32_t mrow = 0;
+    (void)ys;
+    (void)mrow;
+#pragma unroll
+    for (int c0 = 0; c0 < MAXC; c0 += 2) {
+      constexpr int N2 = 2;
+      const int n = (MAXC - c0) < N2 ? (MAXC - c0) : N2;
+      u32x4 hw[N2], y[N2], o[N2];
+      float t[N2][8];
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        const int v = vidx[c0 + j];
+        const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
+        const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
+        const u32x4 w = cur[c0 + j];
+        hw[j][0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
+                        __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
+        hw[j][1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
+                        __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
+        hw[j][2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
+                        __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
+        hw[j][3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
+                        __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
+      }
+      if (!last_live && c0 + n == MAXC) hw[n - 1] = u32x4{0, 0, 0, 0};
+      fwht128_h_n<N2>(hw, t, n, lg);                     // hw already carries the rotation's signs
+#pragma unroll
+      for (int j = 0; j < n; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[j][k] = mul2_to_h2(t[j][2 * k], t[j][2 * k + 1], r.c_h);
+      uint32_t m[N2];
+#pragma unroll
+      for (int j = 0; j < n; ++j) m[j] = vec_absmax16(y[j]);
+      if constexpr (TOKEN) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+          const int c = c0 + j;
+          ys[c] = y[j];
+          mrow = mrow > m[j] ? mrow : m[j];
+          if constexpr (EMIT) {
+            if (c < MAXC - 1 || last_live) {
+              const int64_t at = row * vpr + vidx[c];
+              if (h_out) __builtin_nontemporal_store(u32x4{hw[j][0] ^ sx[0], hw[j][1] ^ sx[1], hw[j][2] ^ sx[2], hw[j][3] ^ sx[3]}, h_out + at);
+              if (y_out) __builtin_nontemporal_store(y[j], y_out + at);
+            }
+          }
+        }
+        continue;
+      }
+      row_max_dpp16_n<N2>(m, n);
+      uint32_t cd[N2];
+      RowScale16 s[N2];
+#pragma unroll
+      for (int j = 0; j < n; ++j) s[j] = row_scale16(m[j], a.fpos.gmax, a.inv_gpos);
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        if constexpr (CODES) cd[j] = codes_vec16(y[j], lut, a.shift, s[j].sf, s[j].inv);
+        else o[j] = quant_vec16<false>(y[j], lut, a.shift, s[j].sf, s[j].inv, s[j].s16x2, 0.f, 0.f, 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        const int c = c0 + j;
+        if (c < MAXC - 1 || last_live) {
+          const int64_t at = row * vpr + vidx[c];
+          if constexpr (EMIT) {
+            if (h_out) __builtin_nontemporal_store(u32x4{hw[j][0] ^ sx[0], hw[j][1] ^ sx[1], hw[j][2] ^ sx[2], hw[j][3] ^ sx[3]}, h_out + at);
+            if (y_out) __builtin_nontemporal_store(y[j], y_out + at);
+          }
+          if constexpr (CODES) {
+            ((uint32_t*)out)[at] = cd[j];
+            if (lg == 0) r.code_scales[at >> 4] = (uint16_t)(s[j].s16x2 & 0xFFFFu);
+          } else {
+            __builtin_nontemporal_store(o[j], out + at);
+          }
+        }
+      }
+    }
+    if constexpr (TOKEN) {
+      // fp6_quant_*_per_token_cuda on the rotated row (tr/quant_utils.py:503-534): one scale for the whole row
+      mrow = row_max_dpp<64>(mrow);
+      const RowScale16 s = row_scale16(mrow, a.fpos.gmax, a.inv_gpos);
+      if (r.code_scales && lane == 0) r.code_scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        if (c == MAXC - 1 && !last_live) continue;
+        const int v = vidx[c];
+        if constexpr (CODES) {   // E4M3 bytes of the levels (fpq_gemm_fp8.h), 8 per vector, or dense 6-bit codes
+          uint32_t cb[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t wk = ys[c][k];
+            const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
+            const float y0 = mul_h_lo(wk, s.inv), y1 = mul_h_hi(wk, s.inv);
+            const float e0 = __builtin_fmaf(-y0, s.sf, x0), e1 = __builtin_fmaf(-y1, s.sf, x1);
+            const float r0 = __builtin_fmaf(e0, s.inv, y0), r1 = __builtin_fmaf(e1, s.inv, y1);
+            const uint32_t rb = f2h2(r0, r1);
+            const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+            cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
+            cb[2 * k + 1] = lut[u >> (16 + a.shift)];
+          }
+          if (r.code_bits == 6) {
+            // 8 six-bit codes = 48 bits per lane, rows packed densely: the four lanes of a quad own 24 contiguous
+            // bytes; lane q of the quad takes the (3 - q) upper 16-bit words of its own string and the q + 1 lower
+            // words of its right neighbour's, so that lanes 0..2 each store 8 aligned bytes (cols % 32 == 0: a quad
+            // is live or dead as a whole).
+            const uint64_t own = (uint64_t)(cb[0] | (cb[1] << 6) | (cb[2] << 12) | (cb[3] << 18)) |
+                                 ((uint64_t)(cb[4] | (cb[5] << 6) | (cb[6] << 12) | (cb[7] << 18)) << 24);
+            const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)own, 0xF9, 0xF, 0xF, false);   // quad_perm [1,2,3,3]
+            const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(own >> 32), 0xF9, 0xF, 0xF, false);
+            const uint64_t nb = ((uint64_t)nhi << 32) | nlo;
+            const int qp = lane & 3, sr = 16 * qp;
+            const uint64_t w = (own >> sr) | (nb << (48 - sr));
+            if (qp < 3) {
+              uint8_t* dst = (uint8_t*)out + row * ((int64_t)vpr * 6) + (int64_t)c * (64 * 6) + 24 * (lane >> 2) + 8 * qp;
+              __builtin_nontemporal_store(u32x2{(uint32_t)w, (uint32_t)(w >> 32)}, (u32x2*)dst);
+            }
+          } else {
+            const u32x2 o2 = {cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24), cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24)};
+            __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
+          }
+        } else {
+          const u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+          __builtin_nontemporal_store(o, out + row * vpr + v);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) cur[c] = nxt[c];
+  }
+}

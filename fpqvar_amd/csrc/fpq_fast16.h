@@ -602,7 +602,8 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t*
 //     q  = fp_quant_*_per_group_cuda(x1, 4, 128)
 // with Q block-diagonal, every 128x128 block = diag(D) . H128 / sqrt(128)
 // (rotate_utils/rotation_utils.py:69-104, hadamard_utils.py:63-99), so per 128-chunk
-//     x1 = half( c_h * FWHT128(h * D) ),   c_h = half(float32(1/sqrt(128))) = 0.08837890625
+//     x1 = half( c_h * FWHT128(h * D) ),   c_h = half(float32(1/sqrt(128))) = 0.08837890625   (one rounding:
+//          v_fma_mixlo/hi_f16; the butterfly of fp16 inputs is nearly always exact in fp32)
 // Here: h = half(x * s) (s optional), sign flip by xor, 3 butterfly stages inside the lane's
 // 8 values, 4 across the 16 lanes of the group (DPP quad_perm for lane^1, lane^2; ds_swizzle
 // for lane^4, lane^8 - no LDS memory is touched), fp32 throughout, one rounding to fp16, and
@@ -676,6 +677,128 @@ __device__ __forceinline__ void fwht128(float (&t)[8], int lane_in_group) {
   for (int j = 0; j < 4; ++j) { t[j] = p[j].x; t[j + 4] = p[j].y; }
 }
 
+// half(a * b) packed from two fp32 values with ONE rounding each (v_fma_mixlo/hi_f16): the rotated value
+// half(c_h * FWHT(...)).  No torch op sequence is mirrored here (the reference's GEMM rounds its fp32 accumulator
+// once, too), so the single rounding is the better one.
+__device__ __forceinline__ uint32_t mul2_to_h2(float lo, float hi, float b) {
+  uint32_t d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(lo), "v"(b));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(hi), "v"(b));
+  return d;
+}
+
+// D = s * (float)half(w) + (float)half(pw), lo / hi halves: both fp16 operands are widened by the instruction itself
+__device__ __forceinline__ float fmix_hsh_lo(uint32_t w, float s, uint32_t pw) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(w), "v"(s), "v"(pw));
+  return d;
+}
+__device__ __forceinline__ float fmix_hsh_hi(uint32_t w, float s, uint32_t pw) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(w), "v"(s), "v"(pw));
+  return d;
+}
+
+// FWHT over the 128 fp16 values held by 16 lanes x 4 packed registers (signs already applied), natural (Sylvester)
+// order, fp32 results (not yet scaled by c_h).  N independent groups are transformed stage by stage (stage-major
+// source order: N dependency chains for the in-order issue to interleave).  The butterfly stages commute, so the
+// first one is the lane-bit-0 stage, taken straight from the PACKED halves: one DPP move fetches two partner
+// values, and v_fma_mix_f32 widens mine and the partner's while it adds (exact) - no separate fp16 -> fp32
+// conversion exists.  Then the three in-register stages on float pairs, then lane bits 1, 2, 3 as in fwht128.
+template <int N>
+__device__ __forceinline__ void fwht128_h_n(const u32x4 (&w)[N], float (&t)[N][8], int n, int lane_in_group) {
+  const float s1 = (lane_in_group & 1) ? -1.0f : 1.0f, s2 = (lane_in_group & 2) ? -1.0f : 1.0f;
+  const float s4 = (lane_in_group & 4) ? -1.0f : 1.0f, s8 = (lane_in_group & 8) ? -1.0f : 1.0f;
+  f2_t p[N][4];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    if (q >= n) continue;
+    uint32_t pw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pw[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[q][k], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // element 2k, 2k+1 -> pair register (k & 1 ? .. ): t index j pairs with j + 4
+      const float lo = fmix_hsh_lo(w[q][k], s1, pw[k]), hi = fmix_hsh_hi(w[q][k], s1, pw[k]);
+      // elements 2k and 2k+1: p[j] = {t[j], t[j + 4]}
+      if (k < 2) {
+        p[q][2 * k].x = lo;
+        p[q][2 * k + 1].x = hi;
+      } else {
+        p[q][2 * k - 4].y = lo;
+        p[q][2 * k - 3].y = hi;
+      }
+    }
+  }
+  // index bit 0 and bit 1: whole pairs against whole pairs; index bit 2: inside each pair
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    if (q >= n) continue;
+    f2_t a = p[q][0], b = p[q][1];
+    p[q][0] = a + b;
+    p[q][1] = a - b;
+    a = p[q][2];
+    b = p[q][3];
+    p[q][2] = a + b;
+    p[q][3] = a - b;
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    if (q >= n) continue;
+    f2_t a = p[q][0], b = p[q][2];
+    p[q][0] = a + b;
+    p[q][2] = a - b;
+    a = p[q][1];
+    b = p[q][3];
+    p[q][1] = a + b;
+    p[q][3] = a - b;
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q < n) p[q][j] = f2_t{p[q][j].x + p[q][j].y, p[q][j].x - p[q][j].y};
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q < n) p[q][j] = __builtin_elementwise_fma(p[q][j], f2_t{s2, s2}, xlane2(p[q][j], 2));
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q < n) p[q][j] = __builtin_elementwise_fma(p[q][j], f2_t{s4, s4}, xlane2(p[q][j], 4));
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q < n) p[q][j] = __builtin_elementwise_fma(p[q][j], f2_t{s8, s8}, xlane2(p[q][j], 8));
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[q][j] = p[q][j].x;
+      t[q][j + 4] = p[q][j].y;
+    }
+}
+
+// group-of-16-lanes maxima of N values, the DPP steps interleaved
+template <int N>
+__device__ __forceinline__ void row_max_dpp16_n(uint32_t (&v)[N], int n) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+#pragma unroll
+  for (int step = 0; step < 4; ++step)
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      if (q >= n) continue;
+      uint32_t o;
+      if (step == 0) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[q], 0xB1, 0xF, 0xF, true);
+      else if (step == 1) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[q], 0x4E, 0xF, 0xF, true);
+      else if (step == 2) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[q], 0x141, 0xF, 0xF, true);
+      else o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[q], 0x140, 0xF, 0xF, true);
+      v[q] = mx(v[q], o);
+    }
+}
+
 template <typename Tin, bool EMIT, int U, bool CODES = false>
 __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __restrict__ xv, u32x4* __restrict__ out,
                                                                u32x4* __restrict__ rot_out, int64_t n_vec,
@@ -730,17 +853,15 @@ __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __re
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float t[8];
+      u32x4 ws[1];
+      float tt[1][8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t w = raw[u][k] ^ sx[k];
-        t[2 * k] = h2f(w & 0xFFFFu);
-        t[2 * k + 1] = h2f(w >> 16);
-      }
-      fwht128(t, lg);
+      for (int k = 0; k < 4; ++k) ws[0][k] = raw[u][k] ^ sx[k];
+      fwht128_h_n<1>(ws, tt, 1, lg);
+      const float(&t)[8] = tt[0];
       u32x4 y;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = f2h2(t[2 * k] * r.c_h, t[2 * k + 1] * r.c_h);
+      for (int k = 0; k < 4; ++k) y[k] = mul2_to_h2(t[2 * k], t[2 * k + 1], r.c_h);
       if (EMIT && live[u]) __builtin_nontemporal_store(y, rot_out + v0 + u * kBlock);
       uint32_t m = row_max_dpp<16>(vec_absmax16(y));
       RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
@@ -946,15 +1067,19 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
     for (int k = 0; k < 4; ++k) hw[k] = f2h2(t[2 * k], t[2 * k + 1]);
     if (h_out && live && row_live) __builtin_nontemporal_store(hw, h_out + row * vpr + v);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint32_t w = hw[k] ^ sx[k];
-      t[2 * k] = h2f(w & 0xFFFFu);
-      t[2 * k + 1] = h2f(w >> 16);
+    for (int k = 0; k < 4; ++k) t[2 * k] = t[2 * k + 1] = 0.0f;
+    {
+      u32x4 ws[1];
+      float tt[1][8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ws[0][k] = hw[k] ^ sx[k];
+      fwht128_h_n<1>(ws, tt, 1, lg);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = tt[0][k];
     }
-    fwht128(t, lg);
     u32x4 y;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) y[k] = f2h2(t[2 * k] * r.c_h, t[2 * k + 1] * r.c_h);
+    for (int k = 0; k < 4; ++k) y[k] = mul2_to_h2(t[2 * k], t[2 * k + 1], r.c_h);
     if (y_out && live && row_live) __builtin_nontemporal_store(y, y_out + row * vpr + v);
     if constexpr (TOKEN) {   // per-token scale: keep the rotated row, quantize after the row maximum is known
       ys[c] = y;

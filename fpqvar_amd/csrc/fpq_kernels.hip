@@ -373,6 +373,7 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 
 #include "fpq_fast16.h"
 #include "fpq_fast32.h"
+#include "fpq_adaln.h"
 #include "fpq_gemm_fp4.h"   // the code-emitting quantizer kernels live beside their consumers;
 #include "fpq_gemm_fp8.h"   // the GEMM templates themselves are instantiated in fpq_gemm.hip
 #include "fpq_gemm_fp6.h"
@@ -950,6 +951,44 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));
   r.vec_per_row = cols / 8;
   const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  if constexpr (sizeof(Tin) == 2) {
+    // second generation (fpq_adaln.h): fp16 rows of up to 2560 channels, one batch entry per workgroup
+    if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !getenv("FPQ_ADALN_V1")) {
+      const char* rows_env = getenv("FPQ_ADALN_ROWS");
+      int rows_per_wg = rows_env ? atoi(rows_env) : 16;
+      if (rows_per_wg < 1) rows_per_wg = 1;
+      const int64_t L = ad.rows_per_batch;
+      const int64_t n_batches = (rows + L - 1) / L;
+      const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
+      if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+      const dim3 g2((unsigned)(n_batches * per_batch));
+      const int lut_entries = 1 << (16 - h.args.shift);
+      const size_t lds2 = (size_t)((lut_entries + 7) & ~7) * sizeof(uint16_t) + (size_t)64 * r.vec_per_row;
+#define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
+  hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN>), g2, dim3(kBlock), lds2, st, (const u32x4*)x,    \
+                     (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, rows_per_wg, (int)per_batch)
+#define FPQ_ADALN2(M)                                                                                                  \
+  do {                                                                                                                 \
+    const bool emit = h_out || y_out;                                                                                  \
+    if (token_mode >= 2) FPQ_ADALN2K(M, true, false, true);                                                            \
+    else if (token_mode == 1 && emit) FPQ_ADALN2K(M, false, true, true);                                               \
+    else if (token_mode == 1) FPQ_ADALN2K(M, false, false, true);                                                      \
+    else if (code_scales) FPQ_ADALN2K(M, true, false, false);                                                          \
+    else if (emit) FPQ_ADALN2K(M, false, true, false);                                                                 \
+    else FPQ_ADALN2K(M, false, false, false);                                                                          \
+  } while (0)
+      switch ((int)((r.vec_per_row + 63) / 64)) {   // MAXC = ceil(vectors per row / 64), exactly
+        case 1: FPQ_ADALN2(1); break;
+        case 2: FPQ_ADALN2(2); break;
+        case 3: FPQ_ADALN2(3); break;
+        case 4: FPQ_ADALN2(4); break;
+        default: FPQ_ADALN2(5); break;
+      }
+#undef FPQ_ADALN2
+#undef FPQ_ADALN2K
+      return check_launch();
+    }
+  }
   const int64_t rows_per_wg = kBlock / lanes_per_row;
   int64_t g64 = (rows + rows_per_wg - 1) / rows_per_wg;
   const char* cap_env = getenv("FPQ_ADALN_GRID");
