@@ -219,20 +219,22 @@ def other_kernels(dev):
     from fpqvar_amd import ops, rotation as rot
     out = {}
 
-    def timed(fn, iters=20):
-        for _ in range(10):      # reach steady clocks first: the first launches after an idle gap read ~20 % slow
-            fn()
-        torch.cuda.synchronize()
-        best = float("inf")
-        for _ in range(3):       # best of three bursts: single bursts vary by 15 % with the clock state of the box
+    def timed(fn, iters=20, max_bursts=40):
+        """Steady-state time per call: bursts of `iters` calls (HIP events around each burst) until three consecutive
+        bursts agree within 2 % - a kernel's first hundred launches after a change of workload run up to 25 % slow on
+        this chip while the clocks settle (profiles/r02_ab_adaln_variants.txt) - then the minimum of those three."""
+        last = []
+        for _ in range(max_bursts):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) / iters)
-        return best
+            last = (last + [e0.elapsed_time(e1) / iters])[-3:]
+            if len(last) == 3 and max(last) <= 1.02 * min(last):
+                break
+        return min(last)
 
     def hbm(name, ms, nbytes):
         out[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1),

@@ -73,19 +73,35 @@ __device__ __forceinline__ void wave_sum2_dpp(float& a, float& b) {
 
 typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 
+// build-time knobs for A/B experiments (tools/ab_quant.py); the defaults are the measured best
+#ifndef FPQ_ADALN_PREFETCH
+#define FPQ_ADALN_PREFETCH 1
+#endif
+#ifndef FPQ_ADALN_N2
+#define FPQ_ADALN_N2 2
+#endif
+#ifndef FPQ_ADALN_WAVES
+#define FPQ_ADALN_WAVES 0
+#endif
+#if FPQ_ADALN_WAVES > 0
+#define FPQ_ADALN_OCC __attribute__((amdgpu_waves_per_eu(FPQ_ADALN_WAVES, 8)))
+#else
+#define FPQ_ADALN_OCC
+#endif
+
 template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false>
-__global__ __launch_bounds__(kBlock) void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
+__global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                            u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                            int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab,
                                                            int rows_per_wg, int wgs_per_batch) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static LDS: addresses known at compile time
+  __shared__ u32x4 planes[4 * 64 * 5];                                      // 64 bytes per vector of the row (<= 320 vectors)
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   constexpr int W = kBlock / 64;
   const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
   const int lut_entries = 1 << (16 - a.shift);
-  // four planes of vpr x 16 bytes behind the table: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
+  // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
-  u32x4* const planes = (u32x4*)(lut + ((lut_entries + 7) & ~7));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t b = blockIdx.x / wgs_per_batch;
   const int chunk = blockIdx.x % wgs_per_batch;
@@ -175,13 +191,17 @@ __global__ __launch_bounds__(kBlock) void adaln_rq16_kernel(const u32x4* __restr
   const float inv_c = 1.0f / (float)ad.cols;
   const h2v_t ones = {(_Float16)1.0f, (_Float16)1.0f};
 
-  for (int i = wave; i < n_here; i += W) {   // no barrier below: wavefronts run their rows independently
+  // One row: `cur` holds it, the wavefront's next row (if any) is requested into `nxt` first (software prefetch).
+  // The row loop below alternates two register sets, so no row is ever copied from register to register.
+  auto do_row = [&](u32x4 (&cur)[MAXC], u32x4 (&nxt)[MAXC], int i) {
     const int64_t row = row0 + i;
+#if FPQ_ADALN_PREFETCH
+    if (i + W < n_here) load_row(nxt, row + W);      // wave-uniform branch
+#else
+    (void)nxt;
+    if (i != wave) load_row(cur, row);               // no prefetch: the row is requested when its turn comes
+#endif
     if (!last_live) cur[MAXC - 1] = u32x4{0, 0, 0, 0};
-    u32x4 nxt[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) nxt[c] = u32x4{0, 0, 0, 0};
-    if (i + W < n_here) load_row(nxt, row + W);      // wave-uniform: prefetch of this wavefront's next row
 
     // ---- LayerNorm statistics: sum and sum of squares in one pass over the packed row (v_dot2_f32_f16: exact
     // products, fp32 accumulation; the zeroed padding vector adds nothing), var = E[x^2] - mean^2.  That
@@ -238,8 +258,8 @@ __global__ __launch_bounds__(kBlock) void adaln_rq16_kernel(const u32x4* __restr
     (void)ys;
     (void)mrow;
 #pragma unroll
-    for (int c0 = 0; c0 < MAXC; c0 += 2) {
-      constexpr int N2 = 2;
+    for (int c0 = 0; c0 < MAXC; c0 += FPQ_ADALN_N2) {
+      constexpr int N2 = FPQ_ADALN_N2;
       const int n = (MAXC - c0) < N2 ? (MAXC - c0) : N2;
       u32x4 hw[N2], y[N2], o[N2];
       float t[N2][8];
@@ -360,7 +380,14 @@ __global__ __launch_bounds__(kBlock) void adaln_rq16_kernel(const u32x4* __restr
         }
       }
     }
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) cur[c] = nxt[c];
+  };
+  u32x4 alt[MAXC];
+#if FPQ_ADALN_PREFETCH
+  for (int i = wave; i < n_here; i += 2 * W) {   // no barrier below: wavefronts run their rows independently
+    do_row(cur, alt, i);
+    if (i + W < n_here) do_row(alt, cur, i + W);
   }
+#else
+  for (int i = wave; i < n_here; i += W) do_row(cur, alt, i);
+#endif
 }

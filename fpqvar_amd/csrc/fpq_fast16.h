@@ -33,6 +33,8 @@ typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef uint16_t us2_t __attribute__((ext_vector_type(2)));
 typedef int16_t s2_t __attribute__((ext_vector_type(2)));
 
+constexpr int kLutLdsEntries = 2048;   // shift >= 5: at most 2 x 1024 buckets
+
 struct Lut16Args {
   Fmt fneg, fpos;      // identical for the symmetric tables
   float inv_gneg;      // RN32(1 / gmax) per side
@@ -89,6 +91,30 @@ __device__ __forceinline__ float mul_h_hi(uint32_t w, float b) {
   return d;
 }
 
+// x - y * s with x an fp16 half of w (widened by the instruction), y and s fp32: the exact residual of the division
+// step without a separate fp16 -> fp32 conversion of x
+__device__ __forceinline__ float resid_h_lo(uint32_t w, float y, float s) {
+  float d;
+  asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(y), "v"(s), "v"(w));
+  return d;
+}
+__device__ __forceinline__ float resid_h_hi(uint32_t w, float y, float s) {
+  float d;
+  asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(y), "v"(s), "v"(w));
+  return d;
+}
+
+// the two table entries of a packed pair of bucket patterns as ONE packed register: byte offsets straight from the
+// pattern (bucket * 2 == (pattern >> (shift - 1)) & mask), 16-bit loads into the low / high half
+__device__ __forceinline__ uint32_t lut_pair16(const uint16_t* lut, uint32_t u, int shift) {
+  const uint32_t mask = ((1u << (16 - shift)) - 1u) << 1;
+  const uint32_t off0 = (u >> (shift - 1)) & mask, off1 = (u >> (15 + shift)) & mask;
+  h2_t q;
+  q.x = *(const _Float16*)((const char*)lut + off0);
+  q.y = *(const _Float16*)((const char*)lut + off1);
+  return __builtin_bit_cast(uint32_t, q);
+}
+
 // max over the LPR lanes that own a row; LPR lanes are contiguous and LPR-aligned
 template <int LPR>
 __device__ __forceinline__ uint32_t row_max_dpp(uint32_t v) {
@@ -135,7 +161,9 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     uint32_t wk = w[k];
+#if defined(FPQ_PKDIV) && FPQ_PKDIV
     float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
+#endif
     float s0 = sf_n, s1 = sf_n, i0 = inv_n, i1 = inv_n;
     uint32_t sc = s16x2_n;
     if (DUAL) {
@@ -154,14 +182,12 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
     uint32_t rb = f2h(rr.x) | (f2h(rr.y) << 16);
 #else
     float y0 = mul_h_lo(wk, i0), y1 = mul_h_hi(wk, i1);
-    float e0 = __builtin_fmaf(-y0, s0, x0), e1 = __builtin_fmaf(-y1, s1, x1);
+    float e0 = resid_h_lo(wk, y0, s0), e1 = resid_h_hi(wk, y1, s1);
     float r0 = __builtin_fmaf(e0, i0, y0), r1 = __builtin_fmaf(e1, i1, y1);
     uint32_t rb = f2h2(r0, r1);
 #endif
     uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
-    uint32_t q0 = lut[(u & 0xFFFFu) >> shift];
-    uint32_t q1 = lut[u >> (16 + shift)];
-    o[k] = pk_mul_f16(q0 | (q1 << 16), sc);
+    o[k] = pk_mul_f16(lut_pair16(lut, u, shift), sc);
   }
   return o;
 }
@@ -173,9 +199,8 @@ __device__ __forceinline__ uint32_t codes_vec16(const u32x4& w, const uint16_t* 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t wk = w[k];
-    const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
     const float y0 = mul_h_lo(wk, inv), y1 = mul_h_hi(wk, inv);
-    const float e0 = __builtin_fmaf(-y0, sf, x0), e1 = __builtin_fmaf(-y1, sf, x1);
+    const float e0 = resid_h_lo(wk, y0, sf), e1 = resid_h_hi(wk, y1, sf);
     const float r0 = __builtin_fmaf(e0, inv, y0), r1 = __builtin_fmaf(e1, inv, y1);
     const uint32_t rb = f2h2(r0, r1);
     const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
@@ -267,7 +292,7 @@ template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = t
 __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4* __restrict__ x,
                                                                    u32x4* __restrict__ out, int64_t n_vec,
                                                                    Lut16Args a, Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   bool first = true;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -338,7 +363,7 @@ struct KvStepArgs {
 
 template <int LPR, int U>
 __global__ __launch_bounds__(kBlock) void kv16_step_kernel(KvStepArgs k, Lut16Args a, Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   const int kv = blockIdx.z, b = blockIdx.y;
   u32x4* slab = k.cache + ((int64_t)kv * k.batch + b) * k.slab_vec;
   if ((int)blockIdx.x < k.q_tiles) {
@@ -387,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void kv16_step_kernel(KvStepArgs k, Lut16Ar
 template <int LPR, bool DUAL, bool TAB_ARG>
 __global__ __launch_bounds__(kBlock) void rows16_lut_pair_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                                 int64_t n_vec, Lut16Args a, Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   constexpr int64_t kTile = (int64_t)kBlock * 2;
   const int64_t tiles = (n_vec + kTile - 1) / kTile;
   const int in_row = threadIdx.x % LPR, row_in_tile = threadIdx.x / LPR;
@@ -454,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
                                                                  uint16_t* __restrict__ out, int64_t rows,
                                                                  int64_t cols, int64_t rows_per_block, Lut16Args a,
                                                                  Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   __shared__ uint32_t sh[kBlock / 64];
   const int64_t vec_per_row = cols >> 3;
   // rows blockIdx.x, blockIdx.x + gridDim.x, ...: the workgroups in flight sweep the tensor front to back together
@@ -534,7 +559,7 @@ template <bool DUAL, int MAXC, bool TAB_ARG>
 __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t* __restrict__ x,
                                                                 uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                                                 Lut16Args a, Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   if (TAB_ARG) {
     const int n = 1 << (16 - a.shift);
     for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
@@ -803,7 +828,7 @@ template <typename Tin, bool EMIT, int U, bool CODES = false>
 __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __restrict__ xv, u32x4* __restrict__ out,
                                                                u32x4* __restrict__ rot_out, int64_t n_vec,
                                                                RotArgs r, Lut16Args a, Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   const int lg = threadIdx.x & 15;
   // this lane's 8 sign bits -> xor masks on packed halves
   const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
@@ -932,7 +957,7 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
                                                                      u32x4* __restrict__ out, u32x4* __restrict__ h_out,
                                                                      u32x4* __restrict__ y_out, int64_t rows,
                                                                      AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   __shared__ float shf[kBlock / 64];
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   const int lane = threadIdx.x & (LANES - 1);

@@ -221,7 +221,7 @@ template <int MAXC>
 __global__ __launch_bounds__(kBlock) void rows16_codes8_wave_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ codes,
                                                                    uint16_t* __restrict__ scales, int64_t rows, int64_t cols,
                                                                    Lut16Args a, Lut16Tab tab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lut[];
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   {
     const int n = 1 << (16 - a.shift);
     for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];

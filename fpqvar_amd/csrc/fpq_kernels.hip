@@ -881,7 +881,7 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   args.nan_flag = nan_flag;
   const int64_t n_vec = rows * (cols / 8);
   const int lpr = (int)(cols / 8);
-  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   auto go = [&](auto kern_tab, auto kern_fill) {
     if (h.tab_valid)
@@ -919,7 +919,7 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   r.vec_per_row = cols / 8;
   const int64_t n_vec = rows * (cols / 8);
   constexpr int U = 2;
-  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   const dim3 grid(grid_for(tiles, 1 << 20));
   if (code_scales)
@@ -950,7 +950,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));
   r.vec_per_row = cols / 8;
-  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   if constexpr (sizeof(Tin) == 2) {
     // second generation (fpq_adaln.h): fp16 rows of up to 2560 channels, one batch entry per workgroup
     if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !getenv("FPQ_ADALN_V1")) {
@@ -962,8 +962,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
       const dim3 g2((unsigned)(n_batches * per_batch));
-      const int lut_entries = 1 << (16 - h.args.shift);
-      const size_t lds2 = (size_t)((lut_entries + 7) & ~7) * sizeof(uint16_t) + (size_t)64 * r.vec_per_row;
+      const size_t lds2 = 0;   // table and modulation planes live in static LDS
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN>), g2, dim3(kBlock), lds2, st, (const u32x4*)x,    \
                      (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, rows_per_wg, (int)per_batch)
@@ -1040,7 +1039,7 @@ int launch_fast16_pair8(const void* x, void* out, int64_t rows, int neg_id, int 
   Lut16Args args = h.args;
   args.nan_flag = nan_flag;
   const int64_t n_vec = rows * 16;   // rows of 128 halves
-  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t tiles = (n_vec + (int64_t)kBlock * 2 - 1) / ((int64_t)kBlock * 2);
   if (h.tab_valid)
     hipLaunchKernelGGL((rows16_lut_pair_kernel<8, DUAL, true>), dim3(grid_for(tiles, 1 << 20)), dim3(kBlock), lds, st,
@@ -1057,7 +1056,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   const Lut16Host& h = lut16_host(neg_id, pos_id);
   Lut16Args args = h.args;
   args.nan_flag = nan_flag;
-  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t vec_per_row = cols / 8;
   if (vec_per_row <= 64 * 5 && !getenv("FPQ_NO_WAVE_ROWS")) {
     // one wavefront per row: 4 rows per workgroup pass, enough workgroups to keep every CU busy while the
@@ -1348,7 +1347,7 @@ int fpq_kv_cache_step(void* cache, int64_t batch, int64_t max_len, int64_t row_e
   if (q_tiles + c_tiles > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
   k.q_tiles = (int)q_tiles;
   const dim3 grid((unsigned)(q_tiles + c_tiles), (unsigned)batch, 2);
-  const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+  const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   hipStream_t st = (hipStream_t)stream;
 #define FPQ_KV_CASE(L) \
   case L: hipLaunchKernelGGL((kv16_step_kernel<L, U>), grid, dim3(kBlock), lds, st, k, h.args, h.tab); break;
@@ -1539,7 +1538,7 @@ int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t
   if (in_dtype == FPQ_F16) {
     const Lut16Host& h = lut16_host(FPQ_E2M1, FPQ_E2M1);
     const int64_t n_vec = rows * (cols / 8);
-    const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+    const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
     hipLaunchKernelGGL(rows16_codes_mx_kernel, dim3(grid_for((n_vec + kBlock - 1) / kBlock, 16384)), dim3(kBlock), lds, st,
                        (const u32x4*)x, (uint32_t*)codes, (uint16_t*)scales, n_vec, h.args, lut16_mx_codes_e2m1());
   } else {
@@ -1587,7 +1586,7 @@ int fpq_quant_rows_codes_fp8(const void* x, uint8_t* codes, void* scales, int64_
   if (in_dtype == FPQ_F16 && cols % 8 == 0 && cols <= 4096 && (((uintptr_t)x | (uintptr_t)codes) & 15) == 0 &&
       lut16_host(table_id, table_id).tab_valid) {
     const Lut16Host& h = lut16_host(table_id, table_id);
-    const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+    const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
     const int64_t wgs = (rows + kBlock / 64 - 1) / (kBlock / 64);
     const dim3 gw(grid_for(wgs, 8192));
     const int maxc = (int)((cols / 8 + 63) / 64);
@@ -1664,7 +1663,7 @@ int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == FPQ_F16 && cols <= 8192 && (((uintptr_t)x) & 15) == 0) {
     const Lut16Host& h = lut16_host(table_id, table_id);
-    const size_t lds = (size_t)(1u << (16 - h.args.shift)) * sizeof(uint16_t);
+    const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
     const int64_t wgs = (rows + kBlock / 64 - 1) / (kBlock / 64);
     const dim3 gw(grid_for(wgs, 8192));
     const int maxc = (int)((cols / 32 + 63) / 64);
