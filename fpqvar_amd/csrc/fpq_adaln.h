@@ -99,7 +99,6 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   constexpr int W = kBlock / 64;
   const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
-  const int lut_entries = 1 << (16 - a.shift);
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
   if (wave < n_here) load_row(cur, row0 + wave);   // requested before the staging below
 
   // ---- stage the table and the folded modulation of batch entry b ----
-  for (int i = threadIdx.x; i < lut_entries; i += kBlock) lut[i] = tab.e[i];
+  lut16_stage(lut, tab, a.shift);
   for (int v = threadIdx.x; v < vpr; v += kBlock) {
     const int64_t col = (int64_t)v * 8;
     float sc[8], sh[8];

@@ -262,13 +262,66 @@ __device__ __forceinline__ void dual_poison(RowScale16& n, RowScale16& p) {
   }
 }
 
-// The bucket -> level table, prebuilt on the host (immutable, cached per table pair)
-// and handed over BY VALUE in the kernel arguments: no device-side global state, and a
-// workgroup pays one 2-byte load per lane instead of evaluating the closed form.
-constexpr int kLutArgEntries = 1024;   // shift >= 6: every table pair except int_neg/e2m3_pos
+// The bucket -> level table, prebuilt on the host (immutable, cached per table pair) and handed over BY VALUE in
+// the kernel arguments: no device-side global state, and a workgroup pays a few 2-byte stores per lane instead of
+// evaluating the closed form.  Kernel arguments are limited to 4 KiB, the widest table (int_neg / e2m3_pos, buckets
+// of 32 patterns) has 2 x 1024 entries - but every table is constant beyond its largest rounding boundary (the
+// largest level, for every finite pattern up to the reach limit) and zero for the inf / NaN patterns, so only the
+// prefix of each sign half travels: <= 1216 entries for the widest pair.
+constexpr int kLutArgEntries = 1280;
 struct Lut16Tab {
-  uint16_t e[kLutArgEntries];
+  uint16_t e[kLutArgEntries];   // positive-half prefix, then negative-half prefix
+  uint16_t n_pos, n_neg;        // prefix lengths (buckets)
+  uint16_t fill_pos, fill_neg;  // every finite bucket beyond the prefix
 };
+
+// expand the by-value table into the workgroup's LDS image [positive half | negative half]
+__device__ __forceinline__ void lut16_stage(uint16_t* lut, const Lut16Tab& tab, int shift) {
+  const int nh = 1 << (15 - shift), nan0 = 0x7C00 >> shift;
+  if (tab.n_pos == 0xFFFFu) {   // small table, stored whole: one plain copy (the common case, kept as cheap as it was)
+    for (int i = threadIdx.x; i < 2 * nh; i += blockDim.x) lut[i] = tab.e[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < 2 * nh; i += blockDim.x) {
+    const bool neg = i >= nh;
+    const int j = neg ? i - nh : i;
+    const int np = neg ? tab.n_neg : tab.n_pos, base = neg ? tab.n_pos : 0;
+    const uint16_t fill = neg ? tab.fill_neg : tab.fill_pos;
+    lut[i] = j < np ? tab.e[base + j] : (j < nan0 ? fill : (uint16_t)0);
+  }
+}
+
+// host: compress a full image (2^(16-shift) entries); false when it does not have the constant-tail structure or
+// the prefixes do not fit
+inline bool lut16_compress(const uint16_t* full, int shift, Lut16Tab* out) {
+  const int nh = 1 << (15 - shift), nan0 = 0x7C00 >> shift;
+  if (2 * nh <= kLutArgEntries) {   // fits whole
+    for (int i = 0; i < kLutArgEntries; ++i) out->e[i] = i < 2 * nh ? full[i] : 0;
+    out->n_pos = out->n_neg = 0xFFFFu;
+    out->fill_pos = out->fill_neg = 0;
+    return true;
+  }
+  int np[2];
+  uint16_t fill[2];
+  for (int half = 0; half < 2; ++half) {
+    const uint16_t* f = full + half * nh;
+    for (int j = nan0; j < nh; ++j)
+      if (f[j] != 0) return false;
+    fill[half] = f[nan0 - 1];
+    int n = nan0;
+    while (n > 0 && f[n - 1] == fill[half]) --n;
+    np[half] = n;
+  }
+  if (np[0] + np[1] > kLutArgEntries) return false;
+  for (int i = 0; i < kLutArgEntries; ++i) out->e[i] = 0;
+  for (int j = 0; j < np[0]; ++j) out->e[j] = full[j];
+  for (int j = 0; j < np[1]; ++j) out->e[np[0] + j] = full[nh + j];
+  out->n_pos = (uint16_t)np[0];
+  out->n_neg = (uint16_t)np[1];
+  out->fill_pos = fill[0];
+  out->fill_neg = fill[1];
+  return true;
+}
 
 inline void lut16_build_host(uint16_t* lut, const Lut16Args& a) {
   const int n = 1 << (16 - a.shift);
@@ -307,8 +360,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
     }
     if (first) {
       if (TAB_ARG) {
-        const int n = 1 << (16 - a.shift);
-        for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+        lut16_stage(lut, tab, a.shift);
       } else {
         lut16_fill(lut, a);
       }
@@ -378,8 +430,7 @@ __global__ __launch_bounds__(kBlock) void kv16_step_kernel(KvStepArgs k, Lut16Ar
       raw[u] = live[u] ? p[v] : u32x4{0, 0, 0, 0};
     }
     {
-      const int n = 1 << (16 - a.shift);
-      for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+      lut16_stage(lut, tab, a.shift);
       __syncthreads();
     }
 #pragma unroll
@@ -425,8 +476,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_pair_kernel(const u32x4* __
     u32x4 rb = live ? __builtin_nontemporal_load(x + vb) : u32x4{0, 0, 0, 0};
     if (first) {
       if (TAB_ARG) {
-        const int n = 1 << (16 - a.shift);
-        for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+        lut16_stage(lut, tab, a.shift);
       } else {
         lut16_fill(lut, a);
       }
@@ -497,8 +547,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
     }
     if (first) {
       if (TAB_ARG) {
-        const int n = 1 << (16 - a.shift);
-        for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+        lut16_stage(lut, tab, a.shift);
       } else {
         lut16_fill(lut, a);
       }
@@ -561,8 +610,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t*
                                                                 Lut16Args a, Lut16Tab tab) {
   __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   if (TAB_ARG) {
-    const int n = 1 << (16 - a.shift);
-    for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+    lut16_stage(lut, tab, a.shift);
   } else {
     lut16_fill(lut, a);
   }
@@ -871,8 +919,7 @@ __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __re
       raw[u] = w;
     }
     if (first) {
-      const int n = 1 << (16 - a.shift);
-      for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+      lut16_stage(lut, tab, a.shift);
       __syncthreads();
       first = false;
     }
@@ -967,8 +1014,7 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
 #pragma unroll
   for (int k = 0; k < 4; ++k) sx[k] = (((sb >> (2 * k)) & 1u) << 15) | (((sb >> (2 * k + 1)) & 1u) << 31);
   {
-    const int n = 1 << (16 - a.shift);
-    for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+    lut16_stage(lut, tab, a.shift);
     __syncthreads();
   }
   const int64_t vpr = r.vec_per_row;

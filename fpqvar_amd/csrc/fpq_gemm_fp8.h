@@ -223,8 +223,7 @@ __global__ __launch_bounds__(kBlock) void rows16_codes8_wave_kernel(const uint16
                                                                    Lut16Args a, Lut16Tab tab) {
   __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   {
-    const int n = 1 << (16 - a.shift);
-    for (int i = threadIdx.x; i < n; i += kBlock) lut[i] = tab.e[i];
+    lut16_stage(lut, tab, a.shift);
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;

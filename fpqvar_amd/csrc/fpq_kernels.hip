@@ -845,8 +845,9 @@ inline bool fast16_block_eligible(const void* x, const void* out, int64_t cols, 
 // host cache of prebuilt tables: built once per (neg, pos) pair, immutable afterwards
 struct Lut16Host {
   Lut16Args args;
-  Lut16Tab tab;
-  bool tab_valid;
+  Lut16Tab tab;                    // the compressed image that travels in the kernel arguments
+  bool tab_valid;                  // false: kernels evaluate the closed form themselves (lut16_fill)
+  uint16_t full[kLutLdsEntries];   // the full image (host side: derived code tables are built from it)
 };
 
 inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
@@ -861,9 +862,9 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
         h.args.inv_gpos = 1.0f / h.args.fpos.gmax;
         h.args.shift = table_shift16(n) < table_shift16(p) ? table_shift16(n) : table_shift16(p);
         h.args.nan_flag = nullptr;
-        h.tab_valid = (1 << (16 - h.args.shift)) <= kLutArgEntries;
-        for (int i = 0; i < kLutArgEntries; ++i) h.tab.e[i] = 0;
-        if (h.tab_valid) lut16_build_host(h.tab.e, h.args);
+        for (int i = 0; i < kLutLdsEntries; ++i) h.full[i] = 0;
+        lut16_build_host(h.full, h.args);
+        h.tab_valid = lut16_compress(h.full, h.args.shift, &h.tab);
       }
     return c;
   }();
@@ -1082,6 +1083,11 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   const int64_t target_wgs = h.tab_valid ? (1 << 20) : 2048;
   int64_t rpb = (rows + target_wgs - 1) / target_wgs;
   if (rpb < 1) rpb = 1;
+  if (h.tab_valid && (1 << (16 - h.args.shift)) > 1024) {   // 2 x 1024 buckets to stage: a few rows per workgroup
+    const char* e = getenv("FPQ_BIGTAB_RPB");
+    rpb = e ? atoll(e) : 2;
+    if (rpb < 1) rpb = 1;
+  }
   const int64_t grid = (rows + rpb - 1) / rpb;
   auto go = [&](auto kern_tab, auto kern_fill) {
     if (h.tab_valid)
@@ -1126,7 +1132,7 @@ inline const Lut16Tab& lut16_mx_codes_e2m1() {
     auto* t = new Lut16Tab;
     const Lut16Host& h = lut16_host(FPQ_E2M1, FPQ_E2M1);
     const int n = 1 << (16 - h.args.shift);
-    for (int i = 0; i < kLutArgEntries; ++i) t->e[i] = 0;
+    uint16_t full[kLutLdsEntries] = {0};
     for (int i = 0; i < n; ++i) {
       uint32_t u = (uint32_t)i << h.args.shift;
       bool neg = (u >> 15) != 0;
@@ -1134,8 +1140,9 @@ inline const Lut16Tab& lut16_mx_codes_e2m1() {
       // level -> magnitude index 0..7 (host twin of level_index)
       int li = (qm >= h.args.fpos.kmin) ? (int)((fbits(qm) >> h.args.fpos.mshift) - h.args.fpos.kmin_code_base)
                                         : (int)(qm * h.args.fpos.inv_step0);
-      t->e[i] = (uint16_t)(li | ((neg && li != 0) ? 8 : 0));
+      full[i] = (uint16_t)(li | ((neg && li != 0) ? 8 : 0));
     }
+    if (!lut16_compress(full, h.args.shift, t)) abort();   // E2M1: 2 x 128 buckets, always fits
     return t;
   }();
   return *tab;
@@ -1390,10 +1397,17 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
     // int_neg/e2m3_pos needs a 2048-entry table (too big for the kernel arguments): every workgroup
     // evaluates it once, so give each workgroup many tiles (measured: 88 us vs 127 us with a full grid)
-    if (lut16_host(neg_table, pos_table).tab_valid)
+    // tables of 2 x 1024 buckets (int_neg / e2m3_pos) cost a workgroup 8 stores per lane to stage: give each
+    // workgroup many tiles (capped grid, U = 4); the smaller ones run one tile per workgroup on a full grid
+    if ((1 << (16 - lut16_host(neg_table, pos_table).args.shift)) <= 1024)
       rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag);
-    else
-      rc = launch_fast16<true, 4>(x, out, rows, cols, neg_table, pos_table, st, 4096, flag);
+    else {
+      const char* eu = getenv("FPQ_BIGTAB_U");
+      const char* ec = getenv("FPQ_BIGTAB_CAP");
+      const int cap = ec ? atoi(ec) : 16384;   // measured on [65536 x 7680]: 4096 -> 366 us, 16384 -> 348 us, full grid -> 367 us
+      if (eu && atoi(eu) == 8) rc = launch_fast16<true, 8>(x, out, rows, cols, neg_table, pos_table, st, cap, flag);
+      else rc = launch_fast16<true, 4>(x, out, rows, cols, neg_table, pos_table, st, cap, flag);
+    }
   } else if (!clip_absmax && fast16_block_eligible(x, out, cols, in_dtype, out_dtype)) {
     rc = launch_fast16_block<true>(x, out, rows, cols, neg_table, pos_table, st, flag);
   } else {
@@ -1569,7 +1583,9 @@ static const Lut16Tab& lut16_codes8(int table_id) {
       const Lut16Host& h = lut16_host(id, id);
       if (!h.tab_valid) continue;
       const int n = 1 << (16 - h.args.shift);
-      for (int i = 0; i < n; ++i) t[id].e[i] = e4m3_of(h2f(h.tab.e[i]));
+      uint16_t full[kLutLdsEntries] = {0};
+      for (int i = 0; i < n; ++i) full[i] = e4m3_of(h2f(h.full[i]));
+      if (!lut16_compress(full, h.args.shift, &t[id])) abort();   // same structure as the level table it is derived from
     }
     return t;
   }();
@@ -1633,7 +1649,9 @@ static const Lut16Tab& lut16_codes6_e2m3() {
     auto* t = new Lut16Tab();
     const Lut16Host& h = lut16_host(FPQ_E2M3, FPQ_E2M3);
     const int n = 1 << (16 - h.args.shift);
-    for (int i = 0; i < n; ++i) t->e[i] = (uint16_t)e2m3_of_level(h2f(h.tab.e[i]));
+    uint16_t full[kLutLdsEntries] = {0};
+    for (int i = 0; i < n; ++i) full[i] = (uint16_t)e2m3_of_level(h2f(h.full[i]));
+    if (!lut16_compress(full, h.args.shift, t)) abort();
     return t;
   }();
   return *tab;
