@@ -72,6 +72,45 @@ __device__ __forceinline__ void lut32_fill(float* lut, const Lut32Args& a) {
   }
 }
 
+// Four elements of one lane through the fast path: levels * s in p[].  `slow` (this lane already knows its scale is
+// outside the fast path's range) is OR-ed with "one of my values is too close to a rounding boundary"; if ANY lane of
+// the wavefront says so, the wavefront redoes these four with the IEEE path.
+__device__ __forceinline__ void quant4_fast32(const u32x4& raw, float s, float r, bool slow, const Lut32Args& a,
+                                              const float* lut, uint32_t low_mask, uint32_t idx_mask, float (&p)[4]) {
+  uint32_t near = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xf = u2f(raw[i]);
+    const float y0 = xf * r;
+    const float e = __builtin_fmaf(-y0, s, xf);
+    const float y = __builtin_fmaf(e, r, y0);
+    const uint32_t yb = fbits(y);
+    const uint32_t uu = (yb & 0x7FFFFFFFu) - (yb >> 31);          // negative: magnitude pattern - 1
+    uint32_t c;                                                    // signed clamp: -0.0 gives pattern 0 - 1 = -1 -> lo
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(uu), "s"(a.lo_clamp), "v"(a.hi_clamp));   // one SGPR per VOP3
+    const uint32_t d = (c + 3u) & low_mask;
+    near = near < d ? near : d;
+    const uint32_t off = ((c >> (a.bshift - 2)) & idx_mask) | ((yb >> 31) << (a.nbits + 2));
+    const float q = *(const float*)((const char*)lut + off);
+    p[i] = q * s;
+  }
+  slow |= near <= 6u;
+  if (__builtin_amdgcn_ballot_w64(slow) != 0) {   // rare
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = quant_sym<float>(u2f(raw[i]), s, a.f);
+  }
+}
+
+// scale and its refined reciprocal from a row / group maximum; *slow: the fast path's range check
+__device__ __forceinline__ void scale_fast32(uint32_t amax_bits, float gmax, float* s, float* r, bool* slow) {
+  const float sv = u2f(amax_bits) / gmax;                       // IEEE: scale = absmax / max|table|
+  float rv = __builtin_amdgcn_rcpf(sv);
+  rv = __builtin_fmaf(__builtin_fmaf(-sv, rv, 1.0f), rv, rv);   // one Newton step
+  *s = sv;
+  *r = rv;
+  *slow = (fbits(sv) - 0x12800000u) > (0x6C000000u - 0x12800000u);   // s outside [2^-90, 2^90], zero, inf or NaN
+}
+
 // max over the 32 lanes that own a group (lanes 32k .. 32k+31): 4 DPP steps inside each row of 16, then the two rows
 // of a half-wave trade their maxima with ONE v_permlane16_swap (gfx950; no LDS crossbar, no address VGPR)
 __device__ __forceinline__ uint32_t group32_max(uint32_t v) {
@@ -118,34 +157,12 @@ __global__ __launch_bounds__(kBlock) void groups32_lut_kernel(const Seg32* __res
       m = m > ab ? m : ab;
     }
     m = group32_max(m);
-    const float s = u2f(m) / a.f.gmax;                      // IEEE: scale = absmax / max|table|
-    float r = __builtin_amdgcn_rcpf(s);
-    r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);   // one Newton step
-    // s in [2^-90, 2^90] (this also rejects 0, inf, NaN)
-    bool slow = live[u] && (fbits(s) - 0x12800000u) > (0x6C000000u - 0x12800000u);
+    float s, r;
+    bool slow;
+    scale_fast32(m, a.f.gmax, &s, &r, &slow);
+    slow = slow && live[u];
     float p[4];
-    uint32_t near = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float xf = u2f(raw[u][i]);
-      const float y0 = xf * r;
-      const float e = __builtin_fmaf(-y0, s, xf);
-      const float y = __builtin_fmaf(e, r, y0);
-      const uint32_t yb = fbits(y);
-      const uint32_t uu = (yb & 0x7FFFFFFFu) - (yb >> 31);          // negative: magnitude pattern - 1
-      uint32_t c;                                                    // signed clamp: -0.0 gives pattern 0 - 1 = -1 -> lo
-      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(uu), "s"(a.lo_clamp), "v"(a.hi_clamp));   // one SGPR per VOP3
-      const uint32_t d = (c + 3u) & low_mask;
-      near = near < d ? near : d;
-      const uint32_t off = ((c >> (a.bshift - 2)) & idx_mask) | ((yb >> 31) << (a.nbits + 2));
-      const float q = *(const float*)((const char*)lut + off);
-      p[i] = q * s;
-    }
-    slow |= live[u] && near <= 6u;
-    if (__builtin_amdgcn_ballot_w64(slow) != 0) {   // rare: redo this wavefront's vectors with IEEE division
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = quant_sym<float>(u2f(raw[u][i]), s, a.f);
-    }
+    quant4_fast32(raw[u], s, r, slow, a, lut, low_mask, idx_mask, p);   // dead lanes hold zeros: never "near"
     const int64_t v = v0 + u * kBlock;
     if constexpr (sizeof(Tout) == 4) {
       if (live[u]) __builtin_nontemporal_store(u32x4{fbits(p[0]), fbits(p[1]), fbits(p[2]), fbits(p[3])}, (u32x4*)sg.out + v);
@@ -163,6 +180,91 @@ __global__ __launch_bounds__(kBlock) void groups32_lut_kernel(const Seg32* __res
         const u32x4 o = odd ? u32x4{r0, r1, h0, h1} : u32x4{hprev[0], hprev[1], r0, r1};
         const int64_t vs = odd ? v : v - kBlock;              // the iteration this lane stores
         if (odd ? live[u] : live[u - 1]) __builtin_nontemporal_store(o, (u32x4*)sg.out + (vs >> 1));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Long fp32 rows, one scale per row (per-channel weights of the W6A6 runs: fp6_quant_e2m3_per_token_cuda on the fp32
+// [out, in] weight, tr/quant_utils.py:808-811, result fp16).  LANES = 64: one wavefront per row (in <= 2048),
+// LANES = 256: one workgroup per row.  A lane holds vectors c * LANES + lane of its row (4 floats each, every load a
+// fully coalesced 16 bytes per lane), MAXC of them; same fast path as above with the row's scale; fp16 results leave
+// as 16-byte stores after the neighbour exchange (vector pairs c, c + 1), a last unpaired vector as 8-byte stores.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Tout, int LANES, int MAXC>
+__global__ __launch_bounds__(kBlock) void rows32_lut_kernel(const float* __restrict__ x, Tout* __restrict__ out,
+                                                           int64_t rows, int64_t cols, Lut32Args a) {
+  __shared__ float lut[2 << kLut32MaxBits];
+  __shared__ uint32_t sh[kBlock / 64];
+  lut32_fill(lut, a);
+  __syncthreads();
+  const uint32_t low_mask = (1u << a.bshift) - 1u;
+  const uint32_t idx_mask = ((1u << a.nbits) - 1u) << 2;
+  const int lane = threadIdx.x & (LANES - 1);
+  const int vpr = (int)(cols >> 2);              // host: cols % 8 == 0, vpr <= LANES * MAXC
+  const bool odd = (lane & 1) != 0;
+  constexpr int R = kBlock / LANES;              // rows per workgroup pass
+  for (int64_t base = (int64_t)blockIdx.x * R; base < rows; base += (int64_t)gridDim.x * R) {
+    const int64_t row = base + threadIdx.x / LANES;
+    const bool row_live = row < rows;            // uniform per wavefront (LANES >= 64)
+    const u32x4* xr = (const u32x4*)(x + (row_live ? row : rows - 1) * cols);
+    u32x4 raw[MAXC];
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int v = c * LANES + lane;
+      raw[c] = v < vpr ? __builtin_nontemporal_load(xr + v) : u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t ab = raw[c][i] & 0x7FFFFFFFu;
+        m = m > ab ? m : ab;
+      }
+    }
+    m = row_max_dpp<16>(m);
+    {
+      auto r16 = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+      m = r16[0] > r16[1] ? r16[0] : r16[1];
+      auto r32 = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+      m = r32[0] > r32[1] ? r32[0] : r32[1];
+    }
+    if constexpr (LANES == 256) {                 // rows never share a workgroup here: plain block maximum
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+      __syncthreads();
+      m = sh[0];
+#pragma unroll
+      for (int i = 1; i < kBlock / 64; ++i) m = m > sh[i] ? m : sh[i];
+    }
+    float s, r;
+    bool slow;
+    scale_fast32(m, a.f.gmax, &s, &r, &slow);
+    uint32_t hprev[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int v = c * LANES + lane;
+      const bool live = v < vpr && row_live;
+      float p[4];
+      quant4_fast32(raw[c], s, r, slow && live, a, lut, low_mask, idx_mask, p);
+      if constexpr (sizeof(Tout) == 4) {
+        if (live) __builtin_nontemporal_store(u32x4{fbits(p[0]), fbits(p[1]), fbits(p[2]), fbits(p[3])},
+                                              (u32x4*)(out + row * cols) + v);
+      } else {
+        const uint32_t h0 = f2h2(p[0], p[1]), h1 = f2h2(p[2], p[3]);
+        if ((c & 1) == 0 && c + 1 < MAXC) {
+          hprev[0] = h0;
+          hprev[1] = h1;
+        } else if ((c & 1) == 1) {
+          // as in groups32_lut_kernel: the even lane stores the pair's 16 bytes of vector c - 1, the odd lane those of c
+          const uint32_t s0 = odd ? hprev[0] : h0, s1 = odd ? hprev[1] : h1;
+          const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);
+          const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
+          const u32x4 o = odd ? u32x4{r0, r1, h0, h1} : u32x4{hprev[0], hprev[1], r0, r1};
+          const int vs = odd ? v : v - LANES;                  // vpr is even: the two lanes of a pair are live together
+          if (vs < vpr && row_live) __builtin_nontemporal_store(o, (u32x4*)(out + row * cols) + (vs >> 1));
+        } else {                                               // MAXC odd: the last vector leaves as 8 bytes per lane
+          if (live) __builtin_nontemporal_store(u32x2{h0, h1}, (u32x2*)(out + row * cols) + v);
+        }
       }
     }
   }

@@ -1126,6 +1126,34 @@ inline int launch_fast32(const Seg32* segs, int n_segs, const Seg32& one, int64_
   return check_launch();
 }
 
+// long fp32 rows (per-channel weights): one wavefront or one workgroup per row (fpq_fast32.h)
+inline bool rows32_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int table_id) {
+  return in_dtype == FPQ_F32 && cols % 8 == 0 && cols >= 512 && cols / 4 <= 256 * 10 && kTables[table_id].symmetric &&
+         (((uintptr_t)x | (uintptr_t)out) & 15) == 0 && !getenv("FPQ_NO_FAST32");
+}
+
+template <typename Tout>
+int launch_rows32(const void* x, void* out, int64_t rows, int64_t cols, int table_id, hipStream_t st) {
+  const Lut32Args a = lut32_args(table_id);
+  const int64_t vpr = cols / 4;
+#define FPQ_R32(L, M)                                                                                              \
+  do {                                                                                                             \
+    const int64_t wgs = (rows + (kBlock / L) - 1) / (kBlock / L);                                                  \
+    hipLaunchKernelGGL((rows32_lut_kernel<Tout, L, M>), dim3(grid_for(wgs, 1 << 16)), dim3(kBlock), 0, st,        \
+                       (const float*)x, (Tout*)out, rows, cols, a);                                               \
+    return check_launch();                                                                                         \
+  } while (0)
+  if (vpr <= 64 * 2) FPQ_R32(64, 2);
+  if (vpr <= 64 * 4) FPQ_R32(64, 4);
+  if (vpr <= 64 * 8) FPQ_R32(64, 8);
+  if (vpr <= 256 * 3) FPQ_R32(256, 3);
+  if (vpr <= 256 * 4) FPQ_R32(256, 4);
+  if (vpr <= 256 * 6) FPQ_R32(256, 6);
+  if (vpr <= 256 * 8) FPQ_R32(256, 8);
+  FPQ_R32(256, 10);
+#undef FPQ_R32
+}
+
 // ---- F2: hardware-nibble codes + FP4 MFMA GEMM ---------------------------------------
 inline const Lut16Tab& lut16_mx_codes_e2m1() {
   static const Lut16Tab* tab = [] {
@@ -1298,6 +1326,9 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
     const Seg32 one = {x, out, rows};
     return launch_fast32(nullptr, 1, one, rows, table_id, out_dtype, (hipStream_t)stream);
   }
+  if (rows32_eligible(x, out, cols, in_dtype, table_id))
+    return out_dtype == FPQ_F16 ? launch_rows32<_Float16>(x, out, rows, cols, table_id, (hipStream_t)stream)
+                                : launch_rows32<float>(x, out, rows, cols, table_id, (hipStream_t)stream);
   DualArgs dual = {};
   dual.nan_flag = nullptr;
   return dispatch_rows<false>(x, out, rows, cols, in_dtype, out_dtype, make_fmt(table_id), dual,

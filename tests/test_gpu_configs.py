@@ -221,3 +221,36 @@ def test_sharded_calibration_object_world1(dev):
         assert_bits_equal(got[n], orc.per_group_kernel_sem(w[n], "e2m1", 128).half(), n)
     again = sc.run()                                 # reusable: same slab, same views
     assert all(again[n].data_ptr() == got[n].data_ptr() for n in shapes)
+
+
+@pytest.mark.parametrize("out_dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("cols", (1920, 2304, 7680, 9216, 512, 1000, 2048, 2056, 5000 * 2))
+def test_fast32_long_rows_vs_oracle(dev, cols, out_dtype):
+    """Per-channel fp32 weights (fp6_quant_e2m3_per_token_cuda on [out, in], tr/quant_utils.py:808-811; fp16 result)
+    and the same rows with fp32 output: the wavefront- / workgroup-per-row fast path against the oracle, incl. rows
+    whose scale is outside the fast path's range, boundary values and ragged row counts."""
+    from fpqvar_amd import ops
+    g = torch.Generator().manual_seed(cols)
+    rows = 37
+    x = torch.randn(rows, cols, generator=g) * 0.02
+    x[3] *= torch.exp(torch.randn(cols, generator=g))
+    x[4] = 0.0
+    x[5, 17] = float("nan")
+    x[6, 5] = float("inf")
+    x[7] *= 1e-41
+    x[8] *= 1e30
+    x[9, ::2] = -0.0
+    x[10, 1:] = 0.0
+    tab = torch.unique(orc.TABLES["e2m3"])
+    pts = torch.cat([tab, (tab[:-1] + tab[1:]) / 2])
+    for k, r in zip(range(-3, 4), range(11, 18)):        # rows with scale 1 and elements on / around every boundary
+        vals = (pts.view(torch.int32) + k).view(torch.float32)
+        vals = vals[torch.isfinite(vals) & (vals.abs() < 7.5)]
+        x[r] = 0.0
+        x[r, 0] = 7.5
+        x[r, 1:1 + vals.numel()] = vals[:cols - 1]
+    for table in ("e2m3", "e3m2", "e2m1"):
+        want = orc.per_token_kernel_sem(x, table, out_dtype)
+        got = ops.quant_rows(x.to(dev), table, cols, out_dtype)
+        assert_bits_equal(got, want, f"rows32 {table} cols={cols} -> {out_dtype}")
+    assert_bits_equal(ops.quant_rows(x[:1].to(dev), "e2m3", cols, out_dtype), orc.per_token_kernel_sem(x[:1], "e2m3", out_dtype), "one row")
