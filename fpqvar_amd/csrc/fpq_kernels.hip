@@ -510,15 +510,26 @@ __global__ __launch_bounds__(kBlock) void nearest_builtin_kernel(const float* __
 
 // ---------------------------------------------------------------------------------
 // "any NaN in the tensor => the whole result is zero" (the reference's global clamp with a
-// NaN bound, tr/quant_utils.py:421-422): second launch, exits at once when the flag is clear.
+// NaN bound, tr/quant_utils.py:421-422): second launch, a handful of workgroups that exit at once when the flag is
+// clear.  scratch[0] = the flag the quantizer raised, scratch[1] = a ticket counter: every workgroup takes a ticket
+// AFTER it has read the flag, the one that draws the last ticket clears both words - the scratch is zero again when
+// the launch ends (no memset per call, and a captured graph can be replayed).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void zero_if_flag_kernel(uint8_t* __restrict__ out, int64_t n_bytes,
-                                                             const uint32_t* __restrict__ flag) {
-  if (*flag == 0u) return;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  const int64_t n16 = ((uintptr_t)out & 15) == 0 ? n_bytes / 16 : 0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) ((u32x4*)out)[i] = u32x4{0, 0, 0, 0};
-  for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_bytes; i += stride) out[i] = 0;
+constexpr int kFixupBlocks = 64;
+__global__ __launch_bounds__(kBlock) void zero_if_flag_kernel(uint8_t* __restrict__ out, int64_t n_bytes, uint32_t* scratch) {
+  __shared__ uint32_t f;
+  if (threadIdx.x == 0) f = __hip_atomic_load(scratch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (f != 0u) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t n16 = ((uintptr_t)out & 15) == 0 ? n_bytes / 16 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) ((u32x4*)out)[i] = u32x4{0, 0, 0, 0};
+    for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_bytes; i += stride) out[i] = 0;
+  }
+  if (threadIdx.x == 0 && atomicAdd(scratch + 1, 1u) == gridDim.x - 1) {   // every workgroup has read the flag by now
+    __hip_atomic_store(scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(scratch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1423,7 +1434,7 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   if (!x || !out) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   uint32_t* flag = (uint32_t*)nan_flag;
-  if (flag && hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return FPQ_ERR_LAUNCH;
+  if (flag && (((uintptr_t)flag) & 7) != 0) return FPQ_ERR_ARG;
   int rc;
   if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
     // int_neg/e2m3_pos needs a 2048-entry table (too big for the kernel arguments): every workgroup
@@ -1452,8 +1463,7 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   }
   if (rc != FPQ_OK || !flag) return rc;
   const int64_t n_bytes = rows * cols * (out_dtype == FPQ_F16 ? 2 : 4);
-  hipLaunchKernelGGL(zero_if_flag_kernel, dim3(grid_for((n_bytes / 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                     (uint8_t*)out, n_bytes, flag);
+  hipLaunchKernelGGL(zero_if_flag_kernel, dim3(kFixupBlocks), dim3(kBlock), 0, st, (uint8_t*)out, n_bytes, flag);
   return check_launch();
 }
 

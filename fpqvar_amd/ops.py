@@ -225,8 +225,7 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
     with torch.cuda.device(x.device):
         clip_ptr, strength, flag_ptr = None, 1.0, None
         if clipping_strength is not None and float(clipping_strength) == 1.0:
-            flag = torch.empty(1, dtype=torch.int32, device=x.device)
-            flag_ptr = flag.data_ptr()
+            flag_ptr = _nan_scratch(x.device).data_ptr()
         elif clipping_strength is not None:
             am = absmax(xc)
             clip_ptr, strength = am.data_ptr(), float(clipping_strength)
@@ -234,6 +233,19 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
                                         TABLE_IDS[pos_table], dtype_id(x.dtype), dtype_id(out_dtype), clip_ptr,
                                         strength, flag_ptr, stream_ptr(x.device)), "fpq_quant_rows_dual")
     return out
+
+
+_NAN_SCRATCH = {}
+
+
+def _nan_scratch(device: torch.device) -> torch.Tensor:
+    """8 zeroed bytes per (device, stream) for fpq_quant_rows_dual's NaN flag: the fix-up launch leaves them zero, so
+    one allocation serves every call on that stream (include/fpq.h)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _NAN_SCRATCH.get(key)
+    if t is None:
+        t = _NAN_SCRATCH[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return t
 
 
 def quant_nearest_argmin(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:

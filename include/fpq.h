@@ -160,11 +160,13 @@ int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols,
  * +-(T)(clip_strength * absmax) first (tr/quant_utils.py:421-422).  A NaN bound
  * turns every element into NaN, hence the whole output into zeros, exactly as
  * torch.clamp does.
- * nan_flag: NULL, or 4 bytes of device scratch.  With clip_strength == 1.0 the clamp is
- * the identity unless x holds a NaN (then the bound is NaN and the result all zeros);
- * passing scratch here reproduces exactly that WITHOUT the absmax pass: the kernel
- * raises the flag when it meets a NaN and a second launch (which exits at once when the
- * flag is clear) zero-fills `out`.  The scratch is cleared on the stream first. */
+ * nan_flag: NULL, or 8 bytes of device scratch (8-byte aligned) that are ZERO on entry.  With
+ * clip_strength == 1.0 the clamp is the identity unless x holds a NaN (then the bound is NaN and
+ * the result all zeros); passing scratch here reproduces exactly that WITHOUT the absmax pass: the
+ * kernel raises word 0 when it meets a NaN and a second, 64-workgroup launch (which exits at once
+ * when the flag is clear) zero-fills `out` and leaves the scratch zero again - allocate and zero it
+ * once, reuse it for every call on the same stream (two launches per call, no memset; a captured
+ * graph replays correctly).  Calls that may overlap on different streams need their own scratch. */
 int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table,
                         int pos_table, int in_dtype, int out_dtype, const void* clip_absmax,
                         float clip_strength, void* nan_flag, fpq_stream_t stream);

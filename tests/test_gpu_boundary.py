@@ -133,3 +133,46 @@ def test_calibrate_codes_exchange_rejects_a_custom_quantizer(dev):
     w = {"a": torch.randn(4, 128, device=dev)}
     with pytest.raises(ValueError):
         cal.calibrate_sharded(w, quantize=lambda n, t: t.half(), exchange="codes")
+
+
+def test_dual_nan_flag_scratch_cleans_itself(dev):
+    """fp_quant_e1m2_neg_e2m1_pos_per_group_cuda's NaN rule (tr/quant_utils.py:421-422: a NaN anywhere zeroes the whole
+    result) runs as quantizer + 64-workgroup fix-up with NO memset: the fix-up leaves the scratch zero, so NaN and
+    clean calls can alternate on one stream, eagerly and as a replayed graph."""
+    from fpqvar_amd import ops, quant_utils as qu
+    g = torch.Generator().manual_seed(5)
+    clean = torch.nn.functional.gelu(torch.randn(300, 7680, generator=g)).half()
+    dirty = clean.clone()
+    dirty[123, 4567] = float("nan")
+    want_clean = orc.dual_per_group_kernel_sem(clean, "e1m2_neg", "e2m1_pos", 128, 1.0)
+    c, d = clean.to(dev), dirty.to(dev)
+    for step in range(6):
+        if step % 2 == 0:
+            assert_bits_equal(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(c, 4, 128), want_clean, f"clean call {step}")
+        else:
+            got = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(d, 4, 128)
+            assert not got.any() and not torch.isnan(got).any(), f"NaN call {step}: everything must be +0"
+        assert not ops._nan_scratch(dev).any(), "the scratch must be zero again after every call"
+    # tiny inputs (fewer elements than fix-up lanes), fp32 input, per-token rows
+    t = torch.tensor([[1.0, -2.0, float("nan"), 0.5] * 32], dtype=torch.float16)
+    assert not qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(t.to(dev), 4, 128).any()
+    assert_bits_equal(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(clean[:1].float().to(dev), 4, 128),
+                      orc.dual_per_group_kernel_sem(clean[:1].float(), "e1m2_neg", "e2m1_pos", 128, 1.0), "fp32 after NaN")
+    # a captured call, replayed with clean / dirty / clean contents of its static input
+    static_in = c.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(static_in, 4, 128)      # warm-up on the capture stream
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            static_out = qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(static_in, 4, 128)
+    torch.cuda.current_stream().wait_stream(s)
+    for step, src in enumerate((c, d, c, d, d, c)):
+        static_in.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        if src is c:
+            assert_bits_equal(static_out, want_clean, f"replay {step} (clean)")
+        else:
+            assert not static_out.any(), f"replay {step} (NaN)"
