@@ -141,6 +141,25 @@ def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device: torch.device):
+    """`with device_guard(x.device):` = torch.cuda.device(x.device), minus its cost (2-3 us of the ~11 us a small call
+    spends on the host) in the usual case that the tensor already lives on the current device."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
 def require_gpu(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{what}: expected a tensor on the GPU, got device {t.device} "

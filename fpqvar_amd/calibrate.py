@@ -145,7 +145,7 @@ class LocalShard:
         if self._table is None:
             return self.slab
         lib, _lib = self._lib.lib(), self._lib
-        with torch.cuda.device(self.device):
+        with _lib.device_guard(self.device):
             _lib.check(lib.fpq_quant_rows_segments(self._table.data_ptr(), len(self.names), self.max_rows, _GROUP,
                                                    self.table_id, _lib.F32, _lib.dtype_id(self.out_dtype),
                                                    _lib.stream_ptr(self.device)), "fpq_quant_rows_segments")

@@ -967,7 +967,10 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
     // second generation (fpq_adaln.h): fp16 rows of up to 2560 channels, one batch entry per workgroup
     if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !getenv("FPQ_ADALN_V1")) {
       const char* rows_env = getenv("FPQ_ADALN_ROWS");
-      int rows_per_wg = rows_env ? atoi(rows_env) : 16;
+      // 16 rows per workgroup amortise the staging of the modulation planes; small launches (the early scale steps of a
+      // generation: 100 .. 3600 rows) are latency-bound instead and want every CU busy: 4 rows = one per wavefront
+      // (measured as one graph-replayed call, profiles/r02_small_steps.json: 900 rows 10.1 -> 5.9 us)
+      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 32768 ? 16 : rows >= 8192 ? 8 : 4);
       if (rows_per_wg < 1) rows_per_wg = 1;
       const int64_t L = ad.rows_per_batch;
       const int64_t n_batches = (rows + L - 1) / L;

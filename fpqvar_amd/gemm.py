@@ -12,7 +12,7 @@ import torch
 
 import ctypes
 
-from ._lib import GemmEpilogue, check, dtype_id, lib, require_gpu, stream_ptr
+from ._lib import GemmEpilogue, check, dtype_id, lib, require_gpu, stream_ptr, device_guard
 
 E2M1_LEVELS = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
 
@@ -55,7 +55,7 @@ def quantize_mx(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     rows = xc.numel() // k
     codes = torch.empty((rows, k // 2), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows, k // 128), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows_codes_mx(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
                                             dtype_id(x.dtype), stream_ptr(x.device)), "fpq_quant_rows_codes_mx")
     return codes, scales
@@ -115,7 +115,7 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     _check_operand("linear_fp4(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), a_codes.device)
     ep, keep, out = _epilogue("linear_fp4", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
-    with torch.cuda.device(a_codes.device):
+    with device_guard(a_codes.device):
         check(lib().fpq_gemm_fp4_mx_ex(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
                                        dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
                                        tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp4_mx_ex")
@@ -177,7 +177,7 @@ def quantize_fp8(x: torch.Tensor, table: str = "e2m3") -> Tuple[torch.Tensor, to
     rows = xc.numel() // k
     codes = torch.empty((rows, k), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows,), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows_codes_fp8(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
                                              TABLE_IDS[_FP8_TABLES[table]], dtype_id(x.dtype), stream_ptr(x.device)),
               "fpq_quant_rows_codes_fp8")
@@ -204,7 +204,7 @@ def linear_fp8(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     _check_operand("linear_fp8(weight)", w_codes, w_scales, outs, k, outs, a_codes.device)
     ep, keep, out = _epilogue("linear_fp8", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
-    with torch.cuda.device(a_codes.device):
+    with device_guard(a_codes.device):
         check(lib().fpq_gemm_fp8_rows_ex(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
                                          w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
                                          out.data_ptr(), tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp8_rows_ex")
@@ -253,7 +253,7 @@ def quantize_fp6(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     rows = xc.numel() // k
     codes = torch.empty((rows, k * 3 // 4), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows,), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows_codes_fp6(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
                                              TABLE_IDS["e2m3"], dtype_id(x.dtype), stream_ptr(x.device)),
               "fpq_quant_rows_codes_fp6")
@@ -286,7 +286,7 @@ def linear_fp6(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     _check_operand("linear_fp6(weight)", w_codes, w_scales, outs, a_codes.shape[1], outs, a_codes.device)
     ep, keep, out = _epilogue("linear_fp6", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
-    with torch.cuda.device(a_codes.device):
+    with device_guard(a_codes.device):
         check(lib().fpq_gemm_fp6_rows_ex(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
                                          w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
                                          out.data_ptr(), tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp6_rows_ex")

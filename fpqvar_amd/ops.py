@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import TABLE_IDS, check, dtype_id, lib, require_gpu, stream_ptr
+from ._lib import TABLE_IDS, check, dtype_id, lib, require_gpu, stream_ptr, device_guard
 
 
 def _contig(x: torch.Tensor) -> torch.Tensor:
@@ -34,7 +34,7 @@ def quant_nearest(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
         raise RuntimeError(f"quant_nearest: table must hold 1..256 entries, got {k}")
     tab = table.detach().reshape(-1).to(torch.float32).contiguous()
     z = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_nearest(x.data_ptr(), tab.data_ptr(), z.data_ptr(), x.numel(), k, dtype_id(x.dtype),
                                       stream_ptr(x.device)), "fpq_quant_nearest")
     return z
@@ -45,7 +45,7 @@ def quant_nearest_builtin(x: torch.Tensor, table: str) -> torch.Tensor:
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise RuntimeError("quant_nearest_builtin: x must be contiguous float32")
     z = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_nearest_builtin(x.data_ptr(), z.data_ptr(), x.numel(), TABLE_IDS[table],
                                               stream_ptr(x.device)), "fpq_quant_nearest_builtin")
     return z
@@ -62,7 +62,7 @@ def quant_rows(x: torch.Tensor, table: str, cols: int, out_dtype: Optional[torch
         raise RuntimeError(f"quant_rows: numel {n} is not a multiple of the row length {cols}")
     xc = _contig(x)
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[table],
                                    dtype_id(x.dtype), dtype_id(out_dtype), stream_ptr(x.device)), "fpq_quant_rows")
     return out
@@ -81,7 +81,7 @@ def gate_residual(y: torch.Tensor, gate: torch.Tensor, residual: torch.Tensor) -
         raise RuntimeError(f"gate_residual: shapes {tuple(y.shape)} {tuple(gate.shape)} {tuple(residual.shape)} do not fit")
     yc, gc, rc = _contig(y), _contig(g), _contig(residual)
     out = torch.empty_like(yc)
-    with torch.cuda.device(y.device):
+    with device_guard(y.device):
         check(lib().fpq_gate_residual(yc.data_ptr(), gc.data_ptr(), rc.data_ptr(), out.data_ptr(), rows, C,
                                       max(rows // g.shape[0], 1), stream_ptr(y.device)), "fpq_gate_residual")
     return out.view(y.shape)
@@ -109,7 +109,7 @@ def attention_blhc(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: flo
     if not (rows_ok(k) and rows_ok(v) and k.stride() == v.stride()):
         k, v = k.contiguous(), v.contiguous()
     out = torch.empty((B, Lq, H, c), dtype=torch.float16, device=q.device)
-    with torch.cuda.device(q.device):
+    with device_guard(q.device):
         check(lib().fpq_attention_blhc(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, Lkv, H, c,
                                        q.stride(0), q.stride(1), k.stride(0), k.stride(1), float(scale),
                                        stream_ptr(q.device)), "fpq_attention_blhc")
@@ -134,7 +134,7 @@ def kv_cache_step(cache: torch.Tensor, quant_start: int, quant_stop: int, k: tor
             raise RuntimeError("kv_cache_step: the (H, c) rows of k / v must be contiguous")
     if n and (k.stride() != v.stride()):
         raise RuntimeError("kv_cache_step: k and v must share their strides")
-    with torch.cuda.device(cache.device):
+    with device_guard(cache.device):
         check(lib().fpq_kv_cache_step(cache.data_ptr(), B, max_len, H * c, quant_start, quant_stop, k.data_ptr(),
                                       v.data_ptr(), k.stride(0) if n else 0, k.stride(1) if n else 0, new_start, n, group,
                                       TABLE_IDS[table], stream_ptr(cache.device)), "fpq_kv_cache_step")
@@ -150,7 +150,7 @@ def quant_rows_argmin(x: torch.Tensor, table: str, cols: int, clamp3: bool) -> t
         raise RuntimeError(f"quant_rows_argmin: numel {n} is not a multiple of the row length {cols}")
     xc = _contig(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows_argmin(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[table],
                                           dtype_id(x.dtype), int(clamp3), stream_ptr(x.device)),
               "fpq_quant_rows_argmin")
@@ -167,7 +167,7 @@ def quant_rows_neg_reverse(x: torch.Tensor, table: str, cols: int) -> torch.Tens
         raise RuntimeError(f"quant_rows_neg_reverse: numel {n} is not a multiple of the row length {cols}")
     xc = _contig(x)
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows_neg_reverse(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[table],
                                                dtype_id(x.dtype), stream_ptr(x.device)),
               "fpq_quant_rows_neg_reverse")
@@ -185,7 +185,7 @@ def quant_tensor_argmin(x: torch.Tensor, table: str) -> Tuple[torch.Tensor, torc
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     ws = torch.empty(_lib.TENSOR_WORKSPACE_BYTES // 4 + 1, dtype=torch.int32, device=x.device)   # maxima + the scale
     scale = ws[-1:].view(torch.float32)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_tensor_argmin(xc.data_ptr(), out.data_ptr(), scale.data_ptr(), ws.data_ptr(), xc.numel(),
                                             TABLE_IDS[table], dtype_id(x.dtype), stream_ptr(x.device)),
               "fpq_quant_tensor_argmin")
@@ -197,7 +197,7 @@ def absmax(x: torch.Tensor) -> torch.Tensor:
     require_gpu(x, "absmax")
     xc = _contig(x)
     buf = torch.empty(2 if x.dtype == torch.float16 else 1, dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_absmax(xc.data_ptr(), xc.numel(), dtype_id(x.dtype), buf.data_ptr(), stream_ptr(x.device)),
               "fpq_absmax")
     return buf[0]
@@ -222,7 +222,7 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
         raise RuntimeError(f"quant_rows_dual: numel {n} is not a multiple of the row length {cols}")
     xc = _contig(x)
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         clip_ptr, strength, flag_ptr = None, 1.0, None
         if clipping_strength is not None and float(clipping_strength) == 1.0:
             flag_ptr = _nan_scratch(x.device).data_ptr()
@@ -258,7 +258,7 @@ def quant_nearest_argmin(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("quant_nearest_argmin: the table must hold 1..256 entries")
     xc = _contig(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_nearest_argmin(xc.data_ptr(), t.data_ptr(), out.data_ptr(), xc.numel(), t.numel(),
                                              dtype_id(x.dtype), stream_ptr(x.device)), "fpq_quant_nearest_argmin")
     return out
@@ -279,7 +279,7 @@ def quant_rows_dual_argmin(x: torch.Tensor, neg_table: str, pos_table: str, cols
     if n == 0:
         return out
     amax = absmax(xc)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows_dual_argmin(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[neg_table],
                                                TABLE_IDS[pos_table], dtype_id(x.dtype), amax.data_ptr(),
                                                float(clipping_strength), stream_ptr(x.device)),
@@ -299,7 +299,7 @@ def quant_rows_codes(x: torch.Tensor, table: str, cols: int, pack_nibbles: bool 
     ccols = (cols + 1) // 2 if pack_nibbles else cols
     codes = torch.empty((rows, ccols), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows,), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_quant_rows_codes(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, cols,
                                          TABLE_IDS[table], dtype_id(x.dtype), int(pack_nibbles),
                                          stream_ptr(x.device)), "fpq_quant_rows_codes")
@@ -319,7 +319,7 @@ def dequant_rows_codes(codes: torch.Tensor, scales: torch.Tensor, table: str, co
         raise RuntimeError(f"dequant_rows_codes: {codes.numel()} code bytes do not match {rows} rows of {cols} "
                            f"{'nibble-packed ' if pack_nibbles else ''}codes ({rows * row_bytes} bytes)")
     out = torch.empty((rows, cols), dtype=out_dtype, device=codes.device)
-    with torch.cuda.device(codes.device):
+    with device_guard(codes.device):
         check(lib().fpq_dequant_rows_codes(codes.data_ptr(), scales.data_ptr(), out.data_ptr(), rows, cols,
                                            TABLE_IDS[table], dtype_id(scales.dtype), dtype_id(out_dtype),
                                            int(pack_nibbles), stream_ptr(codes.device)), "fpq_dequant_rows_codes")

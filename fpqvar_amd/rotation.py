@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import TABLE_IDS, check, dtype_id, lib, require_gpu, stream_ptr
+from ._lib import TABLE_IDS, check, dtype_id, lib, require_gpu, stream_ptr, device_guard
 
 
 def sign_vector(size: int = 128, seed: int = 42) -> torch.Tensor:
@@ -146,7 +146,7 @@ def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor]
         sm_ptr = sm.data_ptr()
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
     rot = torch.empty_like(out) if return_rotated else None
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_rotate_quant_rows(xc.data_ptr(), out.data_ptr(), rot.data_ptr() if rot is not None else None,
                                           x.numel() // c, c, dtype_id(x.dtype), sm_ptr, mask, TABLE_IDS[table],
                                           stream_ptr(x.device)), "fpq_rotate_quant_rows")
@@ -178,7 +178,7 @@ def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: O
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     codes = torch.empty((rows, c // 2), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows, c // 128), dtype=torch.float16, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_rotate_quant_rows_codes_mx(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c,
                                                    dtype_id(x.dtype), sm_ptr, mask, stream_ptr(x.device)),
               "fpq_rotate_quant_rows_codes_mx")
@@ -203,7 +203,7 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     codes = torch.empty((bsz * seq, c // 2), dtype=torch.uint8, device=x.device)
     scales = torch.empty((bsz * seq, c // 128), dtype=torch.float16, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_adaln_rotate_quant_rows_codes_mx(
             xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), bsz * seq, c, dtype_id(x.dtype), sc.data_ptr(),
             sh.data_ptr(), dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, stream_ptr(x.device)),
@@ -232,7 +232,7 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     rows = bsz * seq
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         if emit in ("fp8", "fp6"):
             if emit == "fp6" and table != "e2m3":
                 raise RuntimeError("adaln_rotate_quant_token: emit='fp6' is the E2M3 operand format")
@@ -283,7 +283,7 @@ def adaln_rotate_quant(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
     h = torch.empty_like(out) if return_intermediates else None
     y = torch.empty_like(out) if return_intermediates else None
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib().fpq_adaln_rotate_quant_rows(
             xc.data_ptr(), out.data_ptr(), h.data_ptr() if h is not None else None,
             y.data_ptr() if y is not None else None, bsz * seq, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),
