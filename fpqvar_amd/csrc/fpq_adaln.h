@@ -309,8 +309,8 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
       for (int j = 0; j < n; ++j) s[j] = row_scale16(m[j], a.fpos.gmax, a.inv_gpos);
 #pragma unroll
       for (int j = 0; j < n; ++j) {
-        if constexpr (CODES) cd[j] = codes_vec16(y[j], lut, a.shift, s[j].sf, s[j].inv);
-        else o[j] = quant_vec16<false>(y[j], lut, a.shift, s[j].sf, s[j].inv, s[j].s16x2, 0.f, 0.f, 0u);
+        if constexpr (CODES) cd[j] = codes_vec16(y[j], lut, a.shift, s[j].inv, s[j].inv_lo);
+        else o[j] = quant_vec16<false>(y[j], lut, a.shift, s[j].inv, s[j].inv_lo, s[j].s16x2, 0.f, 0.f, 0u);
       }
 #pragma unroll
       for (int j = 0; j < n; ++j) {
@@ -344,11 +344,7 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint32_t wk = ys[c][k];
-            const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
-            const float y0 = mul_h_lo(wk, s.inv), y1 = mul_h_hi(wk, s.inv);
-            const float e0 = __builtin_fmaf(-y0, s.sf, x0), e1 = __builtin_fmaf(-y1, s.sf, x1);
-            const float r0 = __builtin_fmaf(e0, s.inv, y0), r1 = __builtin_fmaf(e1, s.inv, y1);
-            const uint32_t rb = f2h2(r0, r1);
+            const uint32_t rb = div_pair16(wk, s.inv, s.inv_lo, s.inv, s.inv_lo);
             const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
             cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
             cb[2 * k + 1] = lut[u >> (16 + a.shift)];
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
             __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
           }
         } else {
-          const u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+          const u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
           __builtin_nontemporal_store(o, out + row * vpr + v);
         }
       }

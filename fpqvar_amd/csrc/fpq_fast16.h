@@ -104,6 +104,19 @@ __device__ __forceinline__ float resid_h_hi(uint32_t w, float y, float s) {
   return d;
 }
 
+// xn = half(x / s) for the two halves of w: 1/s travels as an unevaluated sum inv_hi + inv_lo (error ~2^-46), the
+// fma x * inv_hi + (x * inv_lo) is exact up to that, and v_fma_mixlo/hi_f16 round ONCE, straight to fp16.  x and s
+// carry 11-bit significands, so x / s is never a rounding tie of fp16 and lies more than 2^-24 (relative) away from
+// every rounding boundary: the result is the correctly rounded quotient - torch's fp16 division - in 2 instructions
+// per element (tests/test_gpu_parity.py::test_every_fp16_pair_fast_path_vs_ieee_path sweeps all 1.0e9 pairs).
+__device__ __forceinline__ uint32_t div_pair16(uint32_t w, float ih0, float il0, float ih1, float il1) {
+  const float t0 = mul_h_lo(w, il0), t1 = mul_h_hi(w, il1);
+  uint32_t d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(ih0), "v"(t0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(w), "v"(ih1), "v"(t1));
+  return d;
+}
+
 // the two table entries of a packed pair of bucket patterns as ONE packed register: byte offsets straight from the
 // pattern (bucket * 2 == (pattern >> (shift - 1)) & mask), 16-bit loads into the low / high half
 __device__ __forceinline__ uint32_t lut_pair16(const uint16_t* lut, uint32_t u, int shift) {
@@ -151,42 +164,25 @@ __device__ __forceinline__ void lut16_fill(uint16_t* lut, const Lut16Args& a) {
   }
 }
 
-// Quantize the 8 halves of one 16-byte vector.  s16x2 = scale replicated in both
-// halves; sf = (float)scale; inv = sf == 0 ? 0 : 1/sf (approximate reciprocal).
-// In DUAL mode each element picks the negative or positive side's scale.
+// Quantize the 8 halves of one 16-byte vector.  s16x2 = scale replicated in both halves; inv_hi + inv_lo = 1 / scale
+// (0 for a zero scale).  In DUAL mode each element picks the negative or positive side's scale.
 template <bool DUAL>
-__device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut, int shift, float sf_n, float inv_n,
-                                             uint32_t s16x2_n, float sf_p, float inv_p, uint32_t s16x2_p) {
+__device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut, int shift, float ih_n, float il_n,
+                                             uint32_t s16x2_n, float ih_p, float il_p, uint32_t s16x2_p) {
   u32x4 o;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    uint32_t wk = w[k];
-#if defined(FPQ_PKDIV) && FPQ_PKDIV
-    float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
-#endif
-    float s0 = sf_n, s1 = sf_n, i0 = inv_n, i1 = inv_n;
+    const uint32_t wk = w[k];
+    float h0 = ih_n, h1 = ih_n, l0 = il_n, l1 = il_n;
     uint32_t sc = s16x2_n;
     if (DUAL) {
-      bool n0 = (wk & 0x8000u) != 0, n1 = (wk & 0x80000000u) != 0;
-      s0 = n0 ? sf_n : sf_p;  i0 = n0 ? inv_n : inv_p;
-      s1 = n1 ? sf_n : sf_p;  i1 = n1 ? inv_n : inv_p;
+      const bool n0 = (wk & 0x8000u) != 0, n1 = (wk & 0x80000000u) != 0;
+      h0 = n0 ? ih_n : ih_p;  l0 = n0 ? il_n : il_p;
+      h1 = n1 ? ih_n : ih_p;  l1 = n1 ? il_n : il_p;
       sc = (n0 ? (s16x2_n & 0xFFFFu) : (s16x2_p & 0xFFFFu)) | (n1 ? (s16x2_n & 0xFFFF0000u) : (s16x2_p & 0xFFFF0000u));
     }
-#if defined(FPQ_PKDIV) && FPQ_PKDIV
-    // the two elements of the word go through the packed fp32 ALU together
-    typedef float f2q_t __attribute__((ext_vector_type(2)));
-    const f2q_t xx = {x0, x1}, ii = {i0, i1}, ss = {s0, s1};
-    const f2q_t yy = xx * ii;
-    const f2q_t ee = __builtin_elementwise_fma(-yy, ss, xx);
-    const f2q_t rr = __builtin_elementwise_fma(ee, ii, yy);
-    uint32_t rb = f2h(rr.x) | (f2h(rr.y) << 16);
-#else
-    float y0 = mul_h_lo(wk, i0), y1 = mul_h_hi(wk, i1);
-    float e0 = resid_h_lo(wk, y0, s0), e1 = resid_h_hi(wk, y1, s1);
-    float r0 = __builtin_fmaf(e0, i0, y0), r1 = __builtin_fmaf(e1, i1, y1);
-    uint32_t rb = f2h2(r0, r1);
-#endif
-    uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
+    const uint32_t rb = div_pair16(wk, h0, l0, h1, l1);
+    const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
     o[k] = pk_mul_f16(lut_pair16(lut, u, shift), sc);
   }
   return o;
@@ -194,15 +190,11 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
 
 // Same normalisation and bucketing as quant_vec16, but the table holds 4-bit hardware codes (OCP E2M1
 // nibbles, fpq_gemm_fp4.h): returns the 8 codes of the vector packed low nibble first.
-__device__ __forceinline__ uint32_t codes_vec16(const u32x4& w, const uint16_t* lut, int shift, float sf, float inv) {
+__device__ __forceinline__ uint32_t codes_vec16(const u32x4& w, const uint16_t* lut, int shift, float inv_hi, float inv_lo) {
   uint32_t packed = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint32_t wk = w[k];
-    const float y0 = mul_h_lo(wk, inv), y1 = mul_h_hi(wk, inv);
-    const float e0 = resid_h_lo(wk, y0, sf), e1 = resid_h_hi(wk, y1, sf);
-    const float r0 = __builtin_fmaf(e0, inv, y0), r1 = __builtin_fmaf(e1, inv, y1);
-    const uint32_t rb = f2h2(r0, r1);
+    const uint32_t rb = div_pair16(w[k], inv_hi, inv_lo, inv_hi, inv_lo);
     const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
     const uint32_t c0 = lut[(u & 0xFFFFu) >> shift], c1 = lut[u >> (16 + shift)];
     packed |= (c0 | (c1 << 4)) << (8 * k);
@@ -239,7 +231,9 @@ __device__ __forceinline__ uint32_t vec_absmax16_dual(const u32x4& w, uint32_t& 
 }
 
 struct RowScale16 {
-  float sf, inv;
+  float sf;         // (float)scale
+  float inv;        // 1 / scale = inv + inv_lo, inv = the fp32 nearest (one Newton step on v_rcp_f32), inv_lo the rest;
+  float inv_lo;     // both 0 for a zero scale: x / 0 -> level 0 -> +0
   uint32_t s16x2;
 };
 
@@ -247,7 +241,12 @@ __device__ __forceinline__ RowScale16 row_scale16(uint32_t amax_bits, float g, f
   RowScale16 r;
   uint32_t sb = scale_bits_f16(amax_bits, g, inv_g);
   r.sf = h2f(sb);
-  r.inv = (r.sf == 0.0f) ? 0.0f : __builtin_amdgcn_rcpf(r.sf);   // s = 0: x/0 -> level 0 -> +0
+  const float r0 = __builtin_amdgcn_rcpf(r.sf);
+  const float r1 = __builtin_fmaf(__builtin_fmaf(-r.sf, r0, 1.0f), r0, r0);
+  const float lo = __builtin_fmaf(-r.sf, r1, 1.0f) * r1;          // 1/s - r1, to ~2^-46
+  const bool zero = r.sf == 0.0f;
+  r.inv = zero ? 0.0f : r1;
+  r.inv_lo = zero ? 0.0f : lo;
   r.s16x2 = sb | (sb << 16);
   return r;
 }
@@ -377,11 +376,11 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
         mp = row_max_dpp<LPR>(mp);
         RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
         dual_poison(sn, sp);
-        o = quant_vec16<true>(raw[u], lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+        o = quant_vec16<true>(raw[u], lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
       } else {
         uint32_t m = row_max_dpp<LPR>(vec_absmax16(raw[u]));
         RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-        o = quant_vec16<false>(raw[u], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+        o = quant_vec16<false>(raw[u], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
       }
       if (live[u]) {
         if (NTS) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void kv16_step_kernel(KvStepArgs k, Lut16Ar
     for (int u = 0; u < U; ++u) {
       const uint32_t m = row_max_dpp<LPR>(vec_absmax16(raw[u]));
       const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      const u32x4 o = quant_vec16<false>(raw[u], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      const u32x4 o = quant_vec16<false>(raw[u], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
       if (live[u]) p[v0 + u * kBlock] = o;
     }
   } else {
@@ -492,14 +491,14 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_pair_kernel(const u32x4* __
       mp = row_max_dpp<LPR>(mp > mp2 ? mp : mp2);
       RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
       dual_poison(sn, sp);
-      oa = quant_vec16<true>(ra, lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
-      ob = quant_vec16<true>(rb, lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+      oa = quant_vec16<true>(ra, lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
+      ob = quant_vec16<true>(rb, lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
     } else {
       const uint32_t m1 = vec_absmax16(ra), m2 = vec_absmax16(rb);
       const uint32_t m = row_max_dpp<LPR>(m1 > m2 ? m1 : m2);
       RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      oa = quant_vec16<false>(ra, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
-      ob = quant_vec16<false>(rb, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      oa = quant_vec16<false>(ra, lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
+      ob = quant_vec16<false>(rb, lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
     }
     if (live) {
       __builtin_nontemporal_store(oa, out + va);
@@ -595,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
     for (int c = 0; c < MAXC; ++c) {
       int64_t v = (int64_t)c * kBlock + threadIdx.x;
       if (v < vec_per_row) {
-        u32x4 o = quant_vec16<DUAL>(raw[c], lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+        u32x4 o = quant_vec16<DUAL>(raw[c], lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
         __builtin_nontemporal_store(o, orow + v);
       }
     }
@@ -660,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t*
     for (int c = 0; c < MAXC; ++c) {
       const int64_t v = (int64_t)c * 64 + lane;
       if (v < vpr) {
-        u32x4 o = quant_vec16<DUAL>(raw[c], lut, a.shift, sn.sf, sn.inv, sn.s16x2, sp.sf, sp.inv, sp.s16x2);
+        u32x4 o = quant_vec16<DUAL>(raw[c], lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
         __builtin_nontemporal_store(o, orow + v);
       }
     }
@@ -716,9 +715,21 @@ __device__ __forceinline__ float xlane_xor2(float v) {
 // packed fp32 ALU (v_pk_add_f32 / v_pk_fma_f32: two results per issue slot).
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
+#ifndef FPQ_FWHT_SWZ
+#define FPQ_FWHT_SWZ 0   // 1: lane ^ 1 / lane ^ 2 exchanges through ds_swizzle (LDS crossbar) instead of DPP moves (VALU)
+#endif
+__device__ __forceinline__ float xlane_xor1s(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x80B1));   // quad perm [1,0,3,2]
+}
+__device__ __forceinline__ float xlane_xor2s(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x804E));   // quad perm [2,3,0,1]
+}
 __device__ __forceinline__ f2_t xlane2(f2_t v, int which) {
   f2_t r;
   if (which == 1) { r.x = xlane_xor1(v.x); r.y = xlane_xor1(v.y); }
+#if FPQ_FWHT_SWZ
+  else if (which == 2) { r.x = xlane_xor2s(v.x); r.y = xlane_xor2s(v.y); }
+#endif
   else if (which == 2) { r.x = xlane_xor2(v.x); r.y = xlane_xor2(v.y); }
   else if (which == 4) { r.x = xlane_xor4(v.x); r.y = xlane_xor4(v.y); }
   else { r.x = xlane_xor8(v.x); r.y = xlane_xor8(v.y); }
@@ -788,7 +799,12 @@ __device__ __forceinline__ void fwht128_h_n(const u32x4 (&w)[N], float (&t)[N][8
     if (q >= n) continue;
     uint32_t pw[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pw[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[q][k], 0xB1, 0xF, 0xF, true);
+    for (int k = 0; k < 4; ++k)
+#if FPQ_FWHT_SWZ
+      pw[k] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w[q][k], 0x80B1);
+#else
+      pw[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[q][k], 0xB1, 0xF, 0xF, true);
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // element 2k, 2k+1 -> pair register (k & 1 ? .. ): t index j pairs with j + 4
       const float lo = fmix_hsh_lo(w[q][k], s1, pw[k]), hi = fmix_hsh_hi(w[q][k], s1, pw[k]);
@@ -923,29 +939,36 @@ __global__ __launch_bounds__(kBlock) void rotate_quant16_kernel(const void* __re
       __syncthreads();
       first = false;
     }
+    // the U vectors of a lane go through the stages together (stage-major: U independent dependency chains)
+    u32x4 ws[U], ys[U];
+    float tt[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ws[u][k] = raw[u][k] ^ sx[k];
+    fwht128_h_n<U>(ws, tt, U, lg);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ys[u][k] = mul2_to_h2(tt[u][2 * k], tt[u][2 * k + 1], r.c_h);
+    uint32_t ms[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ms[u] = vec_absmax16(ys[u]);
+    row_max_dpp16_n<U>(ms, U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      u32x4 ws[1];
-      float tt[1][8];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ws[0][k] = raw[u][k] ^ sx[k];
-      fwht128_h_n<1>(ws, tt, 1, lg);
-      const float(&t)[8] = tt[0];
-      u32x4 y;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = mul2_to_h2(t[2 * k], t[2 * k + 1], r.c_h);
+      const u32x4 y = ys[u];
       if (EMIT && live[u]) __builtin_nontemporal_store(y, rot_out + v0 + u * kBlock);
-      uint32_t m = row_max_dpp<16>(vec_absmax16(y));
-      RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      RowScale16 s = row_scale16(ms[u], a.fpos.gmax, a.inv_gpos);
       if constexpr (CODES) {
-        const uint32_t c = codes_vec16(y, lut, a.shift, s.sf, s.inv);
+        const uint32_t c = codes_vec16(y, lut, a.shift, s.inv, s.inv_lo);
         if (live[u]) {
           const int64_t v = v0 + u * kBlock;
           ((uint32_t*)out)[v] = c;
           if (lg == 0) r.code_scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
         }
       } else {
-        u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+        u32x4 o = quant_vec16<false>(y, lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
         if (live[u]) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
       }
     }
@@ -1161,13 +1184,13 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
     uint32_t m = row_max_dpp<16>(vec_absmax16(y));
     RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
     if constexpr (CODES) {
-      const uint32_t cd = codes_vec16(y, lut, a.shift, s.sf, s.inv);
+      const uint32_t cd = codes_vec16(y, lut, a.shift, s.inv, s.inv_lo);
       if (live && row_live) {
         ((uint32_t*)out)[row * vpr + v] = cd;
         if (lg == 0) r.code_scales[(row * vpr + v) >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
       }
     } else {
-      u32x4 o = quant_vec16<false>(y, lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+      u32x4 o = quant_vec16<false>(y, lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
       if (live && row_live) __builtin_nontemporal_store(o, out + row * vpr + v);
     }
   }
@@ -1188,11 +1211,7 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint32_t wk = ws[k];
-            const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
-            const float y0 = mul_h_lo(wk, s.inv), y1 = mul_h_hi(wk, s.inv);
-            const float e0 = __builtin_fmaf(-y0, s.sf, x0), e1 = __builtin_fmaf(-y1, s.sf, x1);
-            const float r0 = __builtin_fmaf(e0, s.inv, y0), r1 = __builtin_fmaf(e1, s.inv, y1);
-            const uint32_t rb = f2h2(r0, r1);
+            const uint32_t rb = div_pair16(wk, s.inv, s.inv_lo, s.inv, s.inv_lo);
             const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
             cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
             cb[2 * k + 1] = lut[u >> (16 + a.shift)];
@@ -1218,7 +1237,7 @@ __global__ __launch_bounds__(kBlock) void adaln_rotate_quant16_kernel(const void
             __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
           }
         } else {
-          u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.sf, s.inv, s.s16x2, 0.f, 0.f, 0u);
+          u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
           __builtin_nontemporal_store(o, out + row * vpr + v);
         }
       }

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void rows16_codes_mx_kernel(const u32x4* __
     const uint32_t m = row_max_dpp<16>(vec_absmax16(w));
     const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
     if ((threadIdx.x & 15) == 0) scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
-    const uint32_t packed = codes_vec16(w, lut, a.shift, s.sf, s.inv);
+    const uint32_t packed = codes_vec16(w, lut, a.shift, s.inv, s.inv_lo);
     codes[v] = packed;
   }
 }

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void rows16_codes6_wave_kernel(const uint16
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           uint32_t lo4, hi4;                       // eight 6-bit codes, one per byte
-          codes8_vec16(raw[c][v], lut, a.shift, s.sf, s.inv, lo4, hi4);
+          codes8_vec16(raw[c][v], lut, a.shift, s.inv, s.inv_lo, lo4, hi4);
           // 8 codes = 48 bits at bit offset 48 * v
           const uint64_t p48 = (uint64_t)((lo4 & 0x3Fu) | ((lo4 >> 2) & 0xFC0u) | ((lo4 >> 4) & 0x3F000u) | ((lo4 >> 6) & 0xFC0000u)) |
                                ((uint64_t)((hi4 & 0x3Fu) | ((hi4 >> 2) & 0xFC0u) | ((hi4 >> 4) & 0x3F000u) | ((hi4 >> 6) & 0xFC0000u)) << 24);

@@ -198,17 +198,13 @@ __global__ __launch_bounds__(kBlock) void rows_codes_fp8_kernel(const Tin* __res
 // Fast form for fp16 rows of up to 4096 elements (per-token activations, C = 1920 / 2304): one wavefront owns a row,
 // the row stays in registers between the reduction and the rounding, levels come out of the same bucket table as the
 // fake-quant kernels with E4M3 bytes as entries (fpq_fast16.h).
-__device__ __forceinline__ void codes8_vec16(const u32x4& w, const uint16_t* lut, int shift, float sf, float inv,
+__device__ __forceinline__ void codes8_vec16(const u32x4& w, const uint16_t* lut, int shift, float inv_hi, float inv_lo,
                                              uint32_t& lo4, uint32_t& hi4) {
   uint32_t c[8];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t wk = w[k];
-    const float x0 = h2f(wk & 0xFFFFu), x1 = h2f(wk >> 16);
-    const float y0 = mul_h_lo(wk, inv), y1 = mul_h_hi(wk, inv);
-    const float e0 = __builtin_fmaf(-y0, sf, x0), e1 = __builtin_fmaf(-y1, sf, x1);
-    const float r0 = __builtin_fmaf(e0, inv, y0), r1 = __builtin_fmaf(e1, inv, y1);
-    const uint32_t rb = f2h2(r0, r1);
+    const uint32_t rb = div_pair16(wk, inv_hi, inv_lo, inv_hi, inv_lo);
     const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
     c[2 * k] = lut[(u & 0xFFFFu) >> shift];
     c[2 * k + 1] = lut[u >> (16 + shift)];
@@ -251,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void rows16_codes8_wave_kernel(const uint16
       const int64_t v = (int64_t)c * 64 + lane;
       if (v < vpr) {
         uint32_t c_lo, c_hi;
-        codes8_vec16(raw[c], lut, a.shift, s.sf, s.inv, c_lo, c_hi);
+        codes8_vec16(raw[c], lut, a.shift, s.inv, s.inv_lo, c_lo, c_hi);
         __builtin_nontemporal_store(u32x2{c_lo, c_hi}, crow + v);
       }
     }
