@@ -27,17 +27,86 @@ def sign_vector(size: int = 128, seed: int = 42) -> torch.Tensor:
 
 
 def sylvester(n: int) -> torch.Tensor:
-    assert n & (n - 1) == 0, "only power-of-two Hadamard sizes (the reference's block_rotate uses 128)"
+    assert n & (n - 1) == 0, "Sylvester's construction gives power-of-two sizes only"
     h = torch.ones(1, 1, dtype=torch.float64)
     while h.shape[0] < n:
         h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
     return h
 
 
+# ---- Hadamard matrices of the non-power-of-two orders the full-width rotation needs ---------------------------
+# The reference keeps literal 12 .. 172-row tables (rotate_utils/hadamard_utils.py:164-4204, taken from Sloane's
+# library via quip-sharp).  Eight of them ARE Paley's constructions entry for entry (checked against the reference's
+# tables; fixtures in tests/golden): orders 12, 20, 60, 108, 140 = Paley I over GF(11), GF(19), GF(59), GF(107),
+# GF(139); orders 36 and 28 = Paley II over GF(17) and GF(13); order 40 = [[H20, H20], [H20, -H20]].  They are
+# generated here from the quadratic-residue character instead of being stored.  VAR's widths need exactly these:
+# 1280 = 40 * 32 (d20), 1536 = 12 * 128 (d24), 1920 = 60 * 32 (d30), 2304 = 36 * 64 (d36).  Orders 172, 156 and 52
+# (other constructions) are not provided.
+def _chi(q: int):
+    """Quadratic-residue character of GF(q), q an odd prime: chi[x] = +1 (non-zero square), -1 (non-square), 0."""
+    squares = {(x * x) % q for x in range(1, q)}
+    return [0] + [1 if x in squares else -1 for x in range(1, q)]
+
+
+def paley_hadamard_i(q: int) -> torch.Tensor:
+    """Order q + 1, q = 3 (mod 4) prime, normalised as the reference's tables are: first column +1, first row
+    (+1, -1, ..., -1), the q x q core is the right-circulant I - S with S[i][j] = chi(j - i)."""
+    assert q % 4 == 3
+    chi = torch.tensor(_chi(q), dtype=torch.float64)
+    idx = (torch.arange(q)[None, :] - torch.arange(q)[:, None]) % q
+    h = torch.ones(q + 1, q + 1, dtype=torch.float64)
+    h[0, 1:] = -1.0
+    h[1:, 1:] = torch.eye(q, dtype=torch.float64) - chi[idx]
+    return h
+
+
+def paley_hadamard_ii(q: int) -> torch.Tensor:
+    """Order 2 (q + 1), q = 1 (mod 4) prime: with C the symmetric conference matrix [[0, 1], [1, chi(j - i)]],
+    H = [[C + I, C - I], [C - I, -C - I]] (the block layout of the reference's tables)."""
+    assert q % 4 == 1
+    chi = torch.tensor(_chi(q), dtype=torch.float64)
+    idx = (torch.arange(q)[None, :] - torch.arange(q)[:, None]) % q
+    c = torch.ones(q + 1, q + 1, dtype=torch.float64)
+    c[0, 0] = 0.0
+    c[1:, 1:] = chi[idx]
+    eye = torch.eye(q + 1, dtype=torch.float64)
+    return torch.cat([torch.cat([c + eye, c - eye], 1), torch.cat([c - eye, -c - eye], 1)], 0)
+
+
+_PALEY = {140: lambda: paley_hadamard_i(139), 108: lambda: paley_hadamard_i(107), 60: lambda: paley_hadamard_i(59),
+          36: lambda: paley_hadamard_ii(17), 28: lambda: paley_hadamard_ii(13),
+          40: lambda: torch.kron(sylvester(2), paley_hadamard_i(19)),          # the reference's had40 is the doubled had20
+          20: lambda: paley_hadamard_i(19), 12: lambda: paley_hadamard_i(11)}
+
+
+def get_hadK(n: int, transpose: bool = False):
+    """(hadK, K) with the reference's decision ladder (hadamard_utils.py:7-60): the first K of 172, 156, 140, 108,
+    60, 52, 36, 28, 40, 20, 12 that divides n (n / K must then be a power of two), else (None, 1) for a power of two."""
+    for k in (172, 156, 140, 108, 60, 52, 36, 28, 40, 20, 12):
+        if n % k == 0:
+            assert (n // k) & (n // k - 1) == 0
+            if k not in _PALEY:
+                raise NotImplementedError(f"the Hadamard matrix of order {k} (n = {n}) is not one of the generated "
+                                          f"constructions (orders {sorted(_PALEY)})")
+            h = _PALEY[k]()
+            return (h.T.contiguous() if transpose else h), k
+    assert n & (n - 1) == 0
+    return None, 1
+
+
+def hadamard_matrix(n: int) -> torch.Tensor:
+    """The +-1 matrix matmul_hadU applies (hadamard_utils.py:63-85): its radix-2 passes run over the LOW index bits in
+    natural order and the K x K table over the rest, i.e. hadK (x) Sylvester(n / K)."""
+    had_k, k = get_hadK(n)
+    low = sylvester(n // k)
+    return low if had_k is None else torch.kron(had_k, low)
+
+
 def random_hadamard_matrix(size: int, device, seed: int) -> torch.Tensor:
-    """diag(D) . H_size / float32(sqrt(size)) in float64 (hadamard_utils.py:63-99)."""
+    """matmul_hadU(diag(D)) = diag(D) . H_size^T / float32(sqrt(size)) in float64 (hadamard_utils.py:63-99), any size
+    get_hadK accepts (every entry is +-1 over the float32 square root: no rounding depends on summation order)."""
     d = sign_vector(size, seed)
-    return ((d[:, None] * sylvester(size)) / torch.tensor(size).sqrt()).to(device)
+    return ((d[:, None] * hadamard_matrix(size).T) / torch.tensor(size).sqrt()).to(device)
 
 
 def block_random_hadamard_matrix(total_size: int = 1920, block_size: int = 128, device="cuda", seed: int = 42
@@ -79,13 +148,24 @@ def rotate_fc1(layer, Q) -> None:
     layer.ffn.fc1.weight.data = rotate_weight(w, Q)
 
 
+def get_orthogonal_matrix(size: int, mode: str = "hadamard", device=None, seed: int = 42) -> torch.Tensor:
+    """rotation_utils.py:57-63 ('random' draws a QR factor from the global RNG there; only 'hadamard' is reproducible
+    and used by the reference's drivers)."""
+    if mode != "hadamard":
+        raise ValueError(f"Unknown mode {mode}" if mode != "random" else "mode 'random' is not provided (unseeded QR)")
+    return random_hadamard_matrix(size, device, seed)
+
+
 def rotate_model(model, device, block_rotate: bool = True) -> None:
-    """The reference's offline weight rotation for every block (mat_qkv and fc1).  Only the block-diagonal mode the
-    run scripts use (--block_rotate, 128-wide blocks, seed 42) is provided: the full-width mode needs the literal
-    Hadamard tables of hadamard_utils.py (had60 / had36 for 1920 / 2304), which are not reproduced here."""
-    if not block_rotate:
-        raise NotImplementedError("full-width Hadamard rotation (non power-of-two sizes) is not provided; use block_rotate")
-    q = block_random_hadamard_matrix(total_size=model.C, block_size=128, device=device, seed=42)
+    """The reference's offline weight rotation for every block, mat_qkv and fc1 (rotation_utils.py:211-240):
+    block_rotate=True - the run scripts' mode - with the block-diagonal Q (128-wide blocks, seed 42);
+    block_rotate=False with the full-width randomized Hadamard matrix of size model.C (had60 x 2^5 for 1920, had36 x 2^6
+    for 2304).  The ONLINE side of the full-width mode is a dense x . Q (no 128-block structure for the fused
+    kernel to exploit), exactly as in the reference."""
+    if block_rotate:
+        q = block_random_hadamard_matrix(total_size=model.C, block_size=128, device=device, seed=42)
+    else:
+        q = get_orthogonal_matrix(model.C, mode="hadamard", device=device)
     for layer in model.blocks:
         rotate_mat_qkv(layer, q)
         rotate_fc1(layer, q)

@@ -296,6 +296,39 @@ def main():
     for i in range(2):
         out[f"prep/w1/qkv{i}"], out[f"prep/w1/fc1{i}"] = bits(toy.blocks[i].attn.mat_qkv.weight.detach()), bits(toy.blocks[i].ffn.fc1.weight.detach())
 
+    # ---- 7. full-width (non-block) rotation: the literal Hadamard tables, Q for VAR's widths, rotate_model(False) ----
+    import hashlib
+    for k in (12, 20, 28, 36, 40, 60, 108, 140):
+        had, kk = hu.get_hadK(k)
+        assert kk == k
+        out[f"had/table/{k}"] = had.numpy().astype(np.int8)
+    for n in (1280, 1536, 1920, 2304):                     # VAR-d20 / d24 / d30 / d36
+        q = hu.random_hadamard_matrix(n, "cpu", 42)
+        out[f"had/q_sha256/{n}"] = np.frombuffer(hashlib.sha256(q.numpy().tobytes()).digest(), dtype=np.uint8).copy()
+        out[f"had/q_corner/{n}"] = q[:3, :64].numpy().copy()
+        out[f"had/q_lastrow/{n}"] = q[-1].numpy().copy()
+
+    class _BlkF(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn, self.ffn = torch.nn.Module(), torch.nn.Module()
+            self.attn.mat_qkv = torch.nn.Linear(240, 72, bias=False)
+            self.ffn.fc1 = torch.nn.Linear(240, 40)
+
+    class _ToyVARF(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(23)
+            self.C = 240                                     # 60 * 4: the had60 branch of get_hadK
+            self.blocks = torch.nn.ModuleList([_BlkF() for _ in range(2)])
+
+    toyf = _ToyVARF()
+    for i in range(2):
+        out[f"prep_full/w0/qkv{i}"], out[f"prep_full/w0/fc1{i}"] = bits(toyf.blocks[i].attn.mat_qkv.weight.detach()), bits(toyf.blocks[i].ffn.fc1.weight.detach())
+    ru.rotate_model(toyf, "cpu", False)
+    for i in range(2):
+        out[f"prep_full/w1/qkv{i}"], out[f"prep_full/w1/fc1{i}"] = bits(toyf.blocks[i].attn.mat_qkv.weight.detach()), bits(toyf.blocks[i].ffn.fc1.weight.detach())
+
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), len(out), "arrays")
 

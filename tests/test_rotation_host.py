@@ -72,6 +72,63 @@ def test_model_level_preprocessing_matches_the_reference(golden):
     for i in range(2):
         assert_bits_equal(toy.blocks[i].attn.mat_qkv.weight.data, from_bits(golden[f"prep/w1/qkv{i}"]), f"mat_qkv {i}")
         assert_bits_equal(toy.blocks[i].ffn.fc1.weight.data, from_bits(golden[f"prep/w1/fc1{i}"]), f"fc1 {i}")
+
+
+def test_full_width_hadamard_matches_the_reference(golden):
+    """The non-block rotation (rotate_utils/rotation_utils.py:211-222 with hadamard_utils.get_hadK: had60 x 2^5 for
+    1920, had36 x 2^6 for 2304, ...): the generated Paley tables equal the reference's literal ones, Q for VAR's
+    widths is bit-equal (SHA-256 of the float64 bytes + sampled rows), rotate_model(block_rotate=False) reproduces
+    the reference's rotated weights."""
+    import hashlib
     import pytest
-    with pytest.raises(NotImplementedError):
-        rot.rotate_model(toy, "cpu", False)
+    import torch
+    from fpqvar_amd import rotation as rot
+    from tests.conftest import assert_bits_equal, from_bits
+
+    for k in (12, 20, 28, 36, 40, 60, 108, 140):
+        had, kk = rot.get_hadK(k)
+        assert kk == k and torch.equal(had, torch.from_numpy(golden[f"had/table/{k}"]).double()), k
+        assert torch.equal(had @ had.T, k * torch.eye(k, dtype=torch.float64))
+        assert torch.equal(rot.get_hadK(k, transpose=True)[0], had.T)
+    assert rot.get_hadK(1024) == (None, 1)
+    assert rot.get_hadK(1920)[1] == 60 and rot.get_hadK(2304)[1] == 36 and rot.get_hadK(1280)[1] == 40 and rot.get_hadK(1536)[1] == 12
+    for n in (2 * 52, 4 * 172, 8 * 156):
+        with pytest.raises(NotImplementedError):
+            rot.get_hadK(n)
+    for n in (1280, 1536, 1920, 2304):
+        q = rot.random_hadamard_matrix(n, "cpu", 42)
+        assert q.dtype == torch.float64 and q.shape == (n, n)
+        digest = hashlib.sha256(q.numpy().tobytes()).digest()
+        assert digest == golden[f"had/q_sha256/{n}"].tobytes(), n
+        assert torch.equal(q[:3, :64], torch.from_numpy(golden[f"had/q_corner/{n}"]))
+        assert torch.equal(q[-1], torch.from_numpy(golden[f"had/q_lastrow/{n}"]))
+        err = (q @ q.T - torch.eye(n, dtype=torch.float64)).abs().max()
+        assert float(err) < 1e-6          # orthogonal up to float32(sqrt(n)), as the reference's Q is
+    assert torch.equal(rot.get_orthogonal_matrix(1920, "hadamard", "cpu"), rot.random_hadamard_matrix(1920, "cpu", 42))
+    with pytest.raises(ValueError):
+        rot.get_orthogonal_matrix(128, "random", "cpu")
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn, self.ffn = torch.nn.Module(), torch.nn.Module()
+            self.attn.mat_qkv = torch.nn.Linear(240, 72, bias=False)
+            self.ffn.fc1 = torch.nn.Linear(240, 40)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.C = 240
+            self.blocks = torch.nn.ModuleList([Blk() for _ in range(2)])
+
+    toy = Toy()
+    for i in range(2):
+        toy.blocks[i].attn.mat_qkv.weight.data = from_bits(golden[f"prep_full/w0/qkv{i}"])
+        toy.blocks[i].ffn.fc1.weight.data = from_bits(golden[f"prep_full/w0/fc1{i}"])
+    rot.rotate_model(toy, "cpu", False)
+    for i in range(2):       # W . Q is a float64 GEMM over 240 terms: its summation order is the BLAS's, compare to fp32 rounding
+        for got, key in ((toy.blocks[i].attn.mat_qkv.weight.data, f"prep_full/w1/qkv{i}"), (toy.blocks[i].ffn.fc1.weight.data, f"prep_full/w1/fc1{i}")):
+            want = from_bits(golden[key])
+            assert got.dtype == want.dtype and got.shape == want.shape
+            ulp = (got.view(torch.int32) - want.view(torch.int32)).abs().max()
+            assert int(ulp) <= 1, (key, int(ulp))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run ONE kernel a few times (for rocprofv3 --pmc passes).  usage: prof_one.py {adaln|rotate|dual|sym}"""
+"""Run ONE kernel a few times (for rocprofv3 --pmc passes).
+usage: prof_one.py {adaln|rotate|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -26,6 +27,19 @@ elif which == "gemm":
     ac, asc = gemm.quantize_mx(x)
     wc, wsc = gemm.quantize_mx(w)
     fn = lambda: gemm.linear_fp4(ac, asc, wc, wsc)
+elif which == "calib":
+    from fpqvar_amd import calibrate as cal
+    shapes = cal.var_linear_shapes(30)
+    names = list(shapes)[:16]                      # four blocks of VAR-d30: 177 M fp32 weights
+    w = {n: torch.randn(*shapes[n], device=dev) * 0.02 for n in names}
+    shard = cal.LocalShard(w, shapes)
+    fn = shard.quantize
+elif which == "channel":
+    x = torch.randn(32768, C, device=dev) * 0.02
+    fn = lambda: ops.quant_rows(x, "e2m3", C, torch.float16)
+elif which == "dual6":
+    x = torch.nn.functional.gelu(torch.randn(65536, 4 * C, device=dev)).half()
+    fn = lambda: ops.quant_rows_dual(x, "int_neg", "e2m3_pos", 128, None)
 elif which == "rotate":
     x = torch.randn(65536, C, device=dev).half()
     fn = lambda: rot.rotate_quant(x, "e2m1")
