@@ -24,6 +24,11 @@ _DTYPES = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
 _lib: Optional[ctypes.CDLL] = None
 
 _c = ctypes
+class Segment(_c.Structure):
+    """fpq_segment_t (include/fpq.h)."""
+    _fields_ = [("x", _c.c_void_p), ("out", _c.c_void_p), ("rows", _c.c_int64)]
+
+
 class GemmEpilogue(_c.Structure):
     """fpq_gemm_epilogue_t (include/fpq.h)."""
     _fields_ = [("gate", _c.c_void_p), ("residual", _c.c_void_p), ("rows_per_gate", _c.c_int64)]
@@ -85,6 +90,7 @@ _SIGS = {
     "fpq_adaln_rotate_quant_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
                                                 _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float,
                                                 _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_void_p]),
+    "fpq_quant_rows_multi": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "fpq_quant_rows_segments": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                             _c.c_void_p]),
     "fpq_quant_tensor_argmin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,

@@ -390,6 +390,44 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
   }
 }
 
+// Several fp16 tensors, ONE launch (fpq_quant_rows_multi): the same rows as rows16_lut_subwave_kernel, the tensors'
+// descriptors travel by value in the kernel arguments (no device-side table, no copy), blockIdx.y selects the tensor,
+// workgroups beyond a shorter tensor's end exit at once.  For the places where the reference quantizes independent
+// tensors back to back - the cached K and V of a step (tr/basic_var.py:192-200), the samples of a format search.
+constexpr int kMaxMulti = 8;
+struct Multi16 {
+  const u32x4* x[kMaxMulti];
+  u32x4* out[kMaxMulti];
+  int64_t n_vec[kMaxMulti];
+};
+
+template <int LPR, int U>
+__global__ __launch_bounds__(kBlock) void rows16_lut_multi_kernel(Multi16 m, Lut16Args a, Lut16Tab tab) {
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];
+  const int64_t n_vec = m.n_vec[blockIdx.y];
+  const int64_t v0 = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if ((int64_t)blockIdx.x * (kBlock * U) >= n_vec) return;
+  const u32x4* __restrict__ x = m.x[blockIdx.y];
+  u32x4* __restrict__ out = m.out[blockIdx.y];
+  u32x4 raw[U];
+  bool live[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t v = v0 + u * kBlock;
+    live[u] = v < n_vec;
+    raw[u] = live[u] ? __builtin_nontemporal_load(x + v) : u32x4{0, 0, 0, 0};
+  }
+  lut16_stage(lut, tab, a.shift);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t mx = row_max_dpp<LPR>(vec_absmax16(raw[u]));
+    const RowScale16 s = row_scale16(mx, a.fpos.gmax, a.inv_gpos);
+    const u32x4 o = quant_vec16<false>(raw[u], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
+    if (live[u]) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // KV-cache step (the reference's tr/basic_var.py:186-209): ONE launch
 //   (a) quantizes, in place, the cache entries the previous step appended (their first - and, the quantizer being

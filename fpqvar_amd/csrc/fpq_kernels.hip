@@ -1349,6 +1349,53 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
                               (hipStream_t)stream);
 }
 
+int fpq_quant_rows_multi(const fpq_segment_t* segments_host, int n_segments, int64_t cols, int table_id, int in_dtype,
+                         int out_dtype, fpq_stream_t stream) {
+  if (n_segments < 0 || cols < 0 || (n_segments > 0 && !segments_host)) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (out_dtype != FPQ_F16 && out_dtype != FPQ_F32)) return FPQ_ERR_DTYPE;
+  for (int i = 0; i < n_segments; ++i) {
+    if (segments_host[i].rows < 0) return FPQ_ERR_ARG;
+    if (segments_host[i].rows > 0 && cols > 0 && (!segments_host[i].x || !segments_host[i].out)) return FPQ_ERR_ARG;
+  }
+  if (n_segments == 0 || cols == 0) return FPQ_OK;
+  hipStream_t st = (hipStream_t)stream;
+  bool one_launch = in_dtype == FPQ_F16 && out_dtype == FPQ_F16 && n_segments <= kMaxMulti && cols % 8 == 0;
+  const int64_t lpr = cols / 8;
+  one_launch = one_launch && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && lut16_host(table_id, table_id).tab_valid;
+  int64_t max_vec = 0;
+  for (int i = 0; one_launch && i < n_segments; ++i) {
+    if ((((uintptr_t)segments_host[i].x | (uintptr_t)segments_host[i].out) & 15) != 0) one_launch = false;
+    max_vec = segments_host[i].rows * lpr > max_vec ? segments_host[i].rows * lpr : max_vec;
+  }
+  if (!one_launch) {   // anything the fused multi-tensor kernel does not cover: still one C call, one launch per tensor
+    for (int i = 0; i < n_segments; ++i)
+      if (int rc = fpq_quant_rows(segments_host[i].x, segments_host[i].out, segments_host[i].rows, cols, table_id, in_dtype,
+                                  out_dtype, stream))
+        return rc;
+    return FPQ_OK;
+  }
+  if (max_vec == 0) return FPQ_OK;
+  constexpr int U = 2;
+  Multi16 m = {};
+  for (int i = 0; i < n_segments; ++i) {
+    m.x[i] = (const u32x4*)segments_host[i].x;
+    m.out[i] = (u32x4*)segments_host[i].out;
+    m.n_vec[i] = segments_host[i].rows * lpr;
+  }
+  const Lut16Host& h = lut16_host(table_id, table_id);
+  const int64_t tiles = (max_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  if (tiles > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  const dim3 grid((unsigned)tiles, (unsigned)n_segments);
+#define FPQ_MULTI_CASE(L) \
+  case L: hipLaunchKernelGGL((rows16_lut_multi_kernel<L, U>), grid, dim3(kBlock), 0, st, m, h.args, h.tab); break;
+  switch ((int)lpr) {
+    FPQ_MULTI_CASE(1) FPQ_MULTI_CASE(2) FPQ_MULTI_CASE(4) FPQ_MULTI_CASE(8) FPQ_MULTI_CASE(16) FPQ_MULTI_CASE(32) FPQ_MULTI_CASE(64)
+  }
+#undef FPQ_MULTI_CASE
+  return check_launch();
+}
+
 int fpq_quant_rows_segments(const fpq_segment_t* segments_device, int n_segments, int64_t max_rows, int64_t cols,
                             int table_id, int in_dtype, int out_dtype, fpq_stream_t stream) {
   static_assert(sizeof(fpq_segment_t) == sizeof(Seg32), "fpq_segment_t and the kernels' Seg32 share one layout");

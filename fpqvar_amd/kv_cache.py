@@ -24,6 +24,21 @@ def quantize_kv(t: torch.Tensor, kv_bit: int) -> torch.Tensor:
     raise NotImplementedError
 
 
+def quantize_kv_pair(k: torch.Tensor, v: torch.Tensor, kv_bit: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """quantize_kv on the cached K and the cached V (basic_var.py:193-200 quantizes them back to back): one launch for
+    the pair when both are fp16 (fpq_quant_rows_multi), same results and the same layout rule as the single calls."""
+    if k.dtype == v.dtype == torch.float16 and k.device == v.device and kv_bit in (4, 6):
+        if kv_bit == 6:
+            qu._require_viewable(k)
+            qu._require_viewable(v)
+            a, b = ops.quant_rows_multi([k, v], "e2m3", k.shape[-1], torch.float16) if k.shape[-1] == v.shape[-1] else \
+                (quantize_kv(k, 6), quantize_kv(v, 6))
+        else:
+            a, b = ops.quant_rows_multi([k, v], "e2m1", 128)
+        return a, b
+    return quantize_kv(k, kv_bit), quantize_kv(v, kv_bit)
+
+
 def update_kv_cache(cached_k: Optional[torch.Tensor], cached_v: Optional[torch.Tensor], k: torch.Tensor,
                     v: torch.Tensor, quant_KV: bool, kv_bit: int, dim_cat: int, check_finite: bool = True
                     ) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -33,8 +48,7 @@ def update_kv_cache(cached_k: Optional[torch.Tensor], cached_v: Optional[torch.T
     if cached_k is None:
         return k, v
     if quant_KV:
-        cached_k = quantize_kv(cached_k, kv_bit)
-        cached_v = quantize_kv(cached_v, kv_bit)
+        cached_k, cached_v = quantize_kv_pair(cached_k, cached_v, kv_bit)
         if check_finite:
             assert not torch.isnan(k).any(), "Tensor contains NaN values!"
             assert not torch.isinf(k).any(), "Tensor contains inf values!"

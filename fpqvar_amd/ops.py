@@ -68,6 +68,30 @@ def quant_rows(x: torch.Tensor, table: str, cols: int, out_dtype: Optional[torch
     return out
 
 
+def quant_rows_multi(xs, table: str, cols: int, out_dtype: Optional[torch.dtype] = None):
+    """quant_rows on several tensors of one device and dtype with ONE C-ABI call (one launch for up to 8 fp16 tensors
+    with rows of 8 .. 512 elements, fpq_quant_rows_multi): list of results, same shapes."""
+    xs = list(xs)
+    if not xs:
+        return []
+    for x in xs:
+        require_gpu(x, "quant_rows_multi")
+        if x.dtype != xs[0].dtype or x.device != xs[0].device:
+            raise RuntimeError("quant_rows_multi: the tensors must share dtype and device")
+        if cols <= 0 or x.numel() % cols != 0:
+            raise RuntimeError(f"quant_rows_multi: numel {x.numel()} is not a multiple of the row length {cols}")
+    if xs[0].dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"quant_rows_multi: tensors must be float16 or float32, got {xs[0].dtype}")
+    out_dtype = xs[0].dtype if out_dtype is None else out_dtype
+    xc = [_contig(x) for x in xs]
+    outs = [torch.empty(x.shape, dtype=out_dtype, device=x.device) for x in xs]
+    segs = (_lib.Segment * len(xs))(*[_lib.Segment(a.data_ptr(), o.data_ptr(), a.numel() // cols) for a, o in zip(xc, outs)])
+    with device_guard(xs[0].device):
+        check(lib().fpq_quant_rows_multi(segs, len(xs), cols, TABLE_IDS[table], dtype_id(xs[0].dtype), dtype_id(out_dtype),
+                                         stream_ptr(xs[0].device)), "fpq_quant_rows_multi")
+    return outs
+
+
 def gate_residual(y: torch.Tensor, gate: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
     """residual + y.mul(gate) in one launch, bit-identical to the two torch ops (tr/basic_var.py:264,267): y and
     residual fp16 [B, L, C], gate fp16 [B, 1, C] (gamma1 / gamma2 of the AdaLN block)."""

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 120 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments (round 2) */
+#define FPQ_VERSION 121 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -265,6 +265,16 @@ typedef struct {
 } fpq_segment_t;
 int fpq_quant_rows_segments(const fpq_segment_t* segments_device, int n_segments, int64_t max_rows, int64_t cols,
                             int table_id, int in_dtype, int out_dtype, fpq_stream_t stream);
+
+/* A few tensors, one call: the reference quantizes independent tensors back to back in places - the cached K and
+ * the cached V of a generation step (tr/basic_var.py:192-200: two fp6_quant_e2m3_per_token_cuda / two
+ * fp_quant_e2_per_group_cuda calls), the samples of a format search.  segments_host: HOST array (read before the
+ * call returns; the descriptors travel in the kernel arguments, nothing is copied to the device), every segment
+ * `rows` contiguous rows of `cols` elements; same results as fpq_quant_rows per segment.  ONE launch when
+ * in_dtype == out_dtype == F16, n_segments <= 8, cols in {8, 16, ..., 512} and everything 16-byte aligned; otherwise
+ * one launch per segment behind the same call. */
+int fpq_quant_rows_multi(const fpq_segment_t* segments_host, int n_segments, int64_t cols, int table_id, int in_dtype,
+                         int out_dtype, fpq_stream_t stream);
 
 /* Per-tensor quantizer of the reference's pure-torch path (BASELINE.json config 1):
  *   replaces fp_quant_e2_per_tensor   search/baseline/plot_weight_distribution_for_motivation.py:285-294

@@ -176,3 +176,35 @@ def test_dual_nan_flag_scratch_cleans_itself(dev):
             assert_bits_equal(static_out, want_clean, f"replay {step} (clean)")
         else:
             assert not static_out.any(), f"replay {step} (NaN)"
+
+
+def test_quant_rows_multi_equals_single_calls(dev):
+    """fpq_quant_rows_multi: several tensors, one call; same bits as one fpq_quant_rows per tensor, whatever path it
+    takes (one fused launch for <= 8 aligned fp16 tensors, per-tensor launches otherwise)."""
+    from fpqvar_amd import ops
+    g = torch.Generator().manual_seed(31)
+    shapes = [(3, 7, 30, 64), (5, 128), (1, 64), (1000, 64), (2, 3, 1920)]
+    for dtype in (torch.float16, torch.float32):
+        for cols, table in ((64, "e2m3"), (128, "e2m1"), (1920, "e2m3"), (8, "e2m1")):
+            xs = [torch.randn(*s, generator=g).to(dtype) for s in shapes if (torch.Size(s).numel() % cols) == 0]
+            if not xs:
+                continue
+            xs[0].view(-1)[: cols] = 0
+            got = ops.quant_rows_multi([x.to(dev) for x in xs], table, cols, torch.float16)
+            assert len(got) == len(xs)
+            for x, y in zip(xs, got):
+                assert y.shape == x.shape
+                assert_bits_equal(y, ops.quant_rows(x.to(dev), table, cols, torch.float16), f"multi {dtype} cols={cols}")
+                assert_bits_equal(y, orc.per_token_kernel_sem(x.reshape(-1, cols), table).view(x.shape), f"multi vs oracle cols={cols}")
+    # more than eight tensors, an unaligned one, an empty list
+    many = [torch.randn(4, 128, generator=g).half().to(dev) for _ in range(11)]
+    for x, y in zip(many, ops.quant_rows_multi(many, "e2m1", 128)):
+        assert_bits_equal(y, ops.quant_rows(x, "e2m1", 128), "eleven tensors")
+    odd = torch.randn(4 * 128 + 4, generator=g).half().to(dev)[4:].view(4, 128)
+    for x, y in zip([many[0], odd], ops.quant_rows_multi([many[0], odd], "e2m1", 128)):
+        assert_bits_equal(y, ops.quant_rows(x, "e2m1", 128), "unaligned member")
+    assert ops.quant_rows_multi([], "e2m1", 128) == []
+    with pytest.raises(RuntimeError):
+        ops.quant_rows_multi([many[0], many[1].float()], "e2m1", 128)
+    with pytest.raises(RuntimeError):
+        ops.quant_rows_multi([many[0].cpu()], "e2m1", 128)

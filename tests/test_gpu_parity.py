@@ -1367,6 +1367,16 @@ def test_rccl_single_rank_group_paths(dev):
             assert_bits_equal(codes[n], want, f"calibrate_sharded codes {n}")
         total, rate = gen.aggregate_throughput(50, 2.0)
         assert total == 50 and abs(rate - 25.0) < 1e-9
+        # the collective itself in the form ShardedCalibration uses at N > 1: in place, the input is this rank's slot
+        # of the [world, width] output slab (RCCL must accept the aliasing; at one rank it is the identity)
+        sc = cal.ShardedCalibration({n: tuple(w.shape) for n, w in weights.items()}, weights)
+        sc.local.quantize()
+        before = sc.slab.clone()
+        dist.all_gather_into_tensor(sc.slab.view(-1), sc.slab[sc.rank])
+        torch.cuda.synchronize()
+        assert torch.equal(sc.slab, before)
+        for n, w in weights.items():
+            assert_bits_equal(sc.views()[n], orc.per_group_kernel_sem(w.cpu(), "e2m1", 128).half(), f"slab view {n}")
     finally:
         dist.destroy_process_group()
 
