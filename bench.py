@@ -314,7 +314,7 @@ def other_kernels(dev):
 
 
 # ------------------------------------------------------------------------------------------------ config 4
-def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=3):
+def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, warm=6):
     """BASELINE.json config 4: every Linear weight of VAR-d30 (1.327 G fp32 elements, synthetic randn*0.02) quantized
     per-group(128) E2M1 -> fp16, layers partitioned over the ranks (fpqvar_amd.calibrate.partition), each rank
     materialising and quantizing only its own share ("ms": no collective on the data path, max over ranks), and, at
@@ -339,7 +339,8 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=3):
         torch.manual_seed(1000 + rank)
         own = {n: torch.randn(*shapes[n], device=dev) * 0.02 for n in mine}
         local = cal.LocalShard(own, shapes)            # segment table + output slab, built once (not timed)
-        local.quantize()
+        for _ in range(warm):                          # the clocks take ~10 ms of this load to settle (1.29 - 1.56 ms
+            local.quantize()                           # per launch over the first launches, profiles/r02_bench_kernel_stats.csv)
         plat.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
@@ -362,7 +363,8 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=3):
             try:
                 stage[0] = "sharded calibration + all_gather_into_tensor"
                 plan = cal.ShardedCalibration(shapes, own, group=None)   # slab + segment table, built once (not timed)
-                plan.run()
+                for _ in range(3):
+                    plan.run()
                 plat.synchronize()
                 dist.barrier()
                 t0 = time.perf_counter()

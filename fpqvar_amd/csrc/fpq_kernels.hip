@@ -930,7 +930,10 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));   // torch.tensor(128).sqrt() is float32; autocast makes Q fp16
   r.vec_per_row = cols / 8;
   const int64_t n_vec = rows * (cols / 8);
-  constexpr int U = 2;
+  #ifndef FPQ_ROT_U
+#define FPQ_ROT_U 2
+#endif
+  constexpr int U = FPQ_ROT_U;
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   const dim3 grid(grid_for(tiles, 1 << 20));

@@ -11,7 +11,8 @@ acc = defaultdict(lambda: defaultdict(list))
 for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
         k = r["Kernel_Name"]
-        if sub in k and (sub or "_GLOBAL__N_" in k):   # default: this library's kernels only
+        ours = "_GLOBAL__N_" in k or (k.startswith("void (anonymous namespace)::") and "at::native" not in k)
+        if sub in k and (sub or ours):   # default: this library's kernels only
             acc[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
