@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 }
 
 #include "fpq_fast16.h"
+#include "fpq_rotate_mfma.h"
 #include "fpq_fast32.h"
 #include "fpq_adaln.h"
 #include "fpq_gemm_fp4.h"   // the code-emitting quantizer kernels live beside their consumers;
@@ -937,6 +938,26 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   const dim3 grid(grid_for(tiles, 1 << 20));
+  // values out: the transform on the matrix cores (fpq_rotate_mfma.h), one 32-group tile per wavefront
+#ifndef FPQ_ROT_BUTTERFLY_BUILD
+#define FPQ_ROT_BUTTERFLY_BUILD 0
+#endif
+  static const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
+  if (!code_scales && !butterfly) {
+    // persistent wavefronts, every workgroup the same number of passes (FPQ_ROT_WAVES workgroups per CU are resident; twice as many shorter ones measured 2 % faster: 84.2 vs 85.9 us)
+    const int64_t per_wg = (int64_t)(kBlock / 64) * kRqTileVec;
+    const int64_t wg_tiles = (n_vec + per_wg - 1) / per_wg;
+    static const int64_t resident = [] { const char* e = getenv("FPQ_ROT_WGS"); return e ? atoll(e) : 2 * 256ll * FPQ_ROT_WAVES; }();
+    const int64_t passes = (wg_tiles + resident - 1) / resident;
+    const dim3 mgrid((unsigned)((wg_tiles + passes - 1) / passes));
+#define FPQ_ROT_MFMA(EMIT, SMOOTH)                                                                                  \
+  hipLaunchKernelGGL((rotate_quant_mfma_kernel<Tin, EMIT, SMOOTH>), mgrid, dim3(kBlock), lds, st, x, (u32x4*)out, \
+                     (u32x4*)rot_out, n_vec, r, h.args, tab)
+    if (rot_out) { if (smooth) FPQ_ROT_MFMA(true, true); else FPQ_ROT_MFMA(true, false); }
+    else { if (smooth) FPQ_ROT_MFMA(false, true); else FPQ_ROT_MFMA(false, false); }
+#undef FPQ_ROT_MFMA
+    return check_launch();
+  }
   if (code_scales)
     hipLaunchKernelGGL((rotate_quant16_kernel<Tin, false, U, true>), grid, dim3(kBlock), lds, st, x, (u32x4*)out,
                        (u32x4*)nullptr, n_vec, r, h.args, tab);

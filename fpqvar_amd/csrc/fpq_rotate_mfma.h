@@ -1,0 +1,291 @@
+// fpq_rotate_mfma.h - the online rotate in front of the per-group quantizer with the 128-point Hadamard transform
+// on the matrix cores.  Included by fpq_kernels.hip after fpq_fast16.h.
+//
+// Why: the butterfly form (rotate_quant16_kernel) is bound by vector-instruction issue, not by memory
+// (profiles/r02_pmc_rotate.txt: 22 VALU instructions per element, 8.5 of them the butterfly, the vector pipe ~80 %
+// busy at 0.70 of 8 TB/s where the plain quantizer streams at 0.80).  The reference computes this step as a GEMM in
+// the first place (tr/basic_var.py:263,266: torch.matmul(x, Q), Q = blockdiag(diag(D) H128 / sqrt(128))); H128 is
+// +-1, exact as fp16 MFMA operands.
+//
+// One wavefront transforms 16 groups (2048 elements, 4 KiB) at a time:
+//   1. four fully coalesced 16-byte loads per lane (vector i * 64 + lane of the tile); signs D applied by xor;
+//   2. transpose through LDS into the B-operand layout of v_mfma_f32_16x16x32_f16: lane (g = lane % 16,
+//      quarter = lane / 16) needs, for k-step s, the 8 consecutive inputs 32 s + 8 quarter .. of group g = chunk
+//      p = 4 s + quarter.  Chunk (g, p) lives at slot p * 16 + (g ^ p) (16 bytes each): the writes (16 lanes = the 16
+//      chunks of one group) and the reads (16 lanes = one chunk of 16 groups) both touch 16 different slots mod 16;
+//   3. H128[o][b] = (-1)^popcount(o & b) factors over the bits.  Bits 0 .. 4 go through the matrix cores: with
+//      o = i + 16 u (+ 32 t), b = k' + 8 quarter + 32 s the exponent is popcount(i & 7 & k') + i3 q0 + u q1 (+ t0 s0
+//      + t1 s1): a per-lane +-1 pattern A_u (u = 0, 1), and P[u][s] = A_u . B_s is EIGHT independent v_mfma
+//      (16 outputs x 16 groups each, 4 accumulator registers).  Bits 5, 6 are a 4-point butterfly over s on the
+//      accumulators: y[u][t] = sum_s (-1)^(t0 s0 + t1 s1) P[u][s], 64 fp32 adds per lane;
+//   4. the accumulators leave lane (g, quarter) holding outputs 4 quarter + 16 (u + 2 t) + {0..3} of group g: 32 of
+//      its 128; the group maximum is an in-lane v_max3 chain + two v_permlane swaps, the scale is computed once
+//      per lane and 32 elements (butterfly form: once per 8), the quantizer runs on packed pairs of adjacent outputs;
+//   5. results go back through LDS (8-byte pieces in, 16-byte vectors out; chunk p' of group g at slot
+//      g * 16 + (p' ^ g)) and leave as the same coalesced 16-byte stores as the loads.
+// Wavefronts are persistent and (fp16 input) issue the loads of their next tile before transforming the current one.
+//
+// Numerics: +-1 operands - the matrix cores add and subtract the inputs themselves; fp32 sums of fp16 values of like
+// magnitude are exact, cancelling outputs included (+-c_h operands, the reference's own GEMM, show the rounding of
+// the fp32 accumulator as several fp16 ulp on small outputs), and the one rounding is half(sum * c_h).  Same contract
+// as the butterfly form: <= 1 fp16 ulp from the fp64 product, quantization bit-exact on the rotated values produced
+// (tests/test_gpu_parity.py::test_rotate_quant_fused).
+#pragma once
+
+typedef _Float16 rq_h8_t __attribute__((ext_vector_type(8)));
+typedef float rq_f4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kRqTileVec = 256;   // 16 groups x 16 vectors of 8 halves per wavefront
+
+// The LDS addresses of a phase are lane constants + xor patterns: hoisted out of the tile loop they would pin
+// registers for the sake of a few xors per tile.  An empty asm makes the lane index opaque at the start of a phase.
+__device__ __forceinline__ int rq_opaque(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
+struct HadOperand {
+  u32x4 a[2];   // [u]: output bit 4
+};
+
+__device__ __forceinline__ HadOperand had_operand(int lane) {
+  const int i = lane & 15, quarter = lane >> 4;
+  u32x4 base;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t b0 = (uint32_t)__builtin_popcount((i & 7) & (2 * w)) & 1u;
+    const uint32_t b1 = (uint32_t)__builtin_popcount((i & 7) & (2 * w + 1)) & 1u;
+    base[w] = 0x3C003C00u ^ (b0 << 15) ^ (b1 << 31);          // +-1.0, +-1.0
+  }
+  const uint32_t f0 = ((i >> 3) & quarter & 1) ? 0x80008000u : 0u;   // i3 q0
+  const uint32_t f1 = f0 ^ ((quarter & 2) ? 0x80008000u : 0u);       // + q1 for u = 1
+  HadOperand h;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    h.a[0][w] = base[w] ^ f0;
+    h.a[1][w] = base[w] ^ f1;
+  }
+  return h;
+}
+
+// 16 groups of 128 sign-applied fp16 inputs (in `buf`, B-operand layout) -> this lane's 32 rotated outputs of group
+// lane % 16 as packed fp16 words yw[c][r], c = u + 2 t: outputs 16 c + 4 (lane / 16) + 2 r, + 1; returns the
+// maximum |sum| before the scaling by c_h.
+__device__ __forceinline__ float hadamard128_mfma(const u32x4* buf, const HadOperand& ha, float c_h, int lane,
+                                                  uint32_t (&yw)[8][2]) {
+  lane = rq_opaque(lane);
+  const int g = lane & 15, quarter = lane >> 4;
+  rq_f4_t acc[2][4];
+  const rq_f4_t zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int p = 4 * s + quarter;
+    const rq_h8_t b = __builtin_bit_cast(rq_h8_t, buf[p * 16 + (g ^ p)]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rq_h8_t, ha.a[u]), b, zero, 0, 0, 0);
+  }
+  float m = 0.0f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; v += 2) {
+      float y[4][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float p0 = acc[u][0][v + e], p1 = acc[u][1][v + e], p2 = acc[u][2][v + e], p3 = acc[u][3][v + e];
+        const float q00 = p0 + p1, q10 = p0 - p1;   // Q[t0][s1]
+        const float q01 = p2 + p3, q11 = p2 - p3;
+        y[0][e] = q00 + q01;   // t = t0 + 2 t1
+        y[1][e] = q10 + q11;
+        y[2][e] = q00 - q01;
+        y[3][e] = q10 - q11;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(y[t][0])), __builtin_fabsf(y[t][1]));
+        yw[u + 2 * t][v >> 1] = mul2_to_h2(y[t][0], y[t][1], c_h);
+      }
+    }
+  return m;
+}
+
+// A tile is addressed through a buffer resource whose range is the live part of the tile: loads beyond it return
+// zeros, stores beyond it are dropped - no per-vector predicate, no 64-bit address arithmetic in the vector pipe.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rq_rsrc(const void* tile_ptr, int live_bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)tile_ptr, 0, live_bytes < 0 ? 0 : live_bytes, 0x00020000);
+}
+constexpr int kRqNt = 2;   // cache policy: non-temporal
+
+// this lane's 16 words (8-byte pieces c) into the output image, then 4 coalesced 16-byte vectors per lane out
+__device__ __forceinline__ void rq_store_tile(u32x4* buf, const uint32_t (&w)[8][2], __amdgpu_buffer_rsrc_t dst,
+                                              int lane) {
+  lane = rq_opaque(lane);
+  const int g = lane & 15, quarter = lane >> 4;
+  u32x2* b2 = (u32x2*)buf;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int pc = 2 * c + (quarter >> 1);
+    b2[(g * 16 + (pc ^ g)) * 2 + (quarter & 1)] = u32x2{w[c][0], w[c][1]};
+  }
+  __builtin_amdgcn_wave_barrier();
+  lane = rq_opaque(lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gg = 4 * i + (lane >> 4), pc = lane & 15;
+    const u32x4 o = buf[gg * 16 + (pc ^ gg)];
+    __builtin_amdgcn_raw_buffer_store_b128(o, dst, lane * 16 + i * 1024, 0, kRqNt);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one tile's raw input: vector i * 64 + lane, i = 0 .. 3 (fp16: as loaded; fp32: two loads per vector, converted later)
+template <typename Tin>
+struct RqRaw {
+  u32x4 w[sizeof(Tin) == 2 ? 4 : 8];
+};
+
+template <typename Tin>
+__device__ __forceinline__ void rq_load_tile(__amdgpu_buffer_rsrc_t src, int lane, RqRaw<Tin>& raw) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (sizeof(Tin) == 2) {
+      raw.w[i] = __builtin_amdgcn_raw_buffer_load_b128(src, lane * 16 + i * 1024, 0, kRqNt);
+    } else {
+      raw.w[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(src, lane * 32 + i * 2048, 0, kRqNt);
+      raw.w[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(src, lane * 32 + i * 2048 + 16, 0, kRqNt);
+    }
+  }
+}
+
+// lut_pair16 with one instruction less: bit shift-1 of both patterns is cleared at once, after which the byte offsets
+// are a bit-field extract and a shift
+__device__ __forceinline__ uint32_t rq_lut_pair(const uint16_t* lut, uint32_t u, int shift) {
+  const uint32_t u2 = u & ~(0x10001u << (shift - 1));
+  const uint32_t off0 = __builtin_amdgcn_ubfe(u2, (uint32_t)(shift - 1), (uint32_t)(17 - shift)), off1 = u2 >> (15 + shift);
+  h2_t q;
+  q.x = *(const _Float16*)((const char*)lut + off0);
+  q.y = *(const _Float16*)((const char*)lut + off1);
+  return __builtin_bit_cast(uint32_t, q);
+}
+
+#ifndef FPQ_ROT_WAVES
+#define FPQ_ROT_WAVES 6
+#endif
+
+template <typename Tin, bool EMIT, bool SMOOTH>
+__global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kernel(const void* __restrict__ xv,
+                                                                                 u32x4* __restrict__ out,
+                                                                                 u32x4* __restrict__ rot_out,
+                                                                                 int64_t n_vec, RotArgs r, Lut16Args a,
+                                                                                 Lut16Tab tab) {
+  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];
+  __shared__ u32x4 xpose[kBlock / 64][kRqTileVec];   // 4 KiB per wavefront, private to it
+  constexpr bool PREFETCH = sizeof(Tin) == 2 && !EMIT;   // the emitting form is for tests and calibration dumps
+  constexpr int VW = sizeof(Tin) == 2 ? 1 : 2;           // 16-byte words per input vector
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32x4* buf = xpose[wave];
+  const int n_tiles = (int)((n_vec + kRqTileVec - 1) / kRqTileVec);
+  const int tile_step = (int)gridDim.x * (kBlock / 64);
+  int tile = (int)blockIdx.x * (kBlock / 64) + wave;
+  const int lg = lane & 15;
+  const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
+  uint32_t sx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sx[k] = (((sb >> (2 * k)) & 1u) << 15) | (((sb >> (2 * k + 1)) & 1u) << 31);
+  auto rem_of = [&](int t) {
+    const int64_t left = n_vec - (int64_t)t * kRqTileVec;
+    return (int)(left < 0 ? 0 : left > kRqTileVec ? kRqTileVec : left);
+  };
+  auto in_rsrc = [&](int t) {
+    return rq_rsrc((const u32x4*)xv + (int64_t)t * (kRqTileVec * VW), rem_of(t) * (16 * VW));
+  };
+
+  RqRaw<Tin> raw;
+  if (PREFETCH) rq_load_tile<Tin>(in_rsrc(tile), lane, raw);
+  lut16_stage(lut, tab, a.shift);
+  __syncthreads();   // the table (workgroup-wide, once); everything below is private to the wavefront
+  const HadOperand ha = had_operand(lane);
+
+  // The body as a lambda, run once in front of the loop: the compiler merges its s_waitcnt bookkeeping over the edges
+  // into the loop header, and the entry edge (prologue loads, nothing after them) would make the wait for the
+  // prefetched tile "at most 3 .. 0 operations outstanding" - which on the back edge drains the four stores issued
+  // just before it, every iteration.  With the first pass peeled both edges carry "loads, then four stores" and the
+  // wait becomes vmcnt(7 .. 4): the stores of a tile complete under the next tile's work.
+  auto pass = [&]() {
+    const int64_t base_vec = (int64_t)tile * kRqTileVec;
+    const int rem = rem_of(tile);
+    if (!PREFETCH) rq_load_tile<Tin>(in_rsrc(tile), lane, raw);
+    // 1. + 2.: (smooth,) sign, into the B-operand image
+    const int lane_w = rq_opaque(lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 w;
+      if constexpr (sizeof(Tin) == 2) {
+        w = raw.w[i];
+        if (SMOOTH) {   // h = half(float(x) * s)
+          const int64_t v = base_vec + i * 64 + lane;
+          const float* sp = r.smooth + ((v < n_vec ? v : 0) % r.vec_per_row) * 8;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            w[k] = f2h(h2f(w[k] & 0xFFFFu) * sp[2 * k]) | (f2h(h2f(w[k] >> 16) * sp[2 * k + 1]) << 16);
+        }
+      } else {            // fp32 producer output: h = half(x * s)
+        const u32x4 lo = raw.w[2 * i], hi = raw.w[2 * i + 1];
+        float f[8] = {u2f(lo[0]), u2f(lo[1]), u2f(lo[2]), u2f(lo[3]), u2f(hi[0]), u2f(hi[1]), u2f(hi[2]), u2f(hi[3])};
+        if (SMOOTH) {
+          const int64_t v = base_vec + i * 64 + lane;
+          const float* sp = r.smooth + ((v < n_vec ? v : 0) % r.vec_per_row) * 8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] *= sp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = f2h(f[2 * k]) | (f2h(f[2 * k + 1]) << 16);
+      }
+      const int g = 4 * i + (lane_w >> 4), p = lane_w & 15;
+      buf[p * 16 + (g ^ p)] = u32x4{w[0] ^ sx[0], w[1] ^ sx[1], w[2] ^ sx[2], w[3] ^ sx[3]};
+    }
+    if (PREFETCH)   // the next tile, in flight during 3. - 5.
+      rq_load_tile<Tin>(in_rsrc(tile + tile_step), lane, raw);
+    __builtin_amdgcn_wave_barrier();
+
+    // 3. + 4.
+    uint32_t yw[8][2];
+    const float mf = hadamard128_mfma(buf, ha, r.c_h, lane, yw);
+    __builtin_amdgcn_wave_barrier();
+    if (EMIT) rq_store_tile(buf, yw, rq_rsrc(rot_out + base_vec, rem * 16), lane);
+    // rounding is monotonic: half(c_h max |sum|) == max |half(c_h sum)|.  v_max drops NaN where the maximum of the integer patterns
+    // (and torch's amax) keeps it; every output of a group contains every input, so one non-finite input makes ALL
+    // outputs of the group non-finite: one output per lane tells whether the (rare) pattern scan is needed.
+    uint32_t m = mul2_to_h2(mf, 0.0f, r.c_h) & 0xFFFFu;
+    if (__builtin_expect((yw[0][0] & 0x7C00u) == 0x7C00u, 0)) {
+      m = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) m = pk_max_u16(m, pk_max_u16(yw[c][0] & 0x7FFF7FFFu, yw[c][1] & 0x7FFF7FFFu));
+      const uint32_t lo = m & 0xFFFFu, hi = m >> 16;
+      m = lo > hi ? lo : hi;
+    }
+    {   // the other three quarters of the group: lanes ^ 16, ^ 32, ^ 48
+      auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+      m = sw[0] > sw[1] ? sw[0] : sw[1];
+      sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+      m = sw[0] > sw[1] ? sw[0] : sw[1];
+    }
+    const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+        const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+        yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
+      }
+    // 5.
+    rq_store_tile(buf, yw, rq_rsrc(out + base_vec, rem * 16), lane);
+  };
+  if (tile < n_tiles) {
+    pass();
+    for (tile += tile_step; tile < n_tiles; tile += tile_step) pass();
+  }
+}

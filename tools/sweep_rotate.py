@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""rotate_quant at the headline shape for the library in use (FPQ_ROT_* environment read at first launch)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fpqvar_amd import rotation as rot
+
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+xs = [torch.randn(65536, 1920, device=dev, generator=g).half() for _ in range(4)]
+k = 0
+def run():
+    global k
+    k += 1
+    return rot.rotate_quant(xs[k % 4], "e2m1")
+for _ in range(200):
+    run()
+torch.cuda.synchronize()
+res = []
+for _ in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    res.append(e0.elapsed_time(e1) / 50 * 1e3)
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FPQ_ROT"))
+print(f"{tag or 'default':40s} " + " ".join(f"{r:6.1f}" for r in res) + f"  us   min {min(res):.1f}  frac {65536*1920*4/min(res)/1e6/8:.3f}")
