@@ -89,7 +89,8 @@ typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 #define FPQ_ADALN_OCC
 #endif
 
-template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false>
+// MFMA: the rotation on the matrix cores (fpq_rotate_mfma.h: a row of up to 16 groups is one tile; value output only)
+template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false, bool MFMA = false>
 __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                            u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                            int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab,
@@ -101,7 +102,15 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
   const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  static_assert(!MFMA || (!CODES && MAXC <= 4), "matrix-core rotation: value output, rows of at most 16 groups");
+  u32x4* buf = nullptr;           // MFMA: this wavefront's operand / output image
+  HadOperand ha = {};
+  if constexpr (MFMA) {
+    __shared__ u32x4 xpose[W][kRqTileVec];
+    buf = xpose[wave];
+    ha = had_operand(lane);
+  }
   const int64_t b = blockIdx.x / wgs_per_batch;
   const int chunk = blockIdx.x % wgs_per_batch;
   const int64_t L = ad.rows_per_batch;
@@ -251,6 +260,72 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
     rstd = __builtin_fmaf(rstd * __builtin_fmaf(-ve * rstd, rstd, 1.0f), 0.5f, rstd);
     const float nm = -mean * rstd;
 
+    if constexpr (MFMA) {
+      // ---- modulate into the B-operand image (all 16 groups defined: vectors beyond the row are zeros), transform on
+      // the matrix cores, quantize the 32 outputs this lane holds of its group, out through the same image ----
+      const int lane_w = rq_opaque(lane);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x4 hw = {0, 0, 0, 0};
+        if (c < MAXC) {
+          const int v = vidx[c];
+          const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
+          const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
+          const u32x4 w = cur[c];
+          hw[0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
+                       __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
+          hw[1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
+                       __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
+          hw[2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
+                       __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
+          hw[3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
+                       __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
+          if (c == MAXC - 1 && !last_live) hw = u32x4{0, 0, 0, 0};
+          if constexpr (EMIT) {
+            if (h_out && (c < MAXC - 1 || last_live))
+              __builtin_nontemporal_store(u32x4{hw[0] ^ sx[0], hw[1] ^ sx[1], hw[2] ^ sx[2], hw[3] ^ sx[3]}, h_out + row * vpr + v);
+          }
+        }
+        const int g = 4 * c + (lane_w >> 4), p = lane_w & 15;
+        buf[p * 16 + (g ^ p)] = hw;
+      }
+      __builtin_amdgcn_wave_barrier();
+      uint32_t yw[8][2];
+      const float mf = hadamard128_mfma(buf, ha, r.c_h, lane, yw);
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (EMIT) {
+        if (y_out) rq_store_tile(buf, yw, rq_rsrc(y_out + row * vpr, vpr * 16), lane);
+      }
+      uint32_t m = mul2_to_h2(mf, 0.0f, r.c_h) & 0xFFFFu;       // see rotate_quant_mfma_kernel
+      if (__builtin_expect((yw[0][0] & 0x7C00u) == 0x7C00u, 0)) {
+        m = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m = pk_max_u16(m, pk_max_u16(yw[c][0] & 0x7FFF7FFFu, yw[c][1] & 0x7FFF7FFFu));
+        const uint32_t lo = m & 0xFFFFu, hi = m >> 16;
+        m = lo > hi ? lo : hi;
+      }
+      if constexpr (TOKEN) {
+        m = row_max_dpp<64>(m);        // fp6_quant_*_per_token_cuda on the rotated row: one scale for the whole row
+      } else {
+        auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+        m = sw[0] > sw[1] ? sw[0] : sw[1];
+        sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+        m = sw[0] > sw[1] ? sw[0] : sw[1];
+      }
+      const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      if constexpr (TOKEN) {
+        if (r.code_scales && lane == 0) r.code_scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+          const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+          yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
+        }
+      rq_store_tile(buf, yw, rq_rsrc(out + row * vpr, vpr * 16), lane);
+    } else {
     // ---- modulate, rotate, quantize: vectors two at a time, stage by stage ----
     u32x4 ys[TOKEN ? MAXC : 1];   // per-token scale: the rotated row waits here for the row maximum
     uint32_t mrow = 0;
@@ -374,6 +449,7 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
           __builtin_nontemporal_store(o, out + row * vpr + v);
         }
       }
+    }
     }
   };
   u32x4 alt[MAXC];

@@ -373,6 +373,9 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 
 #include "fpq_fast16.h"
 #include "fpq_rotate_mfma.h"
+#ifndef FPQ_ROT_BUTTERFLY_BUILD   // 1: the butterfly forms of the rotation everywhere (A/B builds)
+#define FPQ_ROT_BUTTERFLY_BUILD 0
+#endif
 #include "fpq_fast32.h"
 #include "fpq_adaln.h"
 #include "fpq_gemm_fp4.h"   // the code-emitting quantizer kernels live beside their consumers;
@@ -939,9 +942,6 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   const dim3 grid(grid_for(tiles, 1 << 20));
   // values out: the transform on the matrix cores (fpq_rotate_mfma.h), one 32-group tile per wavefront
-#ifndef FPQ_ROT_BUTTERFLY_BUILD
-#define FPQ_ROT_BUTTERFLY_BUILD 0
-#endif
   static const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
   if (!code_scales && !butterfly) {
     // persistent wavefronts, every workgroup the same number of passes (FPQ_ROT_WAVES workgroups per CU are resident; twice as many shorter ones measured 2 % faster: 84.2 vs 85.9 us)
@@ -1002,9 +1002,22 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
       const dim3 g2((unsigned)(n_batches * per_batch));
       const size_t lds2 = 0;   // table and modulation planes live in static LDS
+      // value output of rows of at most 16 groups: the rotation runs on the matrix cores
+      static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
-  hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN>), g2, dim3(kBlock), lds2, st, (const u32x4*)x,    \
-                     (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, rows_per_wg, (int)per_batch)
+  do {                                                                                                                 \
+    if constexpr (!(CODES) && (M) <= 4) {                                                                              \
+      if (!adaln_butterfly) {                                                                                          \
+        hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, true>), g2, dim3(kBlock), lds2, st,         \
+                           (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,       \
+                           rows_per_wg, (int)per_batch);                                                               \
+        break;                                                                                                         \
+      }                                                                                                                \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN>), g2, dim3(kBlock), lds2, st, (const u32x4*)x,  \
+                       (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, rows_per_wg,               \
+                       (int)per_batch);                                                                                \
+  } while (0)
 #define FPQ_ADALN2(M)                                                                                                  \
   do {                                                                                                                 \
     const bool emit = h_out || y_out;                                                                                  \

@@ -663,6 +663,47 @@ def test_rotate_quant_fused(dev, in_dtype, with_smooth):
     assert_bits_equal(y3, y, "rotation independent of the table")
 
 
+@pytest.mark.parametrize("rows,cols", ((1, 128), (3, 384), (17, 1920), (33, 2048), (257, 1152), (40000, 128)))
+@pytest.mark.parametrize("in_dtype", (torch.float16, torch.float32))
+def test_rotate_quant_tiles(dev, rows, cols, in_dtype):
+    """The matrix-core rotation works on tiles of 16 groups per wavefront, persistent over the tensor: tensors of less
+    than one tile, a ragged last tile, more tiles than resident wavefronts; non-finite inputs and all-zero groups go
+    through the quantizer exactly as the rotated values say (torch's amax keeps NaN; a group with one non-finite input
+    has no finite output)."""
+    from fpqvar_amd import rotation as rot
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = (torch.randn(rows, cols, generator=g) * torch.exp(0.7 * torch.randn(rows, cols, generator=g))).to(in_dtype)
+    x[0, :128] = 0
+    if rows >= 3:
+        x[1, 5] = float("nan")
+        x[2, 77] = float("inf")
+    if rows >= 17:
+        x[5, 130 % cols] = float("inf")
+        x[5, 140 % cols] = float("-inf")    # a group with both: outputs are +-inf or NaN
+        x[16, cols - 1] = float("-inf")
+    out, y = rot.rotate_quant(x.to(dev), "e2m1", return_rotated=True)
+    assert_bits_equal(rot.rotate_quant(x.to(dev), "e2m1"), out, "emit vs no-emit")
+    # the yardstick group by group: in the reference's dense GEMM with the block-diagonal Q (tr/basic_var.py:263) the zero
+    # blocks turn one non-finite input into NaN for its whole row (0 * inf); the fused kernels confine it to its group
+    q_h = rot.block_random_hadamard_matrix(cols, 128, "cpu", 42).float().half()
+    exact = (x.half().view(-1, 128).double() @ q_h[:128, :128].double()).view(rows, cols)
+    assert torch.equal(torch.isfinite(y.cpu()), torch.isfinite(exact)), "non-finite outputs in other places"
+    fin = torch.isfinite(exact)
+    # error bound: one fp16 rounding + the fp32 accumulation of 128 terms (visible on cancelling outputs of groups
+    # with a wide range of magnitudes: the sums are exact in fp32 only while the addends are of like magnitude)
+    yf, rf = torch.where(fin, y.cpu().double(), torch.zeros_like(exact)), torch.where(fin, exact, torch.zeros_like(exact))
+    ulp = torch.maximum(2.0 ** (torch.floor(torch.log2(rf.abs().clamp_min(2.0 ** -14))) - 10), torch.tensor(2.0 ** -24, dtype=torch.float64))
+    l1 = torch.where(torch.isfinite(x), x, torch.zeros_like(x)).double().abs().view(rows, cols // 128, 128).sum(-1, keepdim=True)
+    bound = 0.5 * ulp * 1.001 + (2.0 ** -22 * 128 ** -0.5) * l1.expand(-1, -1, 128).reshape(rows, cols)
+    worst = float(((yf - rf).abs() / bound).max())
+    assert worst <= 1.0, f"rotated value {worst:.2f}x the rounding + accumulation bound"
+    assert float(((yf - rf).abs() > 0.5 * ulp * 1.001).double().mean()) < 1e-3
+    assert_bits_equal(out, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "quant of rotated")
+    o6, y6 = rot.rotate_quant(x.to(dev), "e2m3", return_rotated=True)
+    assert_bits_equal(y6, y, "rotation independent of the table")
+    assert_bits_equal(o6, orc.per_group_kernel_sem(y.cpu(), "e2m3", 128, out_dtype=torch.float16), "e2m3 after rotate")
+
+
 # ------------------------------------------------------------------ KV cache step and format search
 def test_kv_cache_step(dev):
     from fpqvar_amd import kv_cache as kv
