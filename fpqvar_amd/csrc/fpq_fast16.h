@@ -47,6 +47,10 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
   us2_t r = __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b));
   return __builtin_bit_cast(uint32_t, r);
 }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  s2_t r = __builtin_elementwise_max(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b));
+  return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
   us2_t r = __builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b);
   return __builtin_bit_cast(uint32_t, r);
@@ -166,6 +170,8 @@ __device__ __forceinline__ void lut16_fill(uint16_t* lut, const Lut16Args& a) {
 
 // Quantize the 8 halves of one 16-byte vector.  s16x2 = scale replicated in both halves; inv_hi + inv_lo = 1 / scale
 // (0 for a zero scale).  In DUAL mode each element picks the negative or positive side's scale.
+__device__ __forceinline__ uint32_t fbits16(float f) { return __builtin_bit_cast(uint32_t, f); }
+
 template <bool DUAL>
 __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut, int shift, float ih_n, float il_n,
                                              uint32_t s16x2_n, float ih_p, float il_p, uint32_t s16x2_p) {
@@ -175,11 +181,12 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
     const uint32_t wk = w[k];
     float h0 = ih_n, h1 = ih_n, l0 = il_n, l1 = il_n;
     uint32_t sc = s16x2_n;
-    if (DUAL) {
-      const bool n0 = (wk & 0x8000u) != 0, n1 = (wk & 0x80000000u) != 0;
-      h0 = n0 ? ih_n : ih_p;  l0 = n0 ? il_n : il_p;
-      h1 = n1 ? ih_n : ih_p;  l1 = n1 ? il_n : il_p;
-      sc = (n0 ? (s16x2_n & 0xFFFFu) : (s16x2_p & 0xFFFFu)) | (n1 ? (s16x2_n & 0xFFFF0000u) : (s16x2_p & 0xFFFF0000u));
+    if (DUAL) {   // sign masks + v_bfi instead of compares and selects: 8 instructions per pair, not 12
+      const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)wk, 15, 1), m1 = (uint32_t)((int)wk >> 31);   // all ones: negative
+      h0 = u2f((fbits16(ih_n) & m0) | (fbits16(ih_p) & ~m0));  l0 = u2f((fbits16(il_n) & m0) | (fbits16(il_p) & ~m0));
+      h1 = u2f((fbits16(ih_n) & m1) | (fbits16(ih_p) & ~m1));  l1 = u2f((fbits16(il_n) & m1) | (fbits16(il_p) & ~m1));
+      const uint32_t mp = pk_ashr_i16(wk, 15);
+      sc = (s16x2_n & mp) | (s16x2_p & ~mp);
     }
     const uint32_t rb = div_pair16(wk, h0, l0, h1, l1);
     const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
@@ -228,6 +235,30 @@ __device__ __forceinline__ uint32_t vec_absmax16_dual(const u32x4& w, uint32_t& 
   lo = mp & 0xFFFFu; hi = mp >> 16;
   mpos = lo > hi ? lo : hi;
   return any_nan;
+}
+
+// The same two maxima at two instructions per packed pair instead of ten, for inputs without NaN: as UNSIGNED 16-bit
+// integers every negative value beats every positive one and grows with its magnitude, as SIGNED integers every negative
+// value loses against +0 - so `un` = unsigned maximum and `sp` = signed maximum of the raw patterns carry max|x| over
+// x < 0 and over x > 0.  A NaN (|pattern| > 0x7C00) rides along as the largest value of its side: callers test the
+// reduced maxima for > 0x7C00 and, wavefront-uniformly, redo the row with vec_absmax16_dual (rare).
+__device__ __forceinline__ void dual_max_acc(const u32x4& w, uint32_t& un, uint32_t& sp) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    un = pk_max_u16(un, w[k]);
+    sp = pk_max_i16(sp, w[k]);
+  }
+}
+__device__ __forceinline__ void dual_max_finish(uint32_t un, uint32_t sp, uint32_t& mneg, uint32_t& mpos) {
+  const uint32_t ul = un & 0xFFFFu, uh = un >> 16;
+  const uint32_t u = ul > uh ? ul : uh;
+  mneg = (u & 0x8000u) ? (u & 0x7FFFu) : 0u;
+  const int sl = (int)(sp << 16) >> 16, sh = (int)sp >> 16;
+  const int sm = sl > sh ? sl : sh;
+  mpos = sm > 0 ? (uint32_t)sm : 0u;
+}
+__device__ __forceinline__ bool dual_max_has_nan(uint32_t mneg, uint32_t mpos) {
+  return __builtin_amdgcn_ballot_w64(mneg > 0x7C00u || mpos > 0x7C00u) != 0;
 }
 
 struct RowScale16 {
@@ -370,10 +401,16 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
     for (int u = 0; u < U; ++u) {
       u32x4 o;
       if (DUAL) {
-        uint32_t mn, mp;
-        if (vec_absmax16_dual(raw[u], mn, mp) && a.nan_flag) atomicOr(a.nan_flag, 1u);
+        uint32_t un = 0, sg = 0, mn, mp;
+        dual_max_acc(raw[u], un, sg);
+        dual_max_finish(un, sg, mn, mp);
         mn = row_max_dpp<LPR>(mn);
         mp = row_max_dpp<LPR>(mp);
+        if (__builtin_expect(dual_max_has_nan(mn, mp), 0)) {   // a NaN somewhere in the wavefront's vectors: the exact rule
+          if (vec_absmax16_dual(raw[u], mn, mp) && a.nan_flag) atomicOr(a.nan_flag, 1u);
+          mn = row_max_dpp<LPR>(mn);
+          mp = row_max_dpp<LPR>(mp);
+        }
         RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
         dual_poison(sn, sp);
         o = quant_vec16<true>(raw[u], lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
@@ -522,11 +559,19 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_pair_kernel(const u32x4* __
     }
     u32x4 oa, ob;
     if (DUAL) {
-      uint32_t mn, mp, mn2, mp2;
-      const uint32_t nan_any = vec_absmax16_dual(ra, mn, mp) | vec_absmax16_dual(rb, mn2, mp2);
-      if (nan_any && a.nan_flag) atomicOr(a.nan_flag, 1u);
-      mn = row_max_dpp<LPR>(mn > mn2 ? mn : mn2);
-      mp = row_max_dpp<LPR>(mp > mp2 ? mp : mp2);
+      uint32_t un = 0, sg = 0, mn, mp;
+      dual_max_acc(ra, un, sg);
+      dual_max_acc(rb, un, sg);
+      dual_max_finish(un, sg, mn, mp);
+      mn = row_max_dpp<LPR>(mn);
+      mp = row_max_dpp<LPR>(mp);
+      if (__builtin_expect(dual_max_has_nan(mn, mp), 0)) {   // the exact rule (NaN belongs to neither side)
+        uint32_t mn2, mp2;
+        const uint32_t nan_any = vec_absmax16_dual(ra, mn, mp) | vec_absmax16_dual(rb, mn2, mp2);
+        if (nan_any && a.nan_flag) atomicOr(a.nan_flag, 1u);
+        mn = row_max_dpp<LPR>(mn > mn2 ? mn : mn2);
+        mp = row_max_dpp<LPR>(mp > mp2 ? mp : mp2);
+      }
       RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
       dual_poison(sn, sp);
       oa = quant_vec16<true>(ra, lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
@@ -593,26 +638,39 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
     RowScale16 sn, sp;
     if (DUAL) {
       uint32_t mn = 0, mp = 0;
+      auto block_reduce = [&]() {   // both maxima through one LDS exchange (one barrier pair instead of two)
+        mn = row_max_dpp<64>(mn);
+        mp = row_max_dpp<64>(mp);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (mn << 16) | mp;
+        __syncthreads();
+        mn = 0;
+        mp = 0;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
-        uint32_t a1, b1;
-        if (vec_absmax16_dual(raw[c], a1, b1) && a.nan_flag) atomicOr(a.nan_flag, 1u);
-        mn = mn > a1 ? mn : a1;
-        mp = mp > b1 ? mp : b1;
+        for (int i = 0; i < kBlock / 64; ++i) {
+          const uint32_t w = sh[i];
+          mn = mn > (w >> 16) ? mn : (w >> 16);
+          mp = mp > (w & 0xFFFFu) ? mp : (w & 0xFFFFu);
+        }
+      };
+      {
+        uint32_t un = 0, sg = 0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) dual_max_acc(raw[c], un, sg);
+        dual_max_finish(un, sg, mn, mp);
       }
-      // both maxima through one LDS exchange (one barrier pair instead of two)
-      mn = row_max_dpp<64>(mn);
-      mp = row_max_dpp<64>(mp);
-      __syncthreads();
-      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (mn << 16) | mp;
-      __syncthreads();
-      mn = 0;
-      mp = 0;
+      block_reduce();
+      if (__builtin_expect(mn > 0x7C00u || mp > 0x7C00u, 0)) {   // a NaN in the row (the same for every thread): the exact rule
+        mn = 0;
+        mp = 0;
 #pragma unroll
-      for (int i = 0; i < kBlock / 64; ++i) {
-        const uint32_t w = sh[i];
-        mn = mn > (w >> 16) ? mn : (w >> 16);
-        mp = mp > (w & 0xFFFFu) ? mp : (w & 0xFFFFu);
+        for (int c = 0; c < MAXC; ++c) {
+          uint32_t a1, b1;
+          if (vec_absmax16_dual(raw[c], a1, b1) && a.nan_flag) atomicOr(a.nan_flag, 1u);
+          mn = mn > a1 ? mn : a1;
+          mp = mp > b1 ? mp : b1;
+        }
+        block_reduce();
       }
       sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg);
       sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
@@ -668,17 +726,30 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t*
     }
     RowScale16 sn, sp;
     if (DUAL) {
-      uint32_t mn = 0, mp = 0, nan_any = 0;
+      uint32_t mn, mp;
+      {
+        uint32_t un = 0, sg = 0;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
-        uint32_t a1, b1;
-        nan_any |= vec_absmax16_dual(raw[c], a1, b1);
-        mn = mn > a1 ? mn : a1;
-        mp = mp > b1 ? mp : b1;
+        for (int c = 0; c < MAXC; ++c) dual_max_acc(raw[c], un, sg);
+        dual_max_finish(un, sg, mn, mp);
       }
-      if (nan_any && a.nan_flag) atomicOr(a.nan_flag, 1u);
       mn = row_max_dpp<64>(mn);
       mp = row_max_dpp<64>(mp);
+      if (__builtin_expect(mn > 0x7C00u || mp > 0x7C00u, 0)) {   // a NaN in the row (wavefront-uniform): the exact rule
+        uint32_t nan_any = 0;
+        mn = 0;
+        mp = 0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          uint32_t a1, b1;
+          nan_any |= vec_absmax16_dual(raw[c], a1, b1);
+          mn = mn > a1 ? mn : a1;
+          mp = mp > b1 ? mp : b1;
+        }
+        if (nan_any && a.nan_flag) atomicOr(a.nan_flag, 1u);
+        mn = row_max_dpp<64>(mn);
+        mp = row_max_dpp<64>(mp);
+      }
       sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg);
       sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
       dual_poison(sn, sp);
