@@ -704,6 +704,43 @@ def test_rotate_quant_tiles(dev, rows, cols, in_dtype):
     assert_bits_equal(o6, orc.per_group_kernel_sem(y.cpu(), "e2m3", 128, out_dtype=torch.float16), "e2m3 after rotate")
 
 
+def test_rotate_butterfly_switch(dev, tmp_path):
+    """FPQ_ROT_BUTTERFLY=1 (read once per process, hence a child process) selects the butterfly form of the transform in
+    both producers: same contract - quantization exact on the rotated values it produced - and rotated values that agree
+    with the matrix-core form up to the last bit of rare elements."""
+    import subprocess
+    import sys
+    from fpqvar_amd import rotation as rot
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from fpqvar_amd import rotation as rot\n"
+        "d = torch.load(sys.argv[1])\n"
+        "dev = torch.device('cuda:0')\n"
+        "o, y = rot.rotate_quant(d['x'].to(dev), 'e2m1', return_rotated=True)\n"
+        "oa, ha, ya = rot.adaln_rotate_quant(d['xa'].to(dev), d['scale'].to(dev), d['shift'].to(dev), 'e2m1', return_intermediates=True)\n"
+        "torch.save({'o': o.cpu(), 'y': y.cpu(), 'oa': oa.cpu(), 'ha': ha.cpu(), 'ya': ya.cpu()}, sys.argv[2])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = torch.Generator().manual_seed(77)
+    d = {"x": (torch.randn(65, 1920, generator=g) * torch.exp(0.5 * torch.randn(65, 1920, generator=g))).half(),
+         "xa": torch.randn(3, 21, 1920, generator=g).half(),
+         "scale": (torch.randn(3, 1, 1920, generator=g) * 0.3).half(), "shift": (torch.randn(3, 1, 1920, generator=g) * 0.3).half()}
+    fin, fout = str(tmp_path / "in.pt"), str(tmp_path / "out.pt")
+    torch.save(d, fin)
+    env = dict(os.environ, FPQ_ROT_BUTTERFLY="1")
+    subprocess.run([sys.executable, "-c", script, fin, fout], check=True, env=env, timeout=300)
+    b = torch.load(fout)
+    o, y = rot.rotate_quant(d["x"].to(dev), "e2m1", return_rotated=True)
+    oa, ha, ya = rot.adaln_rotate_quant(d["xa"].to(dev), d["scale"].to(dev), d["shift"].to(dev), "e2m1", return_intermediates=True)
+    assert_bits_equal(b["ha"], ha, "modulated rows do not depend on the form of the transform")
+    for name, yb, ym in (("rotate", b["y"], y.cpu()), ("adaln", b["ya"], ya.cpu())):
+        dd = _ulp_diff_f16(yb, ym)
+        assert int(dd.max()) <= 1 and float((dd > 0).float().mean()) < 1e-3, f"{name}: the two forms disagree"
+    assert_bits_equal(b["o"], orc.per_group_kernel_sem(b["y"], "e2m1", 128), "butterfly form: quant of rotated")
+    assert_bits_equal(b["oa"], orc.per_group_kernel_sem(b["ya"].reshape(-1, 1920), "e2m1", 128).view_as(b["oa"]), "butterfly adaLN: quant of rotated")
+    assert_bits_equal(o, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "matrix-core form: quant of rotated")
+
+
 # ------------------------------------------------------------------ KV cache step and format search
 def test_kv_cache_step(dev):
     from fpqvar_amd import kv_cache as kv
