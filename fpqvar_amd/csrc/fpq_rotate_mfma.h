@@ -2,7 +2,7 @@
 // on the matrix cores.  Included by fpq_kernels.hip after fpq_fast16.h.
 //
 // Why: the butterfly form (rotate_quant16_kernel) is bound by vector-instruction issue, not by memory
-// (profiles/r02_pmc_rotate.txt: 22 VALU instructions per element, 8.5 of them the butterfly, the vector pipe ~80 %
+// (profiles/r02_pmc_rotate_butterfly.txt: 22 VALU instructions per element, 8.5 of them the butterfly, the vector pipe ~80 %
 // busy at 0.70 of 8 TB/s where the plain quantizer streams at 0.80).  The reference computes this step as a GEMM in
 // the first place (tr/basic_var.py:263,266: torch.matmul(x, Q), Q = blockdiag(diag(D) H128 / sqrt(128))); H128 is
 // +-1, exact as fp16 MFMA operands.
@@ -85,6 +85,9 @@ __device__ __forceinline__ float hadamard128_mfma(const u32x4* buf, const HadOpe
     for (int u = 0; u < 2; ++u)
       acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rq_h8_t, ha.a[u]), b, zero, 0, 0, 0);
   }
+  // The accumulators' first readers must be instructions the compiler sees (the adds below): its hazard recognizer
+  // inserts the wait states a matrix-core result needs before a VALU read, but does not look into inline assembly
+  // (a v_fma_mixlo_f16 straight on the accumulators read them two k-steps stale).
   float m = 0.0f;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
