@@ -874,6 +874,33 @@ def test_adaln_rotate_quant_fused(dev, C, L, x_dtype):
     assert float((_ulp_diff_f16(h3.cpu(), h3_ref.cpu()) > 0).float().mean()) < 2e-3
 
 
+@pytest.mark.parametrize("C", (128, 512, 1024, 1280, 1536, 2048))
+def test_adaln_rotate_quant_widths(dev, C):
+    """Rows of 1 .. 16 groups in the matrix-core form of the producer (one row = one 16-group tile, the groups beyond the
+    row are zeros in the operand image and fall outside the store range), per group and per token, batch entries of a
+    length that leaves a ragged last workgroup: the modulated row equals what the wide rows give, and given that row
+    everything downstream is the fused rotate+quant / the per-token quantizer bit for bit."""
+    from fpqvar_amd import ops, rotation as rot
+    g = torch.Generator().manual_seed(C)
+    B, L = 5, 23
+    x = (torch.randn(B, L, C, generator=g) * torch.exp(0.4 * torch.randn(B, L, C, generator=g)) + 0.2).half().to(dev)
+    scale = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    shift = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    s = (torch.rand(C, generator=g) * 1.5 + 0.25).to(dev)
+    out, h, y = rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s, return_intermediates=True)
+    assert_bits_equal(rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s), out, "emit vs no-emit")
+    ln = torch.nn.functional.layer_norm(x.float(), (C,), eps=1e-6)
+    h_ref = (ln.mul(scale.add(1)) + shift).mul(s).half()
+    assert float((_ulp_diff_f16(h.cpu(), h_ref.cpu()) > 0).float().mean()) < 5e-3
+    out2, y2 = rot.rotate_quant(h, "e2m1", return_rotated=True)
+    assert_bits_equal(y, y2, "rotated")
+    assert_bits_equal(out, out2, "quantized")
+    assert_bits_equal(out, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "quant of rotated")
+    tok = rot.adaln_rotate_quant_token(x, scale, shift, "e2m3", smooth=s)
+    assert_bits_equal(tok, ops.quant_rows(y, "e2m3", C, torch.float16), "per-token quant of the rotated row")
+    assert_bits_equal(tok, orc.per_token_kernel_sem(y.cpu(), "e2m3"), "per-token oracle")
+
+
 @pytest.mark.parametrize("source", ("qkv_view", "separate", "unaligned"))
 @pytest.mark.parametrize("kv_bit", (6, 4))
 def test_incremental_kv_equals_requantize_everything(dev, kv_bit, source):
