@@ -285,6 +285,13 @@ def other_kernels(dev):
         s = torch.rand(COLS, device=dev, generator=g) + 0.5
         hbm("adaln_rotate_quant_e2m1_fp16_65500x1920",
             timed(lambda: rot.adaln_rotate_quant(nxt(xa), scale, shift, "e2m1", smooth=s)), B * L * COLS * 4)
+        # the same producer on fp32 rows - the dtype of the residual stream in the reference's autocast run
+        # (tr/var.py:209, tr/basic_var.py:264,267): 4 B read + 2 B written per element
+        del xs
+        xf = [xa[i].float() for i in range(2)]
+        del xa
+        hbm("adaln_rotate_quant_e2m1_fp32rows_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant(nxt(xf), scale, shift, "e2m1", smooth=s)), B * L * COLS * 6)
 
     def weights():
         ws = [torch.randn(ROWS // 2, COLS, device=dev, generator=g) * 0.02 for _ in range(3)]

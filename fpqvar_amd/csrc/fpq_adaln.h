@@ -89,8 +89,20 @@ typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 #define FPQ_ADALN_OCC
 #endif
 
-// MFMA: the rotation on the matrix cores (fpq_rotate_mfma.h: a row of up to 16 groups is one tile; value output only)
-template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false, bool MFMA = false>
+#ifndef FPQ_ADALN_PREFETCH32
+#define FPQ_ADALN_PREFETCH32 1
+#endif
+
+// MFMA: the rotation on the matrix cores (fpq_rotate_mfma.h: a row of up to 16 groups is one tile; value output only).
+// X32: fp32 rows - the model's case: the residual stream is fp32 under the reference's autocast (tr/var.py:168,209:
+// fp16 Linear output + fp32 position embedding; tr/basic_var.py:264,267: fp32 x + fp16 branch).  A lane then loads
+// 4-float vectors n * 64 + lane of the row (n = 0 .. 2 MAXC - 1, every load a fully coalesced 16 bytes per lane; a
+// 32-bytes-per-lane mapping would leave each load instruction half of every 128-byte line, see fpq_fast32.h): that is
+// half h = lane & 1 of the 8-element chunk 32 n + lane / 2.  Statistics do not care, the modulation planes are kept by
+// halves anyway, and the lane's fp16 results (8 bytes) meet their other half in LDS - straight in the matrix-core
+// operand image, or in a row buffer that is read back in the one-chunk-per-lane order of the butterfly forms.  No
+// cross-lane exchange, no second kernel.
+template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false, bool MFMA = false, bool X32 = false>
 __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                            u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                            int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab,
@@ -99,6 +111,8 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
   __shared__ u32x4 planes[4 * 64 * 5];                                      // 64 bytes per vector of the row (<= 320 vectors)
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   constexpr int W = kBlock / 64;
+  constexpr int RV = X32 ? 2 * MAXC : MAXC;      // 16-byte registers of one row per lane
+  constexpr bool PREFETCH = X32 ? (FPQ_ADALN_PREFETCH32 != 0) : (FPQ_ADALN_PREFETCH != 0);
   const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
@@ -110,6 +124,9 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
     __shared__ u32x4 xpose[W][kRqTileVec];
     buf = xpose[wave];
     ha = had_operand(lane);
+  } else if constexpr (X32) {
+    __shared__ u32x4 rowbuf[W][64 * MAXC];   // the modulated row, halves in, whole chunks out
+    buf = rowbuf[wave];
   }
   const int64_t b = blockIdx.x / wgs_per_batch;
   const int chunk = blockIdx.x % wgs_per_batch;
@@ -126,14 +143,29 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
   for (int c = 0; c < MAXC; ++c) vidx[c] = c * 64 + lane;
   if (!last_live) vidx[MAXC - 1] = vpr - 1;      // any valid address: the value is zeroed, the store masked
 
-  auto load_row = [&](u32x4 (&dst)[MAXC], int64_t row) {
-    const u32x4* p = x + row * vpr;
+  // X32: 4-float vector n * 64 + lane; only the last two can lie outside (a whole half-wave at a time: vpr % 16 == 0)
+  int qidx[RV];
+  bool qlive[RV];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) dst[c] = __builtin_nontemporal_load(p + vidx[c]);
+  for (int n = 0; n < RV; ++n) {
+    qidx[n] = n * 64 + lane;
+    qlive[n] = !X32 || qidx[n] < 2 * vpr;
+    if (!qlive[n]) qidx[n] = 2 * vpr - 1;
+  }
+  auto load_row = [&](u32x4 (&dst)[RV], int64_t row) {
+    if constexpr (X32) {
+      const u32x4* p = x + row * (2 * vpr);
+#pragma unroll
+      for (int n = 0; n < RV; ++n) dst[n] = __builtin_nontemporal_load(p + qidx[n]);
+    } else {
+      const u32x4* p = x + row * vpr;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) dst[c] = __builtin_nontemporal_load(p + vidx[c]);
+    }
   };
-  u32x4 cur[MAXC];
+  u32x4 cur[RV];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) cur[c] = u32x4{0, 0, 0, 0};
+  for (int c = 0; c < RV; ++c) cur[c] = u32x4{0, 0, 0, 0};
   if (wave < n_here) load_row(cur, row0 + wave);   // requested before the staging below
 
   // ---- stage the table and the folded modulation of batch entry b ----
@@ -201,56 +233,80 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
 
   // One row: `cur` holds it, the wavefront's next row (if any) is requested into `nxt` first (software prefetch).
   // The row loop below alternates two register sets, so no row is ever copied from register to register.
-  auto do_row = [&](u32x4 (&cur)[MAXC], u32x4 (&nxt)[MAXC], int i) {
+  auto do_row = [&](u32x4 (&cur)[RV], u32x4 (&nxt)[RV], int i) {
     const int64_t row = row0 + i;
-#if FPQ_ADALN_PREFETCH
-    if (i + W < n_here) load_row(nxt, row + W);      // wave-uniform branch
-#else
-    (void)nxt;
-    if (i != wave) load_row(cur, row);               // no prefetch: the row is requested when its turn comes
-#endif
-    if (!last_live) cur[MAXC - 1] = u32x4{0, 0, 0, 0};
+    if constexpr (PREFETCH) {
+      if (i + W < n_here) load_row(nxt, row + W);      // wave-uniform branch
+    } else {
+      (void)nxt;
+      if (i != wave) load_row(cur, row);               // no prefetch: the row is requested when its turn comes
+    }
+    if constexpr (X32) {
+#pragma unroll
+      for (int n = (RV > 2 ? RV - 2 : 0); n < RV; ++n)
+        if (!qlive[n]) cur[n] = u32x4{0, 0, 0, 0};
+    } else {
+      if (!last_live) cur[MAXC - 1] = u32x4{0, 0, 0, 0};
+    }
 
     // ---- LayerNorm statistics: sum and sum of squares in one pass over the packed row (v_dot2_f32_f16: exact
     // products, fp32 accumulation; the zeroed padding vector adds nothing), var = E[x^2] - mean^2.  That
     // subtraction cancels when |mean| >> sigma: rows with mean^2 >= 64 var (6 of the 24 bits gone; also NaN / Inf
     // rows) take the centred second pass instead - wave-uniform branch, rare.
-    float a1[MAXC], a2[MAXC];
+    // fp32 rows: plain sums, the squares are rounded: the centred pass already when mean^2 >= 8 var.
+    float a1[RV], a2[RV];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) a1[c] = a2[c] = 0.0f;
+    for (int c = 0; c < RV; ++c) a1[c] = a2[c] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
+      for (int c = 0; c < RV; ++c) {
         const uint32_t xw = cur[c][k];   // NOT __builtin_bit_cast(h2v_t, cur[c][k]): hipcc 7.2 then reads element 0 for every k
-        const h2v_t xv = __builtin_bit_cast(h2v_t, xw);
-        a1[c] = __builtin_amdgcn_fdot2(xv, ones, a1[c], false);
-        a2[c] = __builtin_amdgcn_fdot2(xv, xv, a2[c], false);
+        if constexpr (X32) {
+          const float xf = u2f(xw);
+          a1[c] += xf;
+          a2[c] = __builtin_fmaf(xf, xf, a2[c]);
+        } else {
+          const h2v_t xv = __builtin_bit_cast(h2v_t, xw);
+          a1[c] = __builtin_amdgcn_fdot2(xv, ones, a1[c], false);
+          a2[c] = __builtin_amdgcn_fdot2(xv, xv, a2[c], false);
+        }
       }
     float s1 = a1[0], s2 = a2[0];
 #pragma unroll
-    for (int c = 1; c < MAXC; ++c) {
+    for (int c = 1; c < RV; ++c) {
       s1 += a1[c];
       s2 += a2[c];
     }
     wave_sum2_dpp(s1, s2);
     const float mean = s1 * inv_c;
     float var = __builtin_fmaf(-mean, mean, s2 * inv_c);
-    if (!(mean * mean < 64.0f * var)) {
+    if (!(mean * mean < (X32 ? 8.0f : 64.0f) * var)) {
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) a2[c] = 0.0f;
+      for (int c = 0; c < RV; ++c) a2[c] = 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-          const float d0 = fma_h_lo(cur[c][k], 1.0f, -mean), d1 = fma_h_hi(cur[c][k], 1.0f, -mean);
-          a2[c] = __builtin_fmaf(d0, d0, a2[c]);
-          a2[c] = __builtin_fmaf(d1, d1, a2[c]);
+        for (int c = 0; c < RV; ++c) {
+          if constexpr (X32) {
+            const float d0 = u2f(cur[c][k]) - mean;
+            a2[c] = __builtin_fmaf(d0, d0, a2[c]);
+          } else {
+            const float d0 = fma_h_lo(cur[c][k], 1.0f, -mean), d1 = fma_h_hi(cur[c][k], 1.0f, -mean);
+            a2[c] = __builtin_fmaf(d0, d0, a2[c]);
+            a2[c] = __builtin_fmaf(d1, d1, a2[c]);
+          }
         }
-      if (!last_live) a2[MAXC - 1] = 0.0f;            // the zeroed padding vector is not part of the row
+      if constexpr (X32) {                            // the zeroed padding is not part of the row
+#pragma unroll
+        for (int n = (RV > 2 ? RV - 2 : 0); n < RV; ++n)
+          if (!qlive[n]) a2[n] = 0.0f;
+      } else {
+        if (!last_live) a2[MAXC - 1] = 0.0f;
+      }
       s2 = a2[0];
 #pragma unroll
-      for (int c = 1; c < MAXC; ++c) s2 += a2[c];
+      for (int c = 1; c < RV; ++c) s2 += a2[c];
       var = wave_sum_dpp(s2) * inv_c;
     }
     // rstd = 1 / sqrt(var + eps): v_rsq_f32 (1 ulp) + one Newton step, ~2^-23 relative - four instructions instead of
@@ -260,12 +316,50 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
     rstd = __builtin_fmaf(rstd * __builtin_fmaf(-ve * rstd, rstd, 1.0f), 0.5f, rstd);
     const float nm = -mean * rstd;
 
+    if constexpr (X32) {
+      // ---- fp32 rows: modulate this lane's half-chunks, 8 bytes of fp16 each, into LDS ----
+      const int lane_x = rq_opaque(lane);
+      const int hsel = lane_x & 1, k2 = lane_x >> 1;
+      u32x2* img = (u32x2*)buf;
+      uint32_t sx2[2] = {0, 0};
+      if constexpr (EMIT && MFMA) {   // h_out wants the modulated row without the rotation's signs
+        const int j0 = (k2 & 15) * 8 + 4 * hsel;
+        const uint32_t db = (r.sign[j0 >> 5] >> (j0 & 31)) & 0xFu;
+        sx2[0] = ((db & 1u) << 15) | (((db >> 1) & 1u) << 31);
+        sx2[1] = (((db >> 2) & 1u) << 15) | (((db >> 3) & 1u) << 31);
+      }
+#pragma unroll
+      for (int n = 0; n < (MFMA ? 8 : RV); ++n) {
+        const int v = 32 * n + k2;                       // chunk of the row
+        u32x2 hw2 = {0, 0};
+        if (n < RV) {
+          const u32x4 A = planes[hsel * vpr + v], B = planes[(2 + hsel) * vpr + v];   // beyond the row: in bounds, unused
+          const u32x4 w = cur[n];
+          hw2[0] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[0]), rstd, nm), u2f(A[0]), u2f(B[0])),
+                        __builtin_fmaf(__builtin_fmaf(u2f(w[1]), rstd, nm), u2f(A[1]), u2f(B[1])));
+          hw2[1] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[2]), rstd, nm), u2f(A[2]), u2f(B[2])),
+                        __builtin_fmaf(__builtin_fmaf(u2f(w[3]), rstd, nm), u2f(A[3]), u2f(B[3])));
+          if (n >= RV - 2 && !qlive[n]) hw2 = u32x2{0, 0};
+          if constexpr (EMIT && MFMA) {
+            if (h_out && qlive[n])
+              __builtin_nontemporal_store(u32x2{hw2[0] ^ sx2[0], hw2[1] ^ sx2[1]}, (u32x2*)(h_out + row * vpr + v) + hsel);
+          }
+        }
+        if constexpr (MFMA) {
+          const int g = 2 * n + (k2 >> 4), pc = k2 & 15;
+          img[(pc * 16 + (g ^ pc)) * 2 + hsel] = hw2;
+        } else {
+          img[v * 2 + hsel] = hw2;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     if constexpr (MFMA) {
       // ---- modulate into the B-operand image (all 16 groups defined: vectors beyond the row are zeros), transform on
       // the matrix cores, quantize the 32 outputs this lane holds of its group, out through the same image ----
       const int lane_w = rq_opaque(lane);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < (X32 ? 0 : 4); ++c) {
         u32x4 hw = {0, 0, 0, 0};
         if (c < MAXC) {
           const int v = vidx[c];
@@ -340,17 +434,21 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
 #pragma unroll
       for (int j = 0; j < n; ++j) {
         const int v = vidx[c0 + j];
-        const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
-        const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
-        const u32x4 w = cur[c0 + j];
-        hw[j][0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
-                        __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
-        hw[j][1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
-                        __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
-        hw[j][2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
-                        __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
-        hw[j][3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
-                        __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
+        if constexpr (X32) {
+          hw[j] = buf[v];                                // the modulated row, written by halves above
+        } else {
+          const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
+          const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
+          const u32x4 w = cur[c0 + j];
+          hw[j][0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
+                          __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
+          hw[j][1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
+                          __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
+          hw[j][2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
+                          __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
+          hw[j][3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
+                          __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
+        }
       }
       if (!last_live && c0 + n == MAXC) hw[n - 1] = u32x4{0, 0, 0, 0};
       fwht128_h_n<N2>(hw, t, n, lg);                     // hw already carries the rotation's signs
@@ -451,14 +549,15 @@ __global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const 
       }
     }
     }
+    if constexpr (X32 && !MFMA) __builtin_amdgcn_wave_barrier();   // the row buffer is rewritten by the next row
   };
-  u32x4 alt[MAXC];
-#if FPQ_ADALN_PREFETCH
-  for (int i = wave; i < n_here; i += 2 * W) {   // no barrier below: wavefronts run their rows independently
-    do_row(cur, alt, i);
-    if (i + W < n_here) do_row(alt, cur, i + W);
+  u32x4 alt[RV];
+  if constexpr (PREFETCH) {
+    for (int i = wave; i < n_here; i += 2 * W) {   // no barrier below: wavefronts run their rows independently
+      do_row(cur, alt, i);
+      if (i + W < n_here) do_row(alt, cur, i + W);
+    }
+  } else {
+    for (int i = wave; i < n_here; i += W) do_row(cur, alt, i);
   }
-#else
-  for (int i = wave; i < n_here; i += W) do_row(cur, alt, i);
-#endif
 }

@@ -987,8 +987,9 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));
   r.vec_per_row = cols / 8;
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
-  if constexpr (sizeof(Tin) == 2) {
-    // second generation (fpq_adaln.h): fp16 rows of up to 2560 channels, one batch entry per workgroup
+  {
+    // second generation (fpq_adaln.h): fp16 or fp32 rows of up to 2560 channels, one batch entry per workgroup
+    constexpr bool X32 = sizeof(Tin) == 4;
     if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !getenv("FPQ_ADALN_V1")) {
       const char* rows_env = getenv("FPQ_ADALN_ROWS");
       // 16 rows per workgroup amortise the staging of the modulation planes; small launches (the early scale steps of a
@@ -1008,15 +1009,15 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   do {                                                                                                                 \
     if constexpr (!(CODES) && (M) <= 4) {                                                                              \
       if (!adaln_butterfly) {                                                                                          \
-        hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, true>), g2, dim3(kBlock), lds2, st,         \
+        hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, true, X32>), g2, dim3(kBlock), lds2, st,    \
                            (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,       \
                            rows_per_wg, (int)per_batch);                                                               \
         break;                                                                                                         \
       }                                                                                                                \
     }                                                                                                                  \
-    hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN>), g2, dim3(kBlock), lds2, st, (const u32x4*)x,  \
-                       (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, rows_per_wg,               \
-                       (int)per_batch);                                                                                \
+    hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, false, X32>), g2, dim3(kBlock), lds2, st,       \
+                       (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,           \
+                       rows_per_wg, (int)per_batch);                                                                   \
   } while (0)
 #define FPQ_ADALN2(M)                                                                                                  \
   do {                                                                                                                 \

@@ -62,6 +62,17 @@ def main():
     s = torch.rand(C, device=dev, generator=g) + 0.5
     cases["adaln_rotate_quant"] = lambda: rot.adaln_rotate_quant(x16()[:B * L].view(B, L, C), scale, shift, "e2m1", smooth=s)
     cases["adaln_token_e2m3"] = lambda: rot.adaln_rotate_quant_token(x16()[:B * L].view(B, L, C), scale, shift, "e2m3", smooth=s)
+    x32r = None
+
+    def x32():   # the residual stream is fp32 in the model (tr/var.py:209)
+        nonlocal x32r
+        if x32r is None:
+            x32r = rotating([torch.randn(B, L, C, device=dev, generator=g) for _ in range(3)])
+        return x32r()
+    cases["adaln_rotate_quant_x32"] = lambda: rot.adaln_rotate_quant(x32(), scale, shift, "e2m1", smooth=s)
+    cases["adaln_token_e2m3_x32"] = lambda: rot.adaln_rotate_quant_token(x32(), scale, shift, "e2m3", smooth=s)
+    cases["adaln_codes_mx_x32"] = lambda: rot.adaln_rotate_quant_mx(x32(), scale, shift, smooth=s)
+    cases["adaln_codes_mx"] = lambda: rot.adaln_rotate_quant_mx(x16()[:B * L].view(B, L, C), scale, shift, smooth=s)
     big = None
 
     def fc2():

@@ -54,11 +54,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=100)
     ap.add_argument("--tokens", type=int, default=256)
+    ap.add_argument("--residual", default="fp32", choices=("fp32", "fp16"),
+                    help="dtype of the residual stream: fp32 is what the reference's autocast run carries (tr/var.py:209 adds an "
+                         "fp32 position embedding to the fp16 word embedding; tr/basic_var.py:264,267 keep x fp32)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     B, L = args.batch, args.tokens
-    x = torch.randn(B, L, C, device=dev).half()
+    x = torch.randn(B, L, C, device=dev)
+    if args.residual == "fp16":
+        x = x.half()
     mod = [(torch.randn(B, 1, C, device=dev) * 0.2).half() for _ in range(6)]   # gamma1, gamma2, scale1, scale2, shift1, shift2
     gamma1, gamma2, scale1, scale2, shift1, shift2 = mod
     s_qkv = torch.rand(C, device=dev) + 0.5
@@ -137,7 +142,7 @@ def main():
     def rel(a):
         return float((a - yr).norm() / delta.norm())     # error relative to what the block adds to the residual
 
-    res = {"rows": B * L, "R_reference_sequence_ms": round(timed(block_ref, 3), 3), "F_fused_fake_quant_ms": round(timed(block_fused), 3),
+    res = {"rows": B * L, "residual": args.residual, "R_reference_sequence_ms": round(timed(block_ref, 3), 3), "F_fused_fake_quant_ms": round(timed(block_fused), 3),
            "Q_fp4_matrix_cores_ms": round(timed(block_fp4), 3), "F_vs_R_rel_err_of_block_update": round(rel(yf), 5),
            "Q_vs_R_rel_err_of_block_update": round(rel(yq), 5)}
     # the same block without any quantization, for scale
