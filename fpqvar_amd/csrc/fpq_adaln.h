@@ -92,6 +92,9 @@ typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 #ifndef FPQ_ADALN_PREFETCH32
 #define FPQ_ADALN_PREFETCH32 1
 #endif
+#ifndef FPQ_ADALN_X32_WAVES   // fp32 rows of 13 .. 16 groups with the next row prefetched: 130 registers = 3 wavefronts per SIMD; capped at 128 (= 4, with 3 - 5 spilled) measured the same 134 - 138 us: left uncapped
+#define FPQ_ADALN_X32_WAVES 1
+#endif
 
 // MFMA: the rotation on the matrix cores (fpq_rotate_mfma.h: a row of up to 16 groups is one tile; value output only).
 // X32: fp32 rows - the model's case: the residual stream is fp32 under the reference's autocast (tr/var.py:168,209:
@@ -103,7 +106,7 @@ typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 // operand image, or in a row buffer that is read back in the one-chunk-per-lane order of the butterfly forms.  No
 // cross-lane exchange, no second kernel.
 template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false, bool MFMA = false, bool X32 = false>
-__global__ __launch_bounds__(kBlock) FPQ_ADALN_OCC void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
+__global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_ADALN_X32_WAVES : 1) FPQ_ADALN_OCC void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                            u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                            int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab,
                                                            int rows_per_wg, int wgs_per_batch) {

@@ -6,7 +6,7 @@ set -e
 out=$PWD/gpurun_out/prof_r02
 mkdir -p $out
 export TMPDIR=/tmp
-for k in sym rotate dual dual6 calib channel adaln; do
+for k in sym rotate dual dual6 calib channel adaln adaln32; do
   tools/pmc_run.sh $k > /dev/null 2>&1
   { echo "# tools/pmc_run.sh $k  (tools/prof_one.py $k; averages per launch over 5 launches)"; cat gpurun_out/pmc_$k/p1.summary.txt gpurun_out/pmc_$k/p2.summary.txt gpurun_out/pmc_$k/p3.summary.txt gpurun_out/pmc_$k/p4.summary.txt; echo "# rocprofv3 --kernel-trace --stats of the same script:"; grep -E "^\"_ZN12_GLOBAL__N_|^\"void \(anonymous namespace\)::" gpurun_out/pmc_$k/kernel_stats.csv | sed -E 's/^"(_ZN12_GLOBAL__N_[0-9]*[a-z_0-9]*)[^"]*"/\1/; s/^"void \(anonymous namespace\)::([a-z_0-9]*<[^>]*>)[^"]*"/\1/'; } > $out/pmc_$k.txt
   echo "pmc $k ok"

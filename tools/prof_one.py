@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE kernel a few times (for rocprofv3 --pmc passes).
-usage: prof_one.py {adaln|rotate|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
+usage: prof_one.py {adaln|adaln32|rotate|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -13,9 +13,11 @@ which = sys.argv[1] if len(sys.argv) > 1 else "sym"
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 C = 1920
-if which == "adaln":
+if which in ("adaln", "adaln32"):
     B, L = 100, 655
-    x = torch.randn(B, L, C, device=dev).half()
+    x = torch.randn(B, L, C, device=dev)
+    if which == "adaln":
+        x = x.half()
     scale = (torch.randn(B, 1, C, device=dev) * 0.3).half()
     shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
     s = torch.rand(C, device=dev) + 0.5
