@@ -142,7 +142,10 @@ __device__ __forceinline__ void rq_store_tile(u32x4* buf, const uint32_t (&w)[8]
   __builtin_amdgcn_wave_barrier();
 }
 
-// one tile's raw input: vector i * 64 + lane, i = 0 .. 3 (fp16: as loaded; fp32: two loads per vector, converted later)
+// one tile's raw input, every load a fully coalesced 16 bytes per lane.  fp16: vector i * 64 + lane, i = 0 .. 3, = chunk
+// (8 elements) i * 64 + lane.  fp32: 4-float vector n * 64 + lane, n = 0 .. 7, = half lane & 1 of chunk 32 n + lane / 2
+// (32 bytes per lane would leave each load instruction half of every 128-byte line, fpq_fast32.h): the lane converts
+// its half-chunks and they meet their other halves in the LDS image.
 template <typename Tin>
 struct RqRaw {
   u32x4 w[sizeof(Tin) == 2 ? 4 : 8];
@@ -151,14 +154,8 @@ struct RqRaw {
 template <typename Tin>
 __device__ __forceinline__ void rq_load_tile(__amdgpu_buffer_rsrc_t src, int lane, RqRaw<Tin>& raw) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (sizeof(Tin) == 2) {
-      raw.w[i] = __builtin_amdgcn_raw_buffer_load_b128(src, lane * 16 + i * 1024, 0, kRqNt);
-    } else {
-      raw.w[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(src, lane * 32 + i * 2048, 0, kRqNt);
-      raw.w[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(src, lane * 32 + i * 2048 + 16, 0, kRqNt);
-    }
-  }
+  for (int i = 0; i < (sizeof(Tin) == 2 ? 4 : 8); ++i)
+    raw.w[i] = __builtin_amdgcn_raw_buffer_load_b128(src, lane * 16 + i * 1024, 0, kRqNt);
 }
 
 // lut_pair16 with one instruction less: bit shift-1 of both patterns is cleared at once, after which the byte offsets
@@ -184,7 +181,13 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
                                                                                  Lut16Tab tab) {
   __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];
   __shared__ u32x4 xpose[kBlock / 64][kRqTileVec];   // 4 KiB per wavefront, private to it
-  constexpr bool PREFETCH = sizeof(Tin) == 2 && !EMIT;   // the emitting form is for tests and calibration dumps
+#ifndef FPQ_ROT_PREFETCH16
+#define FPQ_ROT_PREFETCH16 1
+#endif
+#ifndef FPQ_ROT_PREFETCH32   // fp32 input: 32 more registers take the kernel from 8 to 5 wavefronts per SIMD, measured 72 - 75 us against 64 - 65 without
+#define FPQ_ROT_PREFETCH32 0
+#endif
+  constexpr bool PREFETCH = (sizeof(Tin) == 2 ? FPQ_ROT_PREFETCH16 != 0 : FPQ_ROT_PREFETCH32 != 0) && !EMIT;   // the emitting form is for tests and calibration dumps
   constexpr int VW = sizeof(Tin) == 2 ? 1 : 2;           // 16-byte words per input vector
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -222,11 +225,10 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
     if (!PREFETCH) rq_load_tile<Tin>(in_rsrc(tile), lane, raw);
     // 1. + 2.: (smooth,) sign, into the B-operand image
     const int lane_w = rq_opaque(lane);
+    if constexpr (sizeof(Tin) == 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u32x4 w;
-      if constexpr (sizeof(Tin) == 2) {
-        w = raw.w[i];
+      for (int i = 0; i < 4; ++i) {
+        u32x4 w = raw.w[i];
         if (SMOOTH) {   // h = half(float(x) * s)
           const int64_t v = base_vec + i * 64 + lane;
           const float* sp = r.smooth + ((v < n_vec ? v : 0) % r.vec_per_row) * 8;
@@ -234,20 +236,26 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
           for (int k = 0; k < 4; ++k)
             w[k] = f2h(h2f(w[k] & 0xFFFFu) * sp[2 * k]) | (f2h(h2f(w[k] >> 16) * sp[2 * k + 1]) << 16);
         }
-      } else {            // fp32 producer output: h = half(x * s)
-        const u32x4 lo = raw.w[2 * i], hi = raw.w[2 * i + 1];
-        float f[8] = {u2f(lo[0]), u2f(lo[1]), u2f(lo[2]), u2f(lo[3]), u2f(hi[0]), u2f(hi[1]), u2f(hi[2]), u2f(hi[3])};
-        if (SMOOTH) {
-          const int64_t v = base_vec + i * 64 + lane;
-          const float* sp = r.smooth + ((v < n_vec ? v : 0) % r.vec_per_row) * 8;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) f[k] *= sp[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = f2h(f[2 * k]) | (f2h(f[2 * k + 1]) << 16);
+        const int g = 4 * i + (lane_w >> 4), p = lane_w & 15;
+        buf[p * 16 + (g ^ p)] = u32x4{w[0] ^ sx[0], w[1] ^ sx[1], w[2] ^ sx[2], w[3] ^ sx[3]};
       }
-      const int g = 4 * i + (lane_w >> 4), p = lane_w & 15;
-      buf[p * 16 + (g ^ p)] = u32x4{w[0] ^ sx[0], w[1] ^ sx[1], w[2] ^ sx[2], w[3] ^ sx[3]};
+    } else {            // fp32 producer output: h = half(x * s), half-chunks of 8 bytes
+      const int hsel = lane_w & 1, k2 = lane_w >> 1;
+      const uint32_t sb2 = (r.sign[(k2 & 15) >> 2] >> (((k2 & 15) & 3) * 8 + 4 * hsel)) & 0xFu;
+      const uint32_t sy[2] = {((sb2 & 1u) << 15) | (((sb2 >> 1) & 1u) << 31), (((sb2 >> 2) & 1u) << 15) | (((sb2 >> 3) & 1u) << 31)};
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        float f[4] = {u2f(raw.w[n][0]), u2f(raw.w[n][1]), u2f(raw.w[n][2]), u2f(raw.w[n][3])};
+        if (SMOOTH) {
+          const int64_t v = base_vec + 32 * n + k2;
+          const float* sp = r.smooth + ((v < n_vec ? v : 0) % r.vec_per_row) * 8 + 4 * hsel;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f[k] *= sp[k];
+        }
+        const int g = 2 * n + (k2 >> 4), p = k2 & 15;
+        ((u32x2*)buf)[(p * 16 + (g ^ p)) * 2 + hsel] =
+            u32x2{(f2h(f[0]) | (f2h(f[1]) << 16)) ^ sy[0], (f2h(f[2]) | (f2h(f[3]) << 16)) ^ sy[1]};
+      }
     }
     if (PREFETCH)   // the next tile, in flight during 3. - 5.
       rq_load_tile<Tin>(in_rsrc(tile + tile_step), lane, raw);

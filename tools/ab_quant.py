@@ -69,6 +69,8 @@ def main():
         if x32r is None:
             x32r = rotating([torch.randn(B, L, C, device=dev, generator=g) for _ in range(3)])
         return x32r()
+    xr32 = rotating([torch.randn(R // 2, C, device=dev, generator=g) for _ in range(3)])
+    cases["rotate_quant_x32"] = lambda: rot.rotate_quant(xr32(), "e2m1")
     cases["adaln_rotate_quant_x32"] = lambda: rot.adaln_rotate_quant(x32(), scale, shift, "e2m1", smooth=s)
     cases["adaln_token_e2m3_x32"] = lambda: rot.adaln_rotate_quant_token(x32(), scale, shift, "e2m3", smooth=s)
     cases["adaln_codes_mx_x32"] = lambda: rot.adaln_rotate_quant_mx(x32(), scale, shift, smooth=s)
