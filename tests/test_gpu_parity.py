@@ -874,6 +874,29 @@ def test_adaln_rotate_quant_fused(dev, C, L, x_dtype):
     assert float((_ulp_diff_f16(h3.cpu(), h3_ref.cpu()) > 0).float().mean()) < 2e-3
 
 
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("L", (1, 2, 5, 65))
+def test_adaln_rotate_quant_short_entries(dev, L, x_dtype):
+    """Batch entries of 1, 2, 5 tokens (the first scale steps of a generation: idle wavefronts in every workgroup) and of
+    65 (a last workgroup with one row), many entries, fp16 and fp32 rows: against the fused rotate+quant on the emitted
+    modulated row, and fp32 against fp16 rows of the same values."""
+    from fpqvar_amd import rotation as rot
+    C, B = 1920, 37
+    g = torch.Generator().manual_seed(100 + L)
+    x = (torch.randn(B, L, C, generator=g) * 1.5 + 0.1).half().to(x_dtype).to(dev)
+    scale = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    shift = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    out, h, y = rot.adaln_rotate_quant(x, scale, shift, "e2m1", return_intermediates=True)
+    assert_bits_equal(rot.adaln_rotate_quant(x, scale, shift, "e2m1"), out, "emit vs no-emit")
+    out2, y2 = rot.rotate_quant(h, "e2m1", return_rotated=True)
+    assert_bits_equal(y, y2, "rotated")
+    assert_bits_equal(out, out2, "quantized")
+    if x_dtype == torch.float32:   # the same values as fp16 rows: statistics differ in rounding only
+        h16 = rot.adaln_rotate_quant(x.half(), scale, shift, "e2m1", return_intermediates=True)[1]
+        assert float((_ulp_diff_f16(h.cpu(), h16.cpu()) > 0).float().mean()) < 2e-3   # (cancelling elements may move by more than one ulp)
+        assert float((h.float() - h16.float()).abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize("C", (128, 512, 1024, 1280, 1536, 2048))
 def test_adaln_rotate_quant_widths(dev, C):
     """Rows of 1 .. 16 groups in the matrix-core form of the producer (one row = one 16-group tile, the groups beyond the
