@@ -200,9 +200,12 @@ int fpq_quant_rows_neg_reverse(const void* x, void* out, int64_t rows, int64_t c
  * smooth: device float[cols] (the GALT factor s of this block) or NULL;
  * sign_mask_host: HOST pointer to 4 x uint32, bit j set <=> D[j] == -1 (seed-42 vector);
  * out: fp16 [rows, cols]; rotated_out: NULL, or fp16 [rows, cols] receiving y.
- * Parity: out == fpq_quant_rows(y) bit for bit; y is within 1 fp16 ulp of the
- * fp64-accumulated half(x*s) @ half(Q) (the reference GEMM's summation order is
- * unspecified).  All pointers 16-byte aligned. */
+ * Parity: out == fpq_quant_rows(y) bit for bit; y = half(c_h * sum) with the +-h_j summed in fp32 (on the matrix
+ * cores; exact for groups of like magnitude): |y - exact| <= 1/2 fp16 ulp + 2^-22 c_h sum|h_j|, i.e. within 1 fp16
+ * ulp of the fp64-accumulated half(x*s) @ half(Q) except on cancelling outputs of groups spanning > 2^13 in magnitude
+ * (the reference GEMM's summation order is unspecified, and its +-c_h operands round more).  A non-finite input
+ * poisons its own group of 128 only (the reference's dense GEMM with the block-diagonal Q: its whole row, 0 * inf).
+ * x may be F32: the kernel then reads 16 bytes per lane all the same.  All pointers 16-byte aligned. */
 int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t rows, int64_t cols,
                           int in_dtype, const float* smooth, const uint32_t* sign_mask_host, int table_id,
                           fpq_stream_t stream);
@@ -212,7 +215,8 @@ int fpq_rotate_quant_rows(const void* x, void* out, void* rotated_out, int64_t r
  *                                                                            the reference's order)
  *     y   = half( c_h * FWHT128(h * D) )          (= h @ half(Q_block))
  *     out = per-group(128) quant(y)
- * x: [rows, cols] F16/F32, cols % 128 == 0, cols <= 4096; scale, shift: [rows / rows_per_batch, cols]
+ * x: [rows, cols] F16/F32 (F32 is what the reference's autocast run carries: tr/var.py:209, tr/basic_var.py:264,267),
+ * cols % 128 == 0, cols <= 4096; scale, shift: [rows / rows_per_batch, cols]
  * in mod_dtype (the block's AdaLN scale1/shift1 or scale2/shift2, one row per batch element);
  * smooth: device float[cols] or NULL; sign_mask_host as in fpq_rotate_quant_rows.
  * h_out / rotated_out: NULL or fp16 [rows, cols] receiving h / y (for verification).
