@@ -120,7 +120,8 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  static_assert(!MFMA || (!CODES && MAXC <= 4), "matrix-core rotation: value output, rows of at most 16 groups");
+  static_assert(!MFMA || (!CODES && (MAXC <= 4 || (MAXC == 5 && !TOKEN))),
+                "matrix-core rotation: value output; rows of at most 16 groups, or 17 .. 20 with one scale per group");
   u32x4* buf = nullptr;           // MFMA: this wavefront's operand / output image
   HadOperand ha = {};
   if constexpr (MFMA) {
@@ -422,6 +423,64 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
           yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
         }
       rq_store_tile(buf, yw, rq_rsrc(out + row * vpr, vpr * 16), lane);
+      if constexpr (MAXC == 5) {
+        // ---- groups 16 .. 19 (vectors 256 .. vpr - 1; d36: C = 2304 = 18 groups): a second tile would run its
+        // epilogue for 64 lanes to serve 8 - 16 of them; one chunk per lane with the transform as butterflies costs 40 %
+        // of a tile and keeps every lane busy ----
+        u32x4 hw;
+        const int v = vidx[4];
+        if constexpr (X32) {   // the two half-chunk loads beyond the tile: halves meet in the (free again) image
+          const int lane_x = rq_opaque(lane);
+          const int hsel = lane_x & 1, k2 = lane_x >> 1;
+#pragma unroll
+          for (int n = 8; n < RV; ++n) {
+            const int v2 = 32 * n + k2;
+            const u32x4 A = planes[hsel * vpr + v2], B = planes[(2 + hsel) * vpr + v2];
+            const u32x4 w = cur[n];
+            u32x2 hw2;
+            hw2[0] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[0]), rstd, nm), u2f(A[0]), u2f(B[0])),
+                          __builtin_fmaf(__builtin_fmaf(u2f(w[1]), rstd, nm), u2f(A[1]), u2f(B[1])));
+            hw2[1] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[2]), rstd, nm), u2f(A[2]), u2f(B[2])),
+                          __builtin_fmaf(__builtin_fmaf(u2f(w[3]), rstd, nm), u2f(A[3]), u2f(B[3])));
+            if (!qlive[n]) hw2 = u32x2{0, 0};
+            ((u32x2*)buf)[(v2 - 256) * 2 + hsel] = hw2;
+          }
+          __builtin_amdgcn_wave_barrier();
+          hw = buf[rq_opaque(lane)];
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
+          const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
+          const u32x4 w = cur[4];
+          hw[0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
+                       __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
+          hw[1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
+                       __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
+          hw[2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
+                       __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
+          hw[3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
+                       __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
+        }
+        if (!last_live) hw = u32x4{0, 0, 0, 0};
+        const u32x4 hwa[1] = {hw};
+        float t1[1][8];
+        fwht128_h_n<1>(hwa, t1, 1, lg);
+        u32x4 y1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y1[k] = mul2_to_h2(t1[0][2 * k], t1[0][2 * k + 1], r.c_h);
+        uint32_t m1[1] = {vec_absmax16(y1)};
+        row_max_dpp16_n<1>(m1, 1);
+        const RowScale16 s1 = row_scale16(m1[0], a.fpos.gmax, a.inv_gpos);
+        const u32x4 o1 = quant_vec16<false>(y1, lut, a.shift, s1.inv, s1.inv_lo, s1.s16x2, 0.f, 0.f, 0u);
+        if (last_live) {
+          const int64_t at = row * vpr + v;
+          if constexpr (EMIT) {
+            if (h_out) __builtin_nontemporal_store(u32x4{hw[0] ^ sx[0], hw[1] ^ sx[1], hw[2] ^ sx[2], hw[3] ^ sx[3]}, h_out + at);
+            if (y_out) __builtin_nontemporal_store(y1, y_out + at);
+          }
+          __builtin_nontemporal_store(o1, out + at);
+        }
+      }
     } else {
     // ---- modulate, rotate, quantize: vectors two at a time, stage by stage ----
     u32x4 ys[TOKEN ? MAXC : 1];   // per-token scale: the rotated row waits here for the row maximum
