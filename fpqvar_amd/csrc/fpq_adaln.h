@@ -120,8 +120,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  static_assert(!MFMA || (!CODES && (MAXC <= 4 || (MAXC == 5 && !TOKEN))),
-                "matrix-core rotation: value output; rows of at most 16 groups, or 17 .. 20 with one scale per group");
+  static_assert(!MFMA || (!CODES && MAXC <= 5), "matrix-core rotation: value output, rows of at most 20 groups");
   u32x4* buf = nullptr;           // MFMA: this wavefront's operand / output image
   HadOperand ha = {};
   if constexpr (MFMA) {
@@ -402,33 +401,13 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
         const uint32_t lo = m & 0xFFFFu, hi = m >> 16;
         m = lo > hi ? lo : hi;
       }
-      if constexpr (TOKEN) {
-        m = row_max_dpp<64>(m);        // fp6_quant_*_per_token_cuda on the rotated row: one scale for the whole row
-      } else {
-        auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
-        m = sw[0] > sw[1] ? sw[0] : sw[1];
-        sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
-        m = sw[0] > sw[1] ? sw[0] : sw[1];
-      }
-      const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      if constexpr (TOKEN) {
-        if (r.code_scales && lane == 0) r.code_scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
-          const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
-          yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
-        }
-      rq_store_tile(buf, yw, rq_rsrc(out + row * vpr, vpr * 16), lane);
+      // ---- groups 16 .. 19 (vectors 256 .. vpr - 1; d36: C = 2304 = 18 groups): a second tile would run its epilogue
+      // for 64 lanes to serve 8 - 16 of them; one chunk per lane with the transform as butterflies costs 40 % of a tile
+      // and keeps every lane busy.  Rotated here, quantized after the tile (per token: with the row's one scale) ----
+      u32x4 hw = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
+      uint32_t m1 = 0;
+      const int v = vidx[MAXC - 1];
       if constexpr (MAXC == 5) {
-        // ---- groups 16 .. 19 (vectors 256 .. vpr - 1; d36: C = 2304 = 18 groups): a second tile would run its
-        // epilogue for 64 lanes to serve 8 - 16 of them; one chunk per lane with the transform as butterflies costs 40 %
-        // of a tile and keeps every lane busy ----
-        u32x4 hw;
-        const int v = vidx[4];
         if constexpr (X32) {   // the two half-chunk loads beyond the tile: halves meet in the (free again) image
           const int lane_x = rq_opaque(lane);
           const int hsel = lane_x & 1, k2 = lane_x >> 1;
@@ -465,12 +444,37 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
         const u32x4 hwa[1] = {hw};
         float t1[1][8];
         fwht128_h_n<1>(hwa, t1, 1, lg);
-        u32x4 y1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) y1[k] = mul2_to_h2(t1[0][2 * k], t1[0][2 * k + 1], r.c_h);
-        uint32_t m1[1] = {vec_absmax16(y1)};
-        row_max_dpp16_n<1>(m1, 1);
-        const RowScale16 s1 = row_scale16(m1[0], a.fpos.gmax, a.inv_gpos);
+        m1 = vec_absmax16(y1);
+      }
+      RowScale16 s, s1;
+      if constexpr (TOKEN) {
+        m = row_max_dpp<64>(m > m1 ? m : m1);   // fp6_quant_*_per_token_cuda on the rotated row: one scale for the whole row
+        s = s1 = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+        if (r.code_scales && lane == 0) r.code_scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
+      } else {
+        auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+        m = sw[0] > sw[1] ? sw[0] : sw[1];
+        sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+        m = sw[0] > sw[1] ? sw[0] : sw[1];
+        s = s1 = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+        if constexpr (MAXC == 5) {
+          uint32_t ms[1] = {m1};
+          row_max_dpp16_n<1>(ms, 1);
+          s1 = row_scale16(ms[0], a.fpos.gmax, a.inv_gpos);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+          const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+          yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
+        }
+      rq_store_tile(buf, yw, rq_rsrc(out + row * vpr, vpr * 16), lane);
+      if constexpr (MAXC == 5) {
         const u32x4 o1 = quant_vec16<false>(y1, lut, a.shift, s1.inv, s1.inv_lo, s1.s16x2, 0.f, 0.f, 0u);
         if (last_live) {
           const int64_t at = row * vpr + v;

@@ -1003,11 +1003,11 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
       const dim3 g2((unsigned)(n_batches * per_batch));
       const size_t lds2 = 0;   // table and modulation planes live in static LDS
-      // value output: the rotation runs on the matrix cores (rows of 17 .. 20 groups: the first 16 of them, per-group scales only)
+      // value output: the rotation runs on the matrix cores (rows of 17 .. 20 groups: the first 16 of them)
       static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
-    if constexpr (!(CODES) && ((M) <= 4 || !(TOKEN))) {                                                                \
+    if constexpr (!(CODES)) {                                                                                          \
       if (!adaln_butterfly) {                                                                                          \
         hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, true, X32>), g2, dim3(kBlock), lds2, st,    \
                            (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,       \
