@@ -120,7 +120,8 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  static_assert(!MFMA || (!CODES && MAXC <= 5), "matrix-core rotation: value output, rows of at most 20 groups");
+  static_assert(!MFMA || (!(CODES && TOKEN) && MAXC <= 5),
+                "matrix-core rotation: values or FP4 codes with a scale per group, values with a scale per token; rows of at most 20 groups");
   u32x4* buf = nullptr;           // MFMA: this wavefront's operand / output image
   HadOperand ha = {};
   if constexpr (MFMA) {
@@ -465,6 +466,18 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
           s1 = row_scale16(ms[0], a.fpos.gmax, a.inv_gpos);
         }
       }
+      if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
+        rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
+                       rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
+        if constexpr (MAXC == 5) {
+          const uint32_t cd = codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
+          if (last_live) {
+            const int64_t at = row * vpr + v;
+            ((uint32_t*)out)[at] = cd;
+            if (lg == 0) r.code_scales[at >> 4] = (uint16_t)(s1.s16x2 & 0xFFFFu);
+          }
+        }
+      } else {
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -474,7 +487,8 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
           yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
         }
       rq_store_tile(buf, yw, rq_rsrc(out + row * vpr, vpr * 16), lane);
-      if constexpr (MAXC == 5) {
+      }
+      if constexpr (MAXC == 5 && !CODES) {
         const u32x4 o1 = quant_vec16<false>(y1, lut, a.shift, s1.inv, s1.inv_lo, s1.s16x2, 0.f, 0.f, 0u);
         if (last_live) {
           const int64_t at = row * vpr + v;

@@ -943,17 +943,18 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   const dim3 grid(grid_for(tiles, 1 << 20));
   // values out: the transform on the matrix cores (fpq_rotate_mfma.h), one 32-group tile per wavefront
   static const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
-  if (!code_scales && !butterfly) {
+  if (!butterfly) {
     // persistent wavefronts, every workgroup the same number of passes (FPQ_ROT_WAVES workgroups per CU are resident; twice as many shorter ones measured 2 % faster: 84.2 vs 85.9 us)
     const int64_t per_wg = (int64_t)(kBlock / 64) * kRqTileVec;
     const int64_t wg_tiles = (n_vec + per_wg - 1) / per_wg;
     static const int64_t resident = [] { const char* e = getenv("FPQ_ROT_WGS"); return e ? atoll(e) : 2 * 256ll * FPQ_ROT_WAVES; }();
     const int64_t passes = (wg_tiles + resident - 1) / resident;
     const dim3 mgrid((unsigned)((wg_tiles + passes - 1) / passes));
-#define FPQ_ROT_MFMA(EMIT, SMOOTH)                                                                                  \
-  hipLaunchKernelGGL((rotate_quant_mfma_kernel<Tin, EMIT, SMOOTH>), mgrid, dim3(kBlock), lds, st, x, (u32x4*)out, \
-                     (u32x4*)rot_out, n_vec, r, h.args, tab)
-    if (rot_out) { if (smooth) FPQ_ROT_MFMA(true, true); else FPQ_ROT_MFMA(true, false); }
+#define FPQ_ROT_MFMA(EMIT, SMOOTH, ...)                                                                             \
+  hipLaunchKernelGGL((rotate_quant_mfma_kernel<Tin, EMIT, SMOOTH, ##__VA_ARGS__>), mgrid, dim3(kBlock), lds, st, x, \
+                     (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, tab)
+    if (code_scales) { if (smooth) FPQ_ROT_MFMA(false, true, true); else FPQ_ROT_MFMA(false, false, true); }
+    else if (rot_out) { if (smooth) FPQ_ROT_MFMA(true, true); else FPQ_ROT_MFMA(true, false); }
     else { if (smooth) FPQ_ROT_MFMA(false, true); else FPQ_ROT_MFMA(false, false); }
 #undef FPQ_ROT_MFMA
     return check_launch();
@@ -1007,7 +1008,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
-    if constexpr (!(CODES)) {                                                                                          \
+    if constexpr (!((CODES) && (TOKEN))) {                                                                             \
       if (!adaln_butterfly) {                                                                                          \
         hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, true, X32>), g2, dim3(kBlock), lds2, st,    \
                            (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,       \

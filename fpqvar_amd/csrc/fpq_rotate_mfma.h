@@ -169,11 +169,46 @@ __device__ __forceinline__ uint32_t rq_lut_pair(const uint16_t* lut, uint32_t u,
   return __builtin_bit_cast(uint32_t, q);
 }
 
+// FP4 operand output (fpq_gemm_fp4.h: E2M1 nibbles, low nibble first, + one fp16 scale per group) from the lane's 16
+// rotated words.  `lut` holds the code table.  A lane's eight 4-element pieces are 16 bits each and belong at bytes
+// 8 c + 2 quarter of its group's 64: 2-byte LDS writes (dword index xor-swizzled with bits 2, 3 of the group: the 64
+// lanes of a write hit 32 different dwords, two lanes each), then every lane reads 16 bytes = chunk lane % 4 of group
+// lane / 4 and the tile's 1 KiB of codes leaves as ONE coalesced store per lane; lanes 0 .. 15 store the scales.
+__device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[8][2], const RowScale16& s,
+                                               const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t codes_dst,
+                                               __amdgpu_buffer_rsrc_t scales_dst, int lane) {
+  lane = rq_opaque(lane);
+  const int g = lane & 15, quarter = lane >> 4;
+  const int swz = ((g >> 2) & 3) << 2;
+  uint16_t* b16 = (uint16_t*)buf;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t w[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+      const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+      w[rr] = rq_lut_pair(lut, u, shift);                      // two codes: bits 0 .. 3 and 16 .. 19
+    }
+    const uint32_t piece = (w[0] & 0xFu) | ((w[0] >> 12) & 0xF0u) | ((w[1] & 0xFu) << 8) | ((w[1] >> 4) & 0xF000u);
+    b16[g * 32 + (((2 * c + (quarter >> 1)) ^ swz) << 1) + (quarter & 1)] = (uint16_t)piece;
+  }
+  __builtin_amdgcn_wave_barrier();
+  lane = rq_opaque(lane);
+  const int gg = lane >> 2, j = lane & 3;
+  const u32x4 o = buf[gg * 4 + (j ^ ((gg >> 2) & 3))];
+  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, lane * 16, 0, kRqNt);
+  if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
+  __builtin_amdgcn_wave_barrier();
+}
+
 #ifndef FPQ_ROT_WAVES
 #define FPQ_ROT_WAVES 6
 #endif
 
-template <typename Tin, bool EMIT, bool SMOOTH>
+// CODES: `out` receives packed E2M1 codes (4 bytes per 8 elements), r.code_scales one fp16 scale per group; the staged
+// table is the code table
+template <typename Tin, bool EMIT, bool SMOOTH, bool CODES = false>
 __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kernel(const void* __restrict__ xv,
                                                                                  u32x4* __restrict__ out,
                                                                                  u32x4* __restrict__ rot_out,
@@ -284,16 +319,21 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
       m = sw[0] > sw[1] ? sw[0] : sw[1];
     }
     const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+    if constexpr (CODES) {
+      rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + base_vec, rem * 4),
+                     rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), lane);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+      for (int c = 0; c < 8; ++c)
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
-        const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
-        yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
-      }
-    // 5.
-    rq_store_tile(buf, yw, rq_rsrc(out + base_vec, rem * 16), lane);
+        for (int rr = 0; rr < 2; ++rr) {
+          const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+          const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+          yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
+        }
+      // 5.
+      rq_store_tile(buf, yw, rq_rsrc(out + base_vec, rem * 16), lane);
+    }
   };
   if (tile < n_tiles) {
     pass();

@@ -56,6 +56,7 @@ def main():
     cases["sym_e2m1_g128_f16"] = lambda: ops.quant_rows(x16(), "e2m1", 128)
     cases["sym_e2m3_token_f16_1920"] = lambda: ops.quant_rows(x16(), "e2m3", C, torch.float16)
     cases["rotate_quant_e2m1"] = lambda: rot.rotate_quant(x16(), "e2m1")
+    cases["rotate_quant_mx"] = lambda: rot.rotate_quant_mx(x16())
     B, L = 100, 655
     scale = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
     shift = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
