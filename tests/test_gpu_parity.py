@@ -1186,6 +1186,28 @@ def test_fused_producers_emit_fp4_operands(dev, x_dtype):
     assert not cz.any() and not sz.any()
 
 
+@pytest.mark.parametrize("rows,C", ((1, 128), (17, 384), (33, 2048), (257, 1152), (300, 2304), (64, 2560)))
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+def test_fp4_operand_output_shapes(dev, rows, C, x_dtype):
+    """The code-emitting forms over ragged tiles and rows of 1 .. 20 groups (17 .. 20: tile + one chunk per lane):
+    level(code) * scale equals the value-emitting kernels bit for bit, scales equal the groups' scales."""
+    from fpqvar_amd import gemm, rotation as rot
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * torch.exp(0.4 * torch.randn(rows, C, generator=g))).to(x_dtype).to(dev)
+    x[0, :128] = 0
+    want = rot.rotate_quant(x, "e2m1")
+    codes, scales = rot.rotate_quant_mx(x)
+    assert codes.shape == (rows, C // 2) and scales.shape == (rows, C // 128)
+    assert_bits_equal(gemm.dequantize_mx(codes, scales).half(), want, "rotate_quant_mx decode")
+    B = 3 if rows % 3 == 0 else 1
+    xa = x.view(B, rows // B, C)
+    scale = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    shift = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    want = rot.adaln_rotate_quant(xa, scale, shift, "e2m1")
+    codes, scales = rot.adaln_rotate_quant_mx(xa, scale, shift)
+    assert_bits_equal(gemm.dequantize_mx(codes, scales).half().view_as(want), want, "adaln_rotate_quant_mx decode")
+
+
 def test_quantize_var_real_fp4(dev):
     """quantize_VAR(..., real_fp4=True): fc1 / mat_qkv / proj become FP4Linear, fc2 keeps its dual-format fake quant;
     outputs agree with the default (fake-quant + fp16 GEMM) model to GEMM tolerance."""
