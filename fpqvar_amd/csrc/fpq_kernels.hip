@@ -26,6 +26,9 @@
 //     for xn < 0.  tests/ prove it equal to the scan on every fp16 input and on fp32
 //     neighbourhoods of every midpoint; fpq_quant_nearest keeps the literal scan.
 #include "fpq_common.h"
+// experiment switches ("Experiment switches"): read from the environment once per process (FPQ_NO_FAST32
+// at every call: tests/test_gpu_configs.py flips it to compare the two paths in one process)
+#define FPQ_ENV(name) ([] { static const char* const v = getenv(name); return v; }())
 
 namespace {
 
@@ -942,12 +945,12 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   const dim3 grid(grid_for(tiles, 1 << 20));
   // values out: the transform on the matrix cores (fpq_rotate_mfma.h), one 32-group tile per wavefront
-  static const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
+  static const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
   if (!butterfly) {
     // persistent wavefronts, every workgroup the same number of passes (FPQ_ROT_WAVES workgroups per CU are resident; twice as many shorter ones measured 2 % faster: 84.2 vs 85.9 us)
     const int64_t per_wg = (int64_t)(kBlock / 64) * kRqTileVec;
     const int64_t wg_tiles = (n_vec + per_wg - 1) / per_wg;
-    static const int64_t resident = [] { const char* e = getenv("FPQ_ROT_WGS"); return e ? atoll(e) : 2 * 256ll * FPQ_ROT_WAVES; }();
+    static const int64_t resident = [] { const char* e = FPQ_ENV("FPQ_ROT_WGS"); return e ? atoll(e) : 2 * 256ll * FPQ_ROT_WAVES; }();
     const int64_t passes = (wg_tiles + resident - 1) / resident;
     const dim3 mgrid((unsigned)((wg_tiles + passes - 1) / passes));
 #define FPQ_ROT_MFMA(EMIT, SMOOTH, ...)                                                                             \
@@ -991,8 +994,8 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   {
     // second generation (fpq_adaln.h): fp16 or fp32 rows of up to 2560 channels, one batch entry per workgroup
     constexpr bool X32 = sizeof(Tin) == 4;
-    if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !getenv("FPQ_ADALN_V1")) {
-      const char* rows_env = getenv("FPQ_ADALN_ROWS");
+    if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !FPQ_ENV("FPQ_ADALN_V1")) {
+      const char* rows_env = FPQ_ENV("FPQ_ADALN_ROWS");
       // 16 rows per workgroup amortise the staging of the modulation planes; small launches (the early scale steps of a
       // generation: 100 .. 3600 rows) are latency-bound instead and want every CU busy: 4 rows = one per wavefront
       // (measured as one graph-replayed call, profiles/r02_small_steps.json: 900 rows 10.1 -> 5.9 us)
@@ -1005,7 +1008,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       const dim3 g2((unsigned)(n_batches * per_batch));
       const size_t lds2 = 0;   // table and modulation planes live in static LDS
       // value output: the rotation runs on the matrix cores (rows of 17 .. 20 groups: the first 16 of them)
-      static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || getenv("FPQ_ROT_BUTTERFLY") != nullptr;
+      static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
     if constexpr (!((CODES) && (TOKEN))) {                                                                             \
@@ -1044,7 +1047,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   }
   const int64_t rows_per_wg = kBlock / lanes_per_row;
   int64_t g64 = (rows + rows_per_wg - 1) / rows_per_wg;
-  const char* cap_env = getenv("FPQ_ADALN_GRID");
+  const char* cap_env = FPQ_ENV("FPQ_ADALN_GRID");
   const int64_t cap = cap_env ? atoll(cap_env) : 8192;   // every workgroup stages the table once, then walks rows
   if (g64 > cap) g64 = cap;
   const dim3 g((unsigned)g64);
@@ -1112,7 +1115,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   args.nan_flag = nan_flag;
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t vec_per_row = cols / 8;
-  if (vec_per_row <= 64 * 5 && !getenv("FPQ_NO_WAVE_ROWS")) {
+  if (vec_per_row <= 64 * 5 && !FPQ_ENV("FPQ_NO_WAVE_ROWS")) {
     // one wavefront per row: 4 rows per workgroup pass, enough workgroups to keep every CU busy while the
     // table staging stays amortised
     const int mc = (int)((vec_per_row + 63) / 64);
@@ -1137,7 +1140,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   int64_t rpb = (rows + target_wgs - 1) / target_wgs;
   if (rpb < 1) rpb = 1;
   if (h.tab_valid && (1 << (16 - h.args.shift)) > 1024) {   // 2 x 1024 buckets to stage: a few rows per workgroup
-    const char* e = getenv("FPQ_BIGTAB_RPB");
+    const char* e = FPQ_ENV("FPQ_BIGTAB_RPB");
     rpb = e ? atoll(e) : 2;
     if (rpb < 1) rpb = 1;
   }
@@ -1533,8 +1536,8 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
     if ((1 << (16 - lut16_host(neg_table, pos_table).args.shift)) <= 1024)
       rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag);
     else {
-      const char* eu = getenv("FPQ_BIGTAB_U");
-      const char* ec = getenv("FPQ_BIGTAB_CAP");
+      const char* eu = FPQ_ENV("FPQ_BIGTAB_U");
+      const char* ec = FPQ_ENV("FPQ_BIGTAB_CAP");
       const int cap = ec ? atoi(ec) : 16384;   // measured on [65536 x 7680]: 4096 -> 366 us, 16384 -> 348 us, full grid -> 367 us
       if (eu && atoi(eu) == 8) rc = launch_fast16<true, 8>(x, out, rows, cols, neg_table, pos_table, st, cap, flag);
       else rc = launch_fast16<true, 4>(x, out, rows, cols, neg_table, pos_table, st, cap, flag);
@@ -1638,7 +1641,7 @@ static int adaln_rotate_quant_impl(const void* x, void* out, void* h_out, void* 
   // One wavefront per row while the row fits 5 vectors per lane (C <= 2560: no barrier in the row
   // loop; measured 0.180 ms vs 0.199 ms per [65500 x 1920] on MI355X), one workgroup per row beyond.
   // FPQ_ADALN_LANES / FPQ_ADALN_GRID override the choice for experiments.
-  const char* env = getenv("FPQ_ADALN_LANES");
+  const char* env = FPQ_ENV("FPQ_ADALN_LANES");
   const int lanes = (env && !token_mode) ? atoi(env) : (cols / 8 <= 64 * 5 ? 64 : 256);
   const int lpr = (lanes == 64) ? 64 : 256;
   if (token_mode && lpr != 64) return FPQ_ERR_SHAPE;   // the per-token form keeps a row inside one wavefront: C <= 2560
