@@ -143,7 +143,14 @@ def dtype_id(dt: torch.dtype) -> int:
         raise RuntimeError(f"fpqvar_amd: unsupported dtype {dt}") from None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device` (the raw accessor skips building a Stream object: ~1.5 us
+    of the ~10 us a small eager call spends on the host)."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 

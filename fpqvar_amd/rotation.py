@@ -197,8 +197,8 @@ def _mask_arg(d: Optional[torch.Tensor]):
     global _DEFAULT_MASK
     if d is None:
         if _DEFAULT_MASK is None:
-            _DEFAULT_MASK = tuple(sign_mask(sign_vector(128, 42)))
-        return (ctypes.c_uint32 * 4)(*_DEFAULT_MASK)
+            _DEFAULT_MASK = (ctypes.c_uint32 * 4)(*sign_mask(sign_vector(128, 42)))   # read-only to the library: shared
+        return _DEFAULT_MASK
     return (ctypes.c_uint32 * 4)(*sign_mask(d.cpu()))
 
 
@@ -216,14 +216,7 @@ def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor]
         raise RuntimeError("rotate_quant: the last dimension must be a multiple of 128")
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
-    sm_ptr = None
-    if smooth is not None:
-        sm = smooth.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
-        if sm.numel() == 1:
-            sm = sm.expand(c).contiguous()
-        if sm.numel() != c:
-            raise RuntimeError("rotate_quant: smooth must have one entry per channel")
-        sm_ptr = sm.data_ptr()
+    sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
     rot = torch.empty_like(out) if return_rotated else None
     with device_guard(x.device):
@@ -233,9 +226,19 @@ def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor]
     return (out, rot) if return_rotated else out
 
 
+def _mod_rows(t: torch.Tensor, bsz: int, c: int) -> torch.Tensor:
+    """[B, 1, C] / [B, C] modulation tensor as B contiguous rows (no tensor op when it already is)."""
+    if t.is_contiguous() and t.numel() == bsz * c:
+        return t
+    return t.reshape(bsz, c).contiguous()
+
+
 def _smooth_ptr(smooth, c, device):
     if smooth is None:
         return None, None
+    if smooth.dtype is torch.float32 and smooth.dim() == 1 and smooth.shape[0] == c and smooth.device == device \
+            and smooth.is_contiguous():
+        return smooth, smooth.data_ptr()          # the usual case: no tensor ops on the host path
     sm = smooth.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
     if sm.numel() == 1:
         sm = sm.expand(c).contiguous()
@@ -276,8 +279,8 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
         raise RuntimeError("adaln_rotate_quant_mx: C must be a multiple of 128 and at most 4096")
     if scale.dtype != shift.dtype or scale.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("adaln_rotate_quant_mx: scale and shift must both be float16 or both float32")
-    sc = scale.reshape(bsz, c).contiguous()
-    sh = shift.reshape(bsz, c).contiguous()
+    sc = _mod_rows(scale, bsz, c)
+    sh = _mod_rows(shift, bsz, c)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
@@ -306,8 +309,8 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
         raise RuntimeError("adaln_rotate_quant_token: C must be a multiple of 128 and at most 2560")
     if scale.dtype != shift.dtype or scale.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("adaln_rotate_quant_token: scale and shift must both be float16 or both float32")
-    sc = scale.reshape(bsz, c).contiguous()
-    sh = shift.reshape(bsz, c).contiguous()
+    sc = _mod_rows(scale, bsz, c)
+    sh = _mod_rows(shift, bsz, c)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
@@ -350,16 +353,11 @@ def adaln_rotate_quant(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor
         raise RuntimeError("adaln_rotate_quant: C must be a multiple of 128 and at most 4096")
     if scale.dtype != shift.dtype or scale.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("adaln_rotate_quant: scale and shift must both be float16 or both float32")
-    sc = scale.reshape(bsz, c).contiguous()
-    sh = shift.reshape(bsz, c).contiguous()
+    sc = _mod_rows(scale, bsz, c)
+    sh = _mod_rows(shift, bsz, c)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
-    sm_ptr, sm = None, None
-    if smooth is not None:
-        sm = smooth.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
-        if sm.numel() == 1:
-            sm = sm.expand(c).contiguous()
-        sm_ptr = sm.data_ptr()
+    sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
     h = torch.empty_like(out) if return_intermediates else None
     y = torch.empty_like(out) if return_intermediates else None
