@@ -120,8 +120,8 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  static_assert(!MFMA || (!(CODES && TOKEN) && MAXC <= 5),
-                "matrix-core rotation: values or FP4 codes with a scale per group, values with a scale per token; rows of at most 20 groups");
+  static_assert(!MFMA || (MAXC <= 5 && !(CODES && TOKEN && MAXC == 5)),
+                "matrix-core rotation: rows of at most 20 groups, per-token operand output of at most 16");
   u32x4* buf = nullptr;           // MFMA: this wavefront's operand / output image
   HadOperand ha = {};
   if constexpr (MFMA) {
@@ -466,7 +466,10 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
           s1 = row_scale16(ms[0], a.fpos.gmax, a.inv_gpos);
         }
       }
-      if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
+      if constexpr (CODES && TOKEN) {   // per-token operands: E4M3 bytes or dense 6-bit codes, the row scale is out already
+        if (r.code_bits == 6) rq_store_codes6(buf, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 6), vpr * 6), lane);
+        else rq_store_codes8(buf, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 8), vpr * 8), lane);
+      } else if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
         rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
                        rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
         if constexpr (MAXC == 5) {

@@ -202,6 +202,68 @@ __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[
   __builtin_amdgcn_wave_barrier();
 }
 
+// Per-token operand outputs of the adaLN producer (one scale per row, fpq_gemm_fp8.h / fpq_gemm_fp6.h): `lut` holds the
+// code table, `s` the row's scale.  E4M3 bytes: a lane's eight pieces are one dword each, at dword 4 c + quarter of its
+// group's 32 (index xor-swizzled with bits 1 .. 3 of the group: 64 lanes, 64 banks); the tile's 2 KiB leave as two
+// 16-byte stores per lane.
+__device__ __forceinline__ void rq_store_codes8(u32x4* buf, const uint32_t (&yw)[8][2], const RowScale16& s,
+                                                const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t dst, int lane) {
+  lane = rq_opaque(lane);
+  const int g = lane & 15, quarter = lane >> 4;
+  const int swz = ((g >> 1) & 7) << 2;
+  uint32_t* b32 = (uint32_t*)buf;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t w[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+      const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+      w[rr] = rq_lut_pair(lut, u, shift);                      // two code bytes: bits 0 .. 7 and 16 .. 23
+    }
+    b32[g * 32 + ((4 * c + quarter) ^ swz)] = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u);
+  }
+  __builtin_amdgcn_wave_barrier();
+  lane = rq_opaque(lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = i * 64 + lane, gg = n >> 3, j = n & 7;
+    const u32x4 o = buf[gg * 8 + (j ^ ((gg >> 1) & 7))];
+    __builtin_amdgcn_raw_buffer_store_b128(o, dst, lane * 16 + i * 1024, 0, kRqNt);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Dense 6-bit codes (E2M3): a piece is 24 bits at byte 12 c + 3 quarter of its group's 96: one 2-byte and one 1-byte LDS
+// write, in the order the address parity asks for; the tile's 1.5 KiB leave as 16-byte stores (lanes 0 .. 31 two).
+__device__ __forceinline__ void rq_store_codes6(u32x4* buf, const uint32_t (&yw)[8][2], const RowScale16& s,
+                                                const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t dst, int lane) {
+  lane = rq_opaque(lane);
+  const int g = lane & 15, quarter = lane >> 4;
+  const bool odd = (quarter & 1) != 0;
+  uint8_t* b8 = (uint8_t*)buf;
+  const int base = g * 96 + 3 * quarter;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t w[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+      const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+      w[rr] = rq_lut_pair(lut, u, shift);                      // two 6-bit codes: bits 0 .. 5 and 16 .. 21
+    }
+    const uint32_t p24 = (w[0] & 0x3Fu) | ((w[0] >> 10) & 0xFC0u) | ((w[1] & 0x3Fu) << 12) | ((w[1] >> 16 & 0x3Fu) << 18);
+    const int at = base + 12 * c;                               // odd quarters sit at odd addresses
+    b8[odd ? at : at + 2] = (uint8_t)(odd ? p24 : p24 >> 16);
+    *(uint16_t*)(b8 + (odd ? at + 1 : at)) = (uint16_t)(odd ? p24 >> 8 : p24);
+  }
+  __builtin_amdgcn_wave_barrier();
+  lane = rq_opaque(lane);
+  __builtin_amdgcn_raw_buffer_store_b128(buf[lane], dst, lane * 16, 0, kRqNt);
+  if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(buf[64 + lane], dst, lane * 16 + 1024, 0, kRqNt);
+  __builtin_amdgcn_wave_barrier();
+}
+
 #ifndef FPQ_ROT_WAVES
 #define FPQ_ROT_WAVES 6
 #endif

@@ -62,6 +62,8 @@ def main():
     shift = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
     s = torch.rand(C, device=dev, generator=g) + 0.5
     cases["adaln_rotate_quant"] = lambda: rot.adaln_rotate_quant(x16()[:B * L].view(B, L, C), scale, shift, "e2m1", smooth=s)
+    cases["adaln_token_fp8"] = lambda: rot.adaln_rotate_quant_token(x16()[:B * L].view(B, L, C), scale, shift, "e2m3", smooth=s, emit="fp8")
+    cases["adaln_token_fp6"] = lambda: rot.adaln_rotate_quant_token(x16()[:B * L].view(B, L, C), scale, shift, "e2m3", smooth=s, emit="fp6")
     cases["adaln_token_e2m3"] = lambda: rot.adaln_rotate_quant_token(x16()[:B * L].view(B, L, C), scale, shift, "e2m3", smooth=s)
     x32r = None
 
