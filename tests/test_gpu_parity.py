@@ -1488,6 +1488,27 @@ def test_adaln_rotate_quant_per_token(dev, C, x_dtype):
                                      torch.zeros(1, 1, 4096, device=dev).half())
 
 
+@pytest.mark.parametrize("C", (128, 640, 1024, 2048))
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+def test_per_token_operand_output_widths(dev, C, x_dtype):
+    """E4M3-byte and dense 6-bit operand output of the producer at rows of 1 .. 16 groups (one row = one tile; 5 groups:
+    a row of 480 code bytes that is not a multiple of the 16-byte stores' reach within the tile image)."""
+    from fpqvar_amd import gemm, rotation as rot
+    g = torch.Generator().manual_seed(C + 1)
+    B, L = 3, 19
+    x = (torch.randn(B, L, C, generator=g) * 2 + 0.3).to(x_dtype).to(dev)
+    scale = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    shift = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    _, _, y = rot.adaln_rotate_quant(x, scale, shift, "e2m1", return_intermediates=True)
+    for table in ("e2m3", "e3m2"):
+        codes, scales = rot.adaln_rotate_quant_token(x, scale, shift, table, emit="fp8")
+        c2, s2 = gemm.quantize_fp8(y.reshape(B * L, C), table)
+        assert torch.equal(scales, s2) and torch.equal(codes, c2), f"fp8 operands, {table}"
+    codes6, scales6 = rot.adaln_rotate_quant_token(x, scale, shift, "e2m3", emit="fp6")
+    c6, s6 = gemm.quantize_fp6(y.reshape(B * L, C))
+    assert codes6.shape == (B * L, C * 3 // 4) and torch.equal(scales6, s6) and torch.equal(codes6, c6), "fp6 operands"
+
+
 def test_rccl_single_rank_group_paths(dev):
     """The collectives the multi-GPU paths use (barrier, all_reduce MAX, all_gather), on a one-rank RCCL group: the
     8-GPU runs are the driver's, this only checks that the nccl backend initialises and the code paths execute here."""
