@@ -892,7 +892,10 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
 // Defaults measured on MI355X with tools/kbench (cold HBM, 4 rotating 252 MB buffer pairs):
 // U = 2 with non-temporal loads and stores matches the best plain copy (78 us for
 // fp16 [65536x1920] = 6.45 TB/s); grid-stride with a capped grid or U = 8 lose 3-8 %.
-template <bool DUAL, int U = 2, bool NTL = true, bool NTS = true>
+#ifndef FPQ_FAST16_U   // vectors per lane of the sub-wavefront row kernels (A/B builds)
+#define FPQ_FAST16_U 2
+#endif
+template <bool DUAL, int U = FPQ_FAST16_U, bool NTL = true, bool NTS = true>
 int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id, hipStream_t st,
                   int grid_cap = 1 << 20, uint32_t* nan_flag = nullptr) {
   const Lut16Host& h = lut16_host(neg_id, pos_id);
