@@ -120,8 +120,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  static_assert(!MFMA || (MAXC <= 5 && !(CODES && TOKEN && MAXC == 5)),
-                "matrix-core rotation: rows of at most 20 groups, per-token operand output of at most 16");
+  static_assert(!MFMA || MAXC <= 5, "matrix-core rotation: rows of at most 20 groups");
   u32x4* buf = nullptr;           // MFMA: this wavefront's operand / output image
   HadOperand ha = {};
   if constexpr (MFMA) {
@@ -320,6 +319,39 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
     rstd = __builtin_fmaf(rstd * __builtin_fmaf(-ve * rstd, rstd, 1.0f), 0.5f, rstd);
     const float nm = -mean * rstd;
 
+    // per-token operand output of ONE chunk per lane (the butterfly forms, and groups 16 .. 19 of the hybrid): E4M3 bytes
+    // of the levels (fpq_gemm_fp8.h), 8 per vector, or dense 6-bit codes (fpq_gemm_fp6.h)
+    auto token_codes_out = [&](int c, const u32x4& yv, const RowScale16& s, int v) {
+        uint32_t cb[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t wk = yv[k];
+          const uint32_t rb = div_pair16(wk, s.inv, s.inv_lo, s.inv, s.inv_lo);
+          const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+          cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
+          cb[2 * k + 1] = lut[u >> (16 + a.shift)];
+        }
+        if (r.code_bits == 6) {
+          // 8 six-bit codes = 48 bits per lane, rows packed densely: the four lanes of a quad own 24 contiguous
+          // bytes; lane q of the quad takes the (3 - q) upper 16-bit words of its own string and the q + 1 lower
+          // words of its right neighbour's, so that lanes 0..2 each store 8 aligned bytes (cols % 32 == 0: a quad
+          // is live or dead as a whole).
+          const uint64_t own = (uint64_t)(cb[0] | (cb[1] << 6) | (cb[2] << 12) | (cb[3] << 18)) |
+                               ((uint64_t)(cb[4] | (cb[5] << 6) | (cb[6] << 12) | (cb[7] << 18)) << 24);
+          const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)own, 0xF9, 0xF, 0xF, false);   // quad_perm [1,2,3,3]
+          const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(own >> 32), 0xF9, 0xF, 0xF, false);
+          const uint64_t nb = ((uint64_t)nhi << 32) | nlo;
+          const int qp = lane & 3, sr = 16 * qp;
+          const uint64_t w = (own >> sr) | (nb << (48 - sr));
+          if (qp < 3) {
+            uint8_t* dst = (uint8_t*)out + row * ((int64_t)vpr * 6) + (int64_t)c * (64 * 6) + 24 * (lane >> 2) + 8 * qp;
+            __builtin_nontemporal_store(u32x2{(uint32_t)w, (uint32_t)(w >> 32)}, (u32x2*)dst);
+          }
+        } else {
+          const u32x2 o2 = {cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24), cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24)};
+          __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
+        }
+    };
     if constexpr (X32) {
       // ---- fp32 rows: modulate this lane's half-chunks, 8 bytes of fp16 each, into LDS ----
       const int lane_x = rq_opaque(lane);
@@ -469,6 +501,9 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
       if constexpr (CODES && TOKEN) {   // per-token operands: E4M3 bytes or dense 6-bit codes, the row scale is out already
         if (r.code_bits == 6) rq_store_codes6(buf, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 6), vpr * 6), lane);
         else rq_store_codes8(buf, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 8), vpr * 8), lane);
+        if constexpr (MAXC == 5) {
+          if (last_live) token_codes_out(4, y1, s1, v);
+        }
       } else if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
         rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
                        rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
@@ -595,36 +630,8 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
       for (int c = 0; c < MAXC; ++c) {
         if (c == MAXC - 1 && !last_live) continue;
         const int v = vidx[c];
-        if constexpr (CODES) {   // E4M3 bytes of the levels (fpq_gemm_fp8.h), 8 per vector, or dense 6-bit codes
-          uint32_t cb[8];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t wk = ys[c][k];
-            const uint32_t rb = div_pair16(wk, s.inv, s.inv_lo, s.inv, s.inv_lo);
-            const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
-            cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
-            cb[2 * k + 1] = lut[u >> (16 + a.shift)];
-          }
-          if (r.code_bits == 6) {
-            // 8 six-bit codes = 48 bits per lane, rows packed densely: the four lanes of a quad own 24 contiguous
-            // bytes; lane q of the quad takes the (3 - q) upper 16-bit words of its own string and the q + 1 lower
-            // words of its right neighbour's, so that lanes 0..2 each store 8 aligned bytes (cols % 32 == 0: a quad
-            // is live or dead as a whole).
-            const uint64_t own = (uint64_t)(cb[0] | (cb[1] << 6) | (cb[2] << 12) | (cb[3] << 18)) |
-                                 ((uint64_t)(cb[4] | (cb[5] << 6) | (cb[6] << 12) | (cb[7] << 18)) << 24);
-            const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)own, 0xF9, 0xF, 0xF, false);   // quad_perm [1,2,3,3]
-            const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(own >> 32), 0xF9, 0xF, 0xF, false);
-            const uint64_t nb = ((uint64_t)nhi << 32) | nlo;
-            const int qp = lane & 3, sr = 16 * qp;
-            const uint64_t w = (own >> sr) | (nb << (48 - sr));
-            if (qp < 3) {
-              uint8_t* dst = (uint8_t*)out + row * ((int64_t)vpr * 6) + (int64_t)c * (64 * 6) + 24 * (lane >> 2) + 8 * qp;
-              __builtin_nontemporal_store(u32x2{(uint32_t)w, (uint32_t)(w >> 32)}, (u32x2*)dst);
-            }
-          } else {
-            const u32x2 o2 = {cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24), cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24)};
-            __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
-          }
+        if constexpr (CODES) {
+          token_codes_out(c, ys[c], s, v);
         } else {
           const u32x4 o = quant_vec16<false>(ys[c], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
           __builtin_nontemporal_store(o, out + row * vpr + v);

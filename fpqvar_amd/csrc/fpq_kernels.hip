@@ -1014,7 +1014,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
-    if constexpr (!((CODES) && (TOKEN) && (M) == 5)) {                                                                 \
+    {                                                                                                                  \
       if (!adaln_butterfly) {                                                                                          \
         hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, true, X32>), g2, dim3(kBlock), lds2, st,    \
                            (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,       \
