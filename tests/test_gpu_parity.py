@@ -741,6 +741,40 @@ def test_rotate_butterfly_switch(dev, tmp_path):
     assert_bits_equal(o, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "matrix-core form: quant of rotated")
 
 
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+def test_producers_at_full_size_equal_their_slices(dev, x_dtype):
+    """BASELINE-size launches ([65536 x 1920]: persistent wavefronts, several passes per wavefront, 100 batch entries of 655
+    tokens) against launches on slices of the same tensors: a group's / row's result does not depend on the tile, the
+    pass or the workgroup it was computed in; plus the oracle on rows from both ends and the middle."""
+    from fpqvar_amd import gemm, rotation as rot
+    g = torch.Generator(device=dev).manual_seed(123)
+    R, C = 65536, 1920
+    x = (torch.randn(R, C, device=dev, generator=g) * 1.3).to(x_dtype)
+    out, y = rot.rotate_quant(x, "e2m1", return_rotated=True)
+    assert_bits_equal(rot.rotate_quant(x, "e2m1"), out, "emit vs no-emit at full size")
+    codes, scales = rot.rotate_quant_mx(x)
+    for lo, hi in ((0, 300), (32700, 33111), (R - 257, R)):
+        o_s, y_s = rot.rotate_quant(x[lo:hi].contiguous(), "e2m1", return_rotated=True)
+        assert_bits_equal(out[lo:hi], o_s, f"rotate_quant rows {lo}:{hi}")
+        assert_bits_equal(y[lo:hi], y_s, f"rotated rows {lo}:{hi}")
+        assert_bits_equal(o_s, orc.per_group_kernel_sem(y_s.cpu(), "e2m1", 128), f"oracle rows {lo}:{hi}")
+        assert_bits_equal(gemm.dequantize_mx(codes[lo:hi].contiguous(), scales[lo:hi].contiguous()).half(), o_s, f"codes rows {lo}:{hi}")
+    del out, y, codes, scales
+    B, L = 100, 655
+    xa = x[:B * L].view(B, L, C)
+    scale = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
+    shift = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
+    s = torch.rand(C, device=dev, generator=g) + 0.5
+    full = rot.adaln_rotate_quant(xa, scale, shift, "e2m1", smooth=s)
+    tok = rot.adaln_rotate_quant_token(xa, scale, shift, "e2m3", smooth=s)
+    for b0, b1 in ((0, 2), (49, 51), (98, 100)):
+        part, _, y_p = rot.adaln_rotate_quant(xa[b0:b1].contiguous(), scale[b0:b1].contiguous(), shift[b0:b1].contiguous(), "e2m1",
+                                              smooth=s, return_intermediates=True)
+        assert_bits_equal(full[b0:b1], part, f"adaln entries {b0}:{b1}")
+        assert_bits_equal(part, orc.per_group_kernel_sem(y_p.cpu().reshape(-1, C), "e2m1", 128).view_as(part), f"adaln oracle {b0}:{b1}")
+        assert_bits_equal(tok[b0:b1], orc.per_token_kernel_sem(y_p.cpu(), "e2m3"), f"adaln per token {b0}:{b1}")
+
+
 # ------------------------------------------------------------------ KV cache step and format search
 def test_kv_cache_step(dev):
     from fpqvar_amd import kv_cache as kv
