@@ -681,12 +681,15 @@ def test_rotate_quant_tiles(dev, rows, cols, in_dtype):
         x[5, 130 % cols] = float("inf")
         x[5, 140 % cols] = float("-inf")    # a group with both: outputs are +-inf or NaN
         x[16, cols - 1] = float("-inf")
+        x[9, :128] = 60000.0                   # finite inputs whose rotated output overflows fp16: inf, as the reference's GEMM
+        x[10, :128] = torch.where(torch.arange(128) % 2 == 0, 60000.0, -60000.0).to(x.dtype)
     out, y = rot.rotate_quant(x.to(dev), "e2m1", return_rotated=True)
     assert_bits_equal(rot.rotate_quant(x.to(dev), "e2m1"), out, "emit vs no-emit")
     # the yardstick group by group: in the reference's dense GEMM with the block-diagonal Q (tr/basic_var.py:263) the zero
     # blocks turn one non-finite input into NaN for its whole row (0 * inf); the fused kernels confine it to its group
     q_h = rot.block_random_hadamard_matrix(cols, 128, "cpu", 42).float().half()
     exact = (x.half().view(-1, 128).double() @ q_h[:128, :128].double()).view(rows, cols)
+    exact = torch.where(exact.abs() >= 65520.0, exact.sign() * float("inf"), exact)     # what fp16 cannot hold rounds to inf
     assert torch.equal(torch.isfinite(y.cpu()), torch.isfinite(exact)), "non-finite outputs in other places"
     fin = torch.isfinite(exact)
     # error bound: one fp16 rounding + the fp32 accumulation of 128 terms (visible on cancelling outputs of groups
