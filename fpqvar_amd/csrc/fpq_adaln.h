@@ -117,6 +117,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   constexpr int RV = X32 ? 2 * MAXC : MAXC;      // 16-byte registers of one row per lane
   constexpr bool PREFETCH = X32 ? (FPQ_ADALN_PREFETCH32 != 0) : (FPQ_ADALN_PREFETCH != 0);
   const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
+  FPQ_PHASE("workgroup_prologue");
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   // The row loop below alternates two register sets, so no row is ever copied from register to register.
   auto do_row = [&](u32x4 (&cur)[RV], u32x4 (&nxt)[RV], int i) {
     const int64_t row = row0 + i;
+    FPQ_PHASE("prefetch_next_row");
     if constexpr (PREFETCH) {
       if (i + W < n_here) load_row(nxt, row + W);      // wave-uniform branch
     } else {
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
     // subtraction cancels when |mean| >> sigma: rows with mean^2 >= 64 var (6 of the 24 bits gone; also NaN / Inf
     // rows) take the centred second pass instead - wave-uniform branch, rare.
     // fp32 rows: plain sums, the squares are rounded: the centred pass already when mean^2 >= 8 var.
+    FPQ_PHASE("ln_stats");
     float a1[RV], a2[RV];
 #pragma unroll
     for (int c = 0; c < RV; ++c) a1[c] = a2[c] = 0.0f;
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
       s1 += a1[c];
       s2 += a2[c];
     }
+    FPQ_PHASE("ln_reduce_rstd");
     wave_sum2_dpp(s1, s2);
     const float mean = s1 * inv_c;
     float var = __builtin_fmaf(-mean, mean, s2 * inv_c);
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
           __builtin_nontemporal_store(o2, (u32x2*)out + row * vpr + v);
         }
     };
+    FPQ_PHASE("modulate_to_image");
     if constexpr (X32) {
       // ---- fp32 rows: modulate this lane's half-chunks, 8 bytes of fp16 each, into LDS ----
       const int lane_x = rq_opaque(lane);
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
       if constexpr (EMIT) {
         if (y_out) rq_store_tile(buf, yw, rq_rsrc(y_out + row * vpr, vpr * 16), lane);
       }
+      FPQ_PHASE("group_max_scale");
       uint32_t m = mul2_to_h2(mf, 0.0f, r.c_h) & 0xFFFFu;       // see rotate_quant_mfma_kernel
       if (__builtin_expect((yw[0][0] & 0x7C00u) == 0x7C00u, 0)) {
         m = 0;
@@ -520,11 +526,16 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
       for (int c = 0; c < 8; ++c)
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
+          FPQ_PHASE("quant_divide");
           const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+          FPQ_PHASE("quant_lookup");
           const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
-          yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
+          const uint32_t lv = rq_lut_pair(lut, u, a.shift);
+          FPQ_PHASE("quant_dequant_mul");
+          yw[c][rr] = pk_mul_f16(lv, s.s16x2);
         }
       rq_store_tile(buf, yw, rq_rsrc(out + row * vpr, vpr * 16), lane);
+      FPQ_PHASE("row_end");
       }
       if constexpr (MAXC == 5 && !CODES) {
         const u32x4 o1 = quant_vec16<false>(y1, lut, a.shift, s1.inv, s1.inv_lo, s1.s16x2, 0.f, 0.f, 0u);

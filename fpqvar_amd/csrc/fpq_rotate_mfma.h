@@ -37,6 +37,19 @@ typedef float rq_f4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kRqTileVec = 256;   // 16 groups x 16 vectors of 8 halves per wavefront
 
+// -DFPQ_ISA_CENSUS: phase markers for tools/isa_census.py --phases (a comment line in the assembly between two
+// scheduling barriers, so that every instruction is counted in the phase it belongs to); nothing in a regular build
+#ifdef FPQ_ISA_CENSUS
+#define FPQ_PHASE(name)                        \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    asm volatile("; PHASE " name);             \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+#else
+#define FPQ_PHASE(name) do { } while (0)
+#endif
+
 // The LDS addresses of a phase are lane constants + xor patterns: hoisted out of the tile loop they would pin
 // registers for the sake of a few xors per tile.  An empty asm makes the lane index opaque at the start of a phase.
 __device__ __forceinline__ int rq_opaque(int lane) {
@@ -73,6 +86,7 @@ __device__ __forceinline__ HadOperand had_operand(int lane) {
 // maximum |sum| before the scaling by c_h.
 __device__ __forceinline__ float hadamard128_mfma(const u32x4* buf, const HadOperand& ha, float c_h, int lane,
                                                   uint32_t (&yw)[8][2]) {
+  FPQ_PHASE("mfma");
   lane = rq_opaque(lane);
   const int g = lane & 15, quarter = lane >> 4;
   rq_f4_t acc[2][4];
@@ -88,6 +102,7 @@ __device__ __forceinline__ float hadamard128_mfma(const u32x4* buf, const HadOpe
   // The accumulators' first readers must be instructions the compiler sees (the adds below): its hazard recognizer
   // inserts the wait states a matrix-core result needs before a VALU read, but does not look into inline assembly
   // (a v_fma_mixlo_f16 straight on the accumulators read them two k-steps stale).
+  FPQ_PHASE("butterfly4_max_round");
   float m = 0.0f;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -123,6 +138,7 @@ constexpr int kRqNt = 2;   // cache policy: non-temporal
 // this lane's 16 words (8-byte pieces c) into the output image, then 4 coalesced 16-byte vectors per lane out
 __device__ __forceinline__ void rq_store_tile(u32x4* buf, const uint32_t (&w)[8][2], __amdgpu_buffer_rsrc_t dst,
                                               int lane) {
+  FPQ_PHASE("store_tile");
   lane = rq_opaque(lane);
   const int g = lane & 15, quarter = lane >> 4;
   u32x2* b2 = (u32x2*)buf;

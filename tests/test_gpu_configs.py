@@ -223,6 +223,69 @@ def test_sharded_calibration_object_world1(dev):
     assert all(again[n].data_ptr() == got[n].data_ptr() for n in shapes)
 
 
+def _config4_weights(depth, dev):
+    """Synthetic weights of every quantized Linear of VAR-d<depth> (randn * 0.02, seed 30 k + block; no real
+    checkpoint exists offline), generated on the device - 1.33 G (d30) / 2.29 G (d36) fp32 elements."""
+    from fpqvar_amd import calibrate as cal
+    shapes = cal.var_linear_shapes(depth)
+    kinds = {"attn.mat_qkv": 0, "attn.proj": 1, "ffn.fc1": 2, "ffn.fc2": 3}
+    w = {}
+    for n, s in shapes.items():
+        _, b, a, k = n.split(".")
+        g = torch.Generator(device=dev).manual_seed(depth * kinds[a + "." + k] + int(b))
+        w[n] = torch.randn(*s, device=dev, generator=g) * 0.02
+    return shapes, w
+
+
+def _oracle_slices(name, w, got, n_groups=64):
+    """first / last `n_groups` groups of a layer against the CPU oracle (the reference's fp32 quantization + .half())"""
+    flat, gflat = w.reshape(-1, 128), got.reshape(-1, 128)
+    for sl in (slice(0, n_groups), slice(flat.shape[0] - n_groups, flat.shape[0])):
+        want = orc.per_group_kernel_sem(flat[sl].cpu(), "e2m1", 128).half()
+        assert_bits_equal(gflat[sl], want, f"{name} groups {sl.start}..{sl.stop} vs oracle")
+
+
+@pytest.mark.parametrize("depth", (30, 36))
+def test_config4_one_launch_full_size(dev, depth):
+    """BASELINE config 4 at its real size (tr/quant_utils.py:828-837 via quantize_VAR :1095-1167): all 120 (d30) / 144
+    (d36) Linears in ONE fpq_quant_rows_segments launch - the launch shape bench.py times - bit for bit against one
+    fpq_quant_rows launch per layer on EVERY layer, and against the oracle on the first / last 64 groups of the first,
+    a middle and the last segment."""
+    from fpqvar_amd import calibrate as cal, ops
+    shapes, w = _config4_weights(depth, dev)
+    assert len(w) == 4 * depth
+    sc = cal.ShardedCalibration(shapes, w)
+    assert len(sc.local.names) == 4 * depth and sc.local.total == sum(t.numel() for t in w.values())
+    got = sc.run()
+    torch.cuda.synchronize()
+    names = list(shapes)
+    for n in names:
+        per_layer = ops.quant_rows(w[n], "e2m1", 128, torch.float16)
+        assert got[n].shape == w[n].shape and got[n].dtype == torch.float16
+        same = bool((got[n].view(torch.int16) == per_layer.view(torch.int16)).all())
+        assert same, f"d{depth} {n}: one-launch segment output differs from the per-layer launch"
+    for n in (names[0], names[len(names) // 2], names[len(names) // 2 + 2], names[-1]):
+        _oracle_slices(f"d{depth} {n}", w[n], got[n])
+    # the slab is exactly the layers back to back (world 1): nothing outside the segments was written or skipped
+    assert sc.slab.numel() >= sc.local.total
+    again = sc.run()
+    assert all(again[n].data_ptr() == got[n].data_ptr() for n in names)
+
+
+def test_config4_d30_codes_exchange_full_size(dev):
+    """The packed exchange format of the sharded calibration (nibble codes + one fp32 scale per group, 0.53 B per
+    element) at d30 size: decoded result bit-equal to the one-launch fp16 form on every layer."""
+    from fpqvar_amd import calibrate as cal
+    shapes, w = _config4_weights(30, dev)
+    ref = cal.ShardedCalibration(shapes, w).run()
+    got = cal.calibrate_sharded(w, exchange="codes")
+    assert list(got) == list(shapes)
+    for n in shapes:
+        assert got[n].dtype == torch.float16 and got[n].shape == w[n].shape
+        assert bool((got[n].view(torch.int16) == ref[n].view(torch.int16)).all()), f"codes exchange differs on {n}"
+    _oracle_slices("codes " + list(shapes)[-1], w[list(shapes)[-1]], got[list(shapes)[-1]])
+
+
 @pytest.mark.parametrize("out_dtype", (torch.float16, torch.float32))
 @pytest.mark.parametrize("cols", (1920, 2304, 7680, 9216, 512, 1000, 2048, 2056, 5000 * 2))
 def test_fast32_long_rows_vs_oracle(dev, cols, out_dtype):
