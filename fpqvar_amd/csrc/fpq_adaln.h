@@ -105,8 +105,8 @@ typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 // halves anyway, and the lane's fp16 results (8 bytes) meet their other half in LDS - straight in the matrix-core
 // operand image, or in a row buffer that is read back in the one-chunk-per-lane order of the butterfly forms.  No
 // cross-lane exchange, no second kernel.
-template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false, bool MFMA = false, bool X32 = false>
-__global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_ADALN_X32_WAVES : 1) FPQ_ADALN_OCC void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
+template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN = false, bool X32 = false>
+__global__ __launch_bounds__(kBlock, 1) FPQ_ADALN_OCC void adaln_rq16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                            u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                            int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a, Lut16Tab tab,
                                                            int rows_per_wg, int wgs_per_batch) {
@@ -121,14 +121,8 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   // four planes of vpr x 16 bytes: A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
   // (a lane reads 16 bytes of each plane at 16 * v: consecutive lanes, consecutive banks)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  static_assert(!MFMA || MAXC <= 5, "matrix-core rotation: rows of at most 20 groups");
-  u32x4* buf = nullptr;           // MFMA: this wavefront's operand / output image
-  HadOperand ha = {};
-  if constexpr (MFMA) {
-    __shared__ u32x4 xpose[W][kRqTileVec];
-    buf = xpose[wave];
-    ha = had_operand(lane);
-  } else if constexpr (X32) {
+  u32x4* buf = nullptr;
+  if constexpr (X32) {
     __shared__ u32x4 rowbuf[W][64 * MAXC];   // the modulated row, halves in, whole chunks out
     buf = rowbuf[wave];
   }
@@ -362,193 +356,22 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
       const int lane_x = rq_opaque(lane);
       const int hsel = lane_x & 1, k2 = lane_x >> 1;
       u32x2* img = (u32x2*)buf;
-      uint32_t sx2[2] = {0, 0};
-      if constexpr (EMIT && MFMA) {   // h_out wants the modulated row without the rotation's signs
-        const int j0 = (k2 & 15) * 8 + 4 * hsel;
-        const uint32_t db = (r.sign[j0 >> 5] >> (j0 & 31)) & 0xFu;
-        sx2[0] = ((db & 1u) << 15) | (((db >> 1) & 1u) << 31);
-        sx2[1] = (((db >> 2) & 1u) << 15) | (((db >> 3) & 1u) << 31);
-      }
 #pragma unroll
-      for (int n = 0; n < (MFMA ? 8 : RV); ++n) {
+      for (int n = 0; n < RV; ++n) {
         const int v = 32 * n + k2;                       // chunk of the row
         u32x2 hw2 = {0, 0};
         if (n < RV) {
           const u32x4 A = planes[hsel * vpr + v], B = planes[(2 + hsel) * vpr + v];   // beyond the row: in bounds, unused
           const u32x4 w = cur[n];
-          hw2[0] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[0]), rstd, nm), u2f(A[0]), u2f(B[0])),
-                        __builtin_fmaf(__builtin_fmaf(u2f(w[1]), rstd, nm), u2f(A[1]), u2f(B[1])));
-          hw2[1] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[2]), rstd, nm), u2f(A[2]), u2f(B[2])),
-                        __builtin_fmaf(__builtin_fmaf(u2f(w[3]), rstd, nm), u2f(A[3]), u2f(B[3])));
+          hw2[0] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[0]), rstd, nm), u2f(A[0]), u2f(B[0])), __builtin_fmaf(__builtin_fmaf(u2f(w[1]), rstd, nm), u2f(A[1]), u2f(B[1])));
+          hw2[1] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[2]), rstd, nm), u2f(A[2]), u2f(B[2])), __builtin_fmaf(__builtin_fmaf(u2f(w[3]), rstd, nm), u2f(A[3]), u2f(B[3])));
           if (n >= RV - 2 && !qlive[n]) hw2 = u32x2{0, 0};
-          if constexpr (EMIT && MFMA) {
-            if (h_out && qlive[n])
-              __builtin_nontemporal_store(u32x2{hw2[0] ^ sx2[0], hw2[1] ^ sx2[1]}, (u32x2*)(h_out + row * vpr + v) + hsel);
-          }
         }
-        if constexpr (MFMA) {
-          const int g = 2 * n + (k2 >> 4), pc = k2 & 15;
-          img[(pc * 16 + (g ^ pc)) * 2 + hsel] = hw2;
-        } else {
-          img[v * 2 + hsel] = hw2;
-        }
+        img[v * 2 + hsel] = hw2;
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (MFMA) {
-      // ---- modulate into the B-operand image (all 16 groups defined: vectors beyond the row are zeros), transform on
-      // the matrix cores, quantize the 32 outputs this lane holds of its group, out through the same image ----
-      const int lane_w = rq_opaque(lane);
-#pragma unroll
-      for (int c = 0; c < (X32 ? 0 : 4); ++c) {
-        u32x4 hw = {0, 0, 0, 0};
-        if (c < MAXC) {
-          const int v = vidx[c];
-          const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
-          const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
-          const u32x4 w = cur[c];
-          hw[0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
-                       __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
-          hw[1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
-                       __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
-          hw[2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
-                       __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
-          hw[3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
-                       __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
-          if (c == MAXC - 1 && !last_live) hw = u32x4{0, 0, 0, 0};
-          if constexpr (EMIT) {
-            if (h_out && (c < MAXC - 1 || last_live))
-              __builtin_nontemporal_store(u32x4{hw[0] ^ sx[0], hw[1] ^ sx[1], hw[2] ^ sx[2], hw[3] ^ sx[3]}, h_out + row * vpr + v);
-          }
-        }
-        const int g = 4 * c + (lane_w >> 4), p = lane_w & 15;
-        buf[p * 16 + (g ^ p)] = hw;
-      }
-      __builtin_amdgcn_wave_barrier();
-      uint32_t yw[8][2];
-      const float mf = hadamard128_mfma(buf, ha, r.c_h, lane, yw);
-      __builtin_amdgcn_wave_barrier();
-      if constexpr (EMIT) {
-        if (y_out) rq_store_tile(buf, yw, rq_rsrc(y_out + row * vpr, vpr * 16), lane);
-      }
-      FPQ_PHASE("group_max_scale");
-      uint32_t m = mul2_to_h2(mf, 0.0f, r.c_h) & 0xFFFFu;       // see rotate_quant_mfma_kernel
-      if (__builtin_expect((yw[0][0] & 0x7C00u) == 0x7C00u, 0)) {
-        m = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) m = pk_max_u16(m, pk_max_u16(yw[c][0] & 0x7FFF7FFFu, yw[c][1] & 0x7FFF7FFFu));
-        const uint32_t lo = m & 0xFFFFu, hi = m >> 16;
-        m = lo > hi ? lo : hi;
-      }
-      // ---- groups 16 .. 19 (vectors 256 .. vpr - 1; d36: C = 2304 = 18 groups): a second tile would run its epilogue
-      // for 64 lanes to serve 8 - 16 of them; one chunk per lane with the transform as butterflies costs 40 % of a tile
-      // and keeps every lane busy.  Rotated here, quantized after the tile (per token: with the row's one scale) ----
-      u32x4 hw = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
-      uint32_t m1 = 0;
-      const int v = vidx[MAXC - 1];
-      if constexpr (MAXC == 5) {
-        if constexpr (X32) {   // the two half-chunk loads beyond the tile: halves meet in the (free again) image
-          const int lane_x = rq_opaque(lane);
-          const int hsel = lane_x & 1, k2 = lane_x >> 1;
-#pragma unroll
-          for (int n = 8; n < RV; ++n) {
-            const int v2 = 32 * n + k2;
-            const u32x4 A = planes[hsel * vpr + v2], B = planes[(2 + hsel) * vpr + v2];
-            const u32x4 w = cur[n];
-            u32x2 hw2;
-            hw2[0] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[0]), rstd, nm), u2f(A[0]), u2f(B[0])),
-                          __builtin_fmaf(__builtin_fmaf(u2f(w[1]), rstd, nm), u2f(A[1]), u2f(B[1])));
-            hw2[1] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[2]), rstd, nm), u2f(A[2]), u2f(B[2])),
-                          __builtin_fmaf(__builtin_fmaf(u2f(w[3]), rstd, nm), u2f(A[3]), u2f(B[3])));
-            if (!qlive[n]) hw2 = u32x2{0, 0};
-            ((u32x2*)buf)[(v2 - 256) * 2 + hsel] = hw2;
-          }
-          __builtin_amdgcn_wave_barrier();
-          hw = buf[rq_opaque(lane)];
-          __builtin_amdgcn_wave_barrier();
-        } else {
-          const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
-          const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
-          const u32x4 w = cur[4];
-          hw[0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
-                       __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
-          hw[1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
-                       __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
-          hw[2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
-                       __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
-          hw[3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
-                       __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
-        }
-        if (!last_live) hw = u32x4{0, 0, 0, 0};
-        const u32x4 hwa[1] = {hw};
-        float t1[1][8];
-        fwht128_h_n<1>(hwa, t1, 1, lg);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) y1[k] = mul2_to_h2(t1[0][2 * k], t1[0][2 * k + 1], r.c_h);
-        m1 = vec_absmax16(y1);
-      }
-      RowScale16 s, s1;
-      if constexpr (TOKEN) {
-        m = row_max_dpp<64>(m > m1 ? m : m1);   // fp6_quant_*_per_token_cuda on the rotated row: one scale for the whole row
-        s = s1 = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-        if (r.code_scales && lane == 0) r.code_scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
-      } else {
-        auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
-        m = sw[0] > sw[1] ? sw[0] : sw[1];
-        sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
-        m = sw[0] > sw[1] ? sw[0] : sw[1];
-        s = s1 = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-        if constexpr (MAXC == 5) {
-          uint32_t ms[1] = {m1};
-          row_max_dpp16_n<1>(ms, 1);
-          s1 = row_scale16(ms[0], a.fpos.gmax, a.inv_gpos);
-        }
-      }
-      if constexpr (CODES && TOKEN) {   // per-token operands: E4M3 bytes or dense 6-bit codes, the row scale is out already
-        if (r.code_bits == 6) rq_store_codes6(buf, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 6), vpr * 6), lane);
-        else rq_store_codes8(buf, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 8), vpr * 8), lane);
-        if constexpr (MAXC == 5) {
-          if (last_live) token_codes_out(4, y1, s1, v);
-        }
-      } else if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
-        rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
-                       rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
-        if constexpr (MAXC == 5) {
-          const uint32_t cd = codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
-          if (last_live) {
-            const int64_t at = row * vpr + v;
-            ((uint32_t*)out)[at] = cd;
-            if (lg == 0) r.code_scales[at >> 4] = (uint16_t)(s1.s16x2 & 0xFFFFu);
-          }
-        }
-      } else {
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          FPQ_PHASE("quant_divide");
-          const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
-          FPQ_PHASE("quant_lookup");
-          const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
-          const uint32_t lv = rq_lut_pair(lut, u, a.shift);
-          FPQ_PHASE("quant_dequant_mul");
-          yw[c][rr] = pk_mul_f16(lv, s.s16x2);
-        }
-      rq_store_tile(buf, yw, rq_rsrc(out + row * vpr, vpr * 16), lane);
-      FPQ_PHASE("row_end");
-      }
-      if constexpr (MAXC == 5 && !CODES) {
-        const u32x4 o1 = quant_vec16<false>(y1, lut, a.shift, s1.inv, s1.inv_lo, s1.s16x2, 0.f, 0.f, 0u);
-        if (last_live) {
-          const int64_t at = row * vpr + v;
-          if constexpr (EMIT) {
-            if (h_out) __builtin_nontemporal_store(u32x4{hw[0] ^ sx[0], hw[1] ^ sx[1], hw[2] ^ sx[2], hw[3] ^ sx[3]}, h_out + at);
-            if (y_out) __builtin_nontemporal_store(y1, y_out + at);
-          }
-          __builtin_nontemporal_store(o1, out + at);
-        }
-      }
-    } else {
+    {
     // ---- modulate, rotate, quantize: vectors two at a time, stage by stage ----
     u32x4 ys[TOKEN ? MAXC : 1];   // per-token scale: the rotated row waits here for the row maximum
     uint32_t mrow = 0;
@@ -569,14 +392,10 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
           const u32x4 A0 = planes[v], B0 = planes[2 * vpr + v];
           const u32x4 A1 = planes[vpr + v], B1 = planes[3 * vpr + v];
           const u32x4 w = cur[c0 + j];
-          hw[j][0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])),
-                          __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
-          hw[j][1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])),
-                          __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
-          hw[j][2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])),
-                          __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
-          hw[j][3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])),
-                          __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
+          hw[j][0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])), __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
+          hw[j][1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])), __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
+          hw[j][2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])), __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
+          hw[j][3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])), __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
         }
       }
       if (!last_live && c0 + n == MAXC) hw[n - 1] = u32x4{0, 0, 0, 0};
@@ -650,7 +469,7 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
       }
     }
     }
-    if constexpr (X32 && !MFMA) __builtin_amdgcn_wave_barrier();   // the row buffer is rewritten by the next row
+    if constexpr (X32) __builtin_amdgcn_wave_barrier();   // the row buffer is rewritten by the next row
   };
   u32x4 alt[RV];
   if constexpr (PREFETCH) {
@@ -661,4 +480,565 @@ __global__ __launch_bounds__(kBlock, (X32 && MFMA && MAXC == 4 && !EMIT) ? FPQ_A
   } else {
     for (int i = wave; i < n_here; i += W) do_row(cur, alt, i);
   }
+}
+// ==================================================================================================================
+// Third generation (round 3): the matrix-core form of the producer, rebuilt around the instruction census of the second
+// one (profiles/r03_adaln_isa_census.txt: 585 vector instructions per row and wavefront at C = 1920 in the row loop +
+// 62 of workgroup prologue spread over 4 rows; of the 585, ~110 were LDS / global address arithmetic, 16 the v_perm that
+// packs two 16-bit table reads, 14 register copies between the two prefetch sets).
+//   * every LDS access is a lane-constant base + an immediate: padded image rows (fpq_rotate_mfma.h), modulation planes
+//     with a compile-time plane stride; the bases live in registers across the kernel (the LDS footprint allows 4
+//     wavefronts per SIMD = 128 registers each);
+//   * rows are loaded and stored through per-row buffer resources: no per-lane liveness - loads beyond the row return
+//     zeros, stores beyond it are dropped, and the modulation of the padding is zero, so padding lanes need no selects;
+//   * ONE register set per row: the next row is requested right after the current one has been modulated into the
+//     operand image - its raw registers are dead from there on - and lands during the transform / quantize / store half
+//     of the row; no duplicated loop body, 16 (fp16 rows) / 32 (fp32 rows) registers fewer;
+//   * workgroup = (batch entry, chunk of rows), the chunks shrinking towards the end of the grid (AdalnTiers below).
+//     Tried and dropped: ONE generation of 1024 resident workgroups, each
+//     with a contiguous balanced share of ~64 rows and the modulation re-staged at batch boundaries - 105 us against 93
+//     for chunks of 16 rows dispatched in address order (the resident wavefronts then sweep a compact window of the
+//     tensor instead of 4096 streams a quarter of a megabyte apart), 2048 / 4096 shares: 100 / 93 us
+//     (profiles/r03_adaln_partition.txt);
+//   * E2M1 levels come from the FP4 conversion hardware (HW4): level = f16_fp4(fp4_f32(float(xn) + 2^-14)).  The bias
+//     removes every tie (fp16 values >= 0.25 are multiples of 2^-12, every rounding boundary of E2M1 is a multiple of
+//     0.25) and sends each to the side the reference's scan picks (the larger value); tools/probe/cvt_fp4_probe.hip checks all 63 488
+//     finite fp16 values against the scan on the hardware (profiles/r03_cvt_fp4_probe.txt).  Levels that round to zero
+//     from below come back as -0: the dequantizing multiply is an fma with +0.  Non-finite quotients only occur under a
+//     non-finite scale, which is replaced by NaN (the reference's 0 * inf).  5 instructions per pair instead of 7, and
+//     no table, no LDS traffic.
+// Same results as the second generation on every path except that rows of 17 .. 20 groups on fp32 input form their
+// slot first (the order of operations inside a row, not the values).
+// ==================================================================================================================
+// Workgroup -> rows.  A workgroup owns a chunk of rows of ONE batch entry (its modulation is staged once per workgroup).
+// Long chunks amortise that prologue, but the launch ends with the chip draining for about half a workgroup's lifetime
+// (the same kernel as a plain row copy: 81 us with 4 .. 8 rows per workgroup, 86 with 16, 94 with 32 -
+// profiles/r03_adaln_partition.txt).  Hence chunks that shrink towards the end of the grid: the last batch entries in
+// dispatch order are cut into chunks of rows[2], the ones before them into rows[1], the bulk into rows[0].
+struct AdalnTiers {
+  int rows[3];        // rows per workgroup in each tier
+  int per_batch[3];   // workgroups per batch entry = ceil(L / rows)
+  int batches[2];     // batch entries in tiers 0 and 1 (tier 2: the rest)
+};
+
+// the 8 E2M1 levels of a packed pair of normalised values, hardware rounding with the tie-breaking bias (see above)
+__device__ __forceinline__ uint32_t e2m1_levels_hw(uint32_t xn2) {
+  const float t0 = fma_h_lo(xn2, 1.0f, 0x1p-14f), t1 = fma_h_hi(xn2, 1.0f, 0x1p-14f);
+  const uint32_t code = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(xn2, t0, t1, 1.0f, 0);   // byte 0 of a dead register
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(code, 1.0f, 0));
+}
+__device__ __forceinline__ uint32_t pk_fma0_f16(uint32_t a, uint32_t b) {   // a * b + (+0): a -0 product becomes +0
+  const h2_t z = {(_Float16)0.0f, (_Float16)0.0f};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), z));
+}
+__device__ __forceinline__ void scale_nan_if_not_finite(RowScale16& s) {
+  if (!(s.sf < __builtin_inff())) s.s16x2 = 0x7E007E00u;
+}
+
+// 4 wavefronts per SIMD (128 registers) wherever the row fits: d30 on fp16 rows takes 96, on fp32 rows 118.  fp32 rows of
+// 17 .. 20 groups hold 40 registers of raw row and get 168 (3 wavefronts); the emitting forms are for tests and
+// calibration dumps.
+// TIGHT (fp16 rows of exactly 15 groups = VAR-d30, hardware levels: no table): planes of 240 vectors + four 272-byte-stride
+// images = 32 KiB of LDS to the byte, so FIVE workgroups fit a CU; the row loop is bound by latency (loads, LDS round
+// trips, cross-lane hazards: a wavefront issues an instruction every ~20 cycles), not by the vector pipe, and every
+// further wavefront per SIMD shows (profiles/r03_pmc_adaln.txt).  The padding lanes then read past the planes (finite
+// garbage, or the images behind them): their group 15 is dead weight in every phase and its stores are dropped.
+#ifndef FPQ_ADALN_TIGHT
+#define FPQ_ADALN_TIGHT 1
+#endif
+// -DFPQ_ADALN_STAMPS: diagnostic build (tools/adaln_stamps.py).  s_memtime stamps between the phases of a row, summed per
+// wavefront in scalar registers and written - to `y_out`, which the non-emitting form never touches otherwise - once at
+// the end: where a wavefront's row time goes.  Each stamp drains the LDS queue and the first one of a row the memory
+// queue: read the SHARES, not the length.  No stamp executes in a regular build.
+#ifdef FPQ_ADALN_STAMPS
+#define FPQ_STAMP(k)                                                                  \
+  do {                                                                                \
+    unsigned long long t_;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    st_sum[k] += t_ - st_last;                                                        \
+    st_last = t_;                                                                     \
+  } while (0)
+#else
+#define FPQ_STAMP(k) do { } while (0)
+#endif
+#ifndef FPQ_ADALN_DB       // 1: two register sets, the next row is requested at the START of the current one (same-process A/B: 95.4 - 97.0 us against 91.9 - 97.6 for the single set, profiles/r03_adaln_ab.txt: not the default)
+#define FPQ_ADALN_DB 0
+#endif
+// NW: wavefronts per workgroup.  8 (TIGHT only) share one set of planes: 49 KiB of LDS, three workgroups = SIX wavefronts
+// per SIMD at <= 80 registers, and the staging of the modulation is paid once per 8 wavefronts.
+template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN, bool X32, bool HW4, bool TIGHT = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8 ? 6 : TIGHT ? 5 : 4) void adaln_mfma_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
+                                                              u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
+                                                              int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a,
+                                                              Lut16Tab tab, AdalnTiers tiers) {
+  static_assert(MAXC >= 1 && MAXC <= 5, "rows of at most 20 groups");
+  static_assert(!HW4 || (!CODES && !TOKEN), "hardware E2M1 levels: fake-quantized values per group only");
+  static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 32 KiB form: fp16 rows of 15 groups, no table");
+  constexpr bool MOD16 = sizeof(Tmod) == 2;
+  static_assert(NW == 4 || (NW == 8 && TIGHT), "8 wavefronts per workgroup: the 32 KiB form only");
+  constexpr int W = NW;
+  constexpr int RV = X32 ? 2 * MAXC : MAXC;      // 16-byte registers of one row per lane
+  constexpr int PV = TIGHT ? 240 : MAXC * 64;    // vectors per modulation plane (not TIGHT: the padding carries zeros)
+  constexpr int INS = TIGHT ? kRqOutStride : kRqInStride;
+  constexpr bool DB = FPQ_ADALN_DB && !X32 && !EMIT;
+  uint16_t* lut = nullptr;                       // symmetric tables only: at most 2 x 512 buckets (E2M3)
+  if constexpr (!HW4) {
+    __shared__ __attribute__((aligned(16))) uint16_t lut_s[1024];
+    lut = lut_s;
+  }
+  __shared__ u32x4 planes[4][PV];                // A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
+  __shared__ u32x4 images[W][INS];               // 16 groups x INS bytes per wavefront
+  const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
+  FPQ_PHASE("workgroup_prologue");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* img = (char*)images[wave];
+  const char* pl = (const char*)planes;
+  const RqLaneAddr la = rq_lane_addr<INS>(lane);
+  const HadOperand ha = had_operand(lane);
+  const int64_t L = ad.rows_per_batch;
+  const int row_bytes = vpr * (X32 ? 32 : 16);
+
+  // workgroup -> (batch entry, chunk): one 32-bit division (the 64-bit row / L of the first version of this kernel was
+  // ~290 scalar instructions of software divide at the head of every workgroup)
+  uint32_t id = blockIdx.x;
+  const uint32_t n0 = (uint32_t)tiers.batches[0] * (uint32_t)tiers.per_batch[0];
+  const uint32_t n1 = (uint32_t)tiers.batches[1] * (uint32_t)tiers.per_batch[1];
+  int tier = 0;
+  uint32_t b0 = 0;
+  if (id >= n0 + n1) {
+    tier = 2;
+    id -= n0 + n1;
+    b0 = (uint32_t)(tiers.batches[0] + tiers.batches[1]);
+  } else if (id >= n0) {
+    tier = 1;
+    id -= n0;
+    b0 = (uint32_t)tiers.batches[0];
+  }
+  const uint32_t pb = (uint32_t)tiers.per_batch[tier];
+  const int rows_per_wg = tiers.rows[tier];
+  const uint32_t bq = id / pb;
+  const int64_t b = b0 + bq;
+  const int64_t lo = b * L + (int64_t)(id - bq * pb) * rows_per_wg;
+  int64_t hi = lo + rows_per_wg;
+  if (hi > (b + 1) * L) hi = (b + 1) * L;
+  if (hi > rows) hi = rows;
+
+  auto load_row = [&](u32x4 (&dst)[RV], int64_t row) {
+#ifdef FPQ_ADALN_NOMEM   // timing experiment: zero-record descriptors - every row load returns zeros, every row store is dropped,
+                         // the instruction stream is unchanged: what the kernel costs without its HBM traffic
+    const __amdgpu_buffer_rsrc_t src = rq_rsrc((const char*)x + row * row_bytes, 0);
+#else
+    const __amdgpu_buffer_rsrc_t src = rq_rsrc((const char*)x + row * row_bytes, row_bytes);
+#endif
+#pragma unroll
+    for (int n = 0; n < RV; ++n) dst[n] = __builtin_amdgcn_raw_buffer_load_b128(src, la.lane16 + n * 1024, 0, kRqNt);
+  };
+
+  // the rotation's signs of this lane's chunk (16-byte vector: chunk lane % 16; fp32 rows: half lane & 1 of chunk
+  // (lane / 2) % 16) - only to take them off again for the h_out of the emitting form
+  uint32_t sx[4] = {0, 0, 0, 0};
+  if constexpr (EMIT || MAXC == 5) {
+    const int lg = lane & 15;
+    const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sx[k] = (((sb >> (2 * k)) & 1u) << 15) | (((sb >> (2 * k + 1)) & 1u) << 31);
+  }
+  uint32_t sx2[2] = {0, 0};
+  if constexpr (EMIT && X32) {
+    const int j0 = ((lane >> 1) & 15) * 8 + 4 * (lane & 1);
+    const uint32_t db = (r.sign[j0 >> 5] >> (j0 & 31)) & 0xFu;
+    sx2[0] = ((db & 1u) << 15) | (((db >> 1) & 1u) << 31);
+    sx2[1] = (((db >> 2) & 1u) << 15) | (((db >> 3) & 1u) << 31);
+  }
+  const int pl_x = (lane & 1) * (PV * 16) + (lane >> 1) * 16;   // fp32 rows: plane `half`, vector lane / 2 (+ 32 n)
+  const float inv_c = 1.0f / (float)ad.cols;
+  const h2v_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+
+  // ---- the folded modulation of batch entry b:  A = half(scale + 1) * s * D,  B = shift * s * D;  zeros beyond the row ----
+  auto stage = [&](int64_t b) {
+    for (int v = threadIdx.x; v < PV; v += 64 * NW) {
+      float sc[8], sh[8];
+      if (TIGHT || v < vpr) {
+        const int64_t col = (int64_t)v * 8;
+        if constexpr (MOD16) {
+          const u32x4 ws = *(const u32x4*)((const _Float16*)ad.scale + b * ad.cols + col);
+          const u32x4 wh = *(const u32x4*)((const _Float16*)ad.shift + b * ad.cols + col);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t s1p = pk_add_f16(ws[k], 0x3C003C00u);   // scale.add(1) is an fp16 op in the reference
+            sc[2 * k] = h2f(s1p & 0xFFFFu);
+            sc[2 * k + 1] = h2f(s1p >> 16);
+            sh[2 * k] = h2f(wh[k] & 0xFFFFu);
+            sh[2 * k + 1] = h2f(wh[k] >> 16);
+          }
+        } else {
+          const u32x4* ap = (const u32x4*)((const float*)ad.scale + b * ad.cols + col);
+          const u32x4* bp = (const u32x4*)((const float*)ad.shift + b * ad.cols + col);
+          const u32x4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            sc[k] = u2f(a0[k]) + 1.0f;
+            sc[4 + k] = u2f(a1[k]) + 1.0f;
+            sh[k] = u2f(b0[k]);
+            sh[4 + k] = u2f(b1[k]);
+          }
+        }
+        if (r.smooth) {
+          const u32x4* sp = (const u32x4*)(r.smooth + col);
+          const u32x4 s0 = sp[0], s1 = sp[1];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            sc[k] *= u2f(s0[k]);
+            sh[k] *= u2f(s0[k]);
+            sc[4 + k] *= u2f(s1[k]);
+            sh[4 + k] *= u2f(s1[k]);
+          }
+        }
+        // the rotation's sign vector D rides on the modulation: half(-t) == -half(t), so h * D = half(fma(ln, A*D, B*D))
+        const int j0 = (v * 8) & 127;
+        const uint32_t dbits = (r.sign[j0 >> 5] >> (j0 & 31)) & 0xFFu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t flip = ((dbits >> k) & 1u) << 31;
+          sc[k] = u2f(fbits(sc[k]) ^ flip);
+          sh[k] = u2f(fbits(sh[k]) ^ flip);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sc[k] = sh[k] = 0.0f;
+      }
+      planes[0][v] = u32x4{fbits(sc[0]), fbits(sc[1]), fbits(sc[2]), fbits(sc[3])};
+      planes[1][v] = u32x4{fbits(sc[4]), fbits(sc[5]), fbits(sc[6]), fbits(sc[7])};
+      planes[2][v] = u32x4{fbits(sh[0]), fbits(sh[1]), fbits(sh[2]), fbits(sh[3])};
+      planes[3][v] = u32x4{fbits(sh[4]), fbits(sh[5]), fbits(sh[6]), fbits(sh[7])};
+    }
+  };
+
+  // One row.  `cur` holds it; `next_row` >= 0: that row is requested - DB: into `nxt`, at once; otherwise into `cur`,
+  // once the current row has left it.
+#ifdef FPQ_ADALN_STAMPS
+  unsigned long long st_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_rows = 0;
+#endif
+  auto do_row = [&](u32x4 (&cur)[RV], u32x4 (&nxt)[RV], int64_t row, int64_t next_row) {
+    FPQ_STAMP(0);                                   // between rows (loop control; the first row: the prologue)
+#ifdef FPQ_ADALN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ++st_rows;
+#endif
+    FPQ_STAMP(1);                                   // waiting for the row (and, in this build, the previous row's stores)
+#ifdef FPQ_ADALN_COPYONLY   // experiment: the kernel's memory access pattern alone (rows in, rows out, nothing computed; 2: no staging either)
+    if constexpr (!X32 && !EMIT && !CODES && !TOKEN) {
+      const __amdgpu_buffer_rsrc_t dst = rq_rsrc(out + row * vpr, vpr * 16);
+      u32x4 keep[RV];
+#pragma unroll
+      for (int n = 0; n < RV; ++n) keep[n] = cur[n];
+      if (next_row >= 0) load_row(DB ? nxt : cur, next_row);
+#pragma unroll
+      for (int n = 0; n < RV; ++n) __builtin_amdgcn_raw_buffer_store_b128(keep[n], dst, la.lane16 + n * 1024, 0, kRqNt);
+      return;
+    }
+#endif
+    if constexpr (DB) {
+      FPQ_PHASE("prefetch_next_row");
+      if (next_row >= 0) load_row(nxt, next_row);   // wave-uniform
+    } else {
+      (void)nxt;
+    }
+    // ---- LayerNorm statistics (see the second generation above; padding lanes hold zeros) ----
+    FPQ_PHASE("ln_stats");
+    float a1[RV], a2[RV];
+#pragma unroll
+    for (int c = 0; c < RV; ++c) a1[c] = a2[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < RV; ++c) {
+        const uint32_t xw = cur[c][k];
+        if constexpr (X32) {
+          const float xf = u2f(xw);
+          a1[c] += xf;
+          a2[c] = __builtin_fmaf(xf, xf, a2[c]);
+        } else {
+          const h2v_t xv = __builtin_bit_cast(h2v_t, xw);
+          a1[c] = __builtin_amdgcn_fdot2(xv, ones, a1[c], false);
+          a2[c] = __builtin_amdgcn_fdot2(xv, xv, a2[c], false);
+        }
+      }
+    float sum1 = a1[0], s2 = a2[0];
+#pragma unroll
+    for (int c = 1; c < RV; ++c) {
+      sum1 += a1[c];
+      s2 += a2[c];
+    }
+    FPQ_PHASE("ln_reduce_rstd");
+    wave_sum2_dpp(sum1, s2);
+    const float mean = sum1 * inv_c;
+    float var = __builtin_fmaf(-mean, mean, s2 * inv_c);
+    if (!(mean * mean < (X32 ? 8.0f : 64.0f) * var)) {   // cancellation (or NaN / Inf): the centred second pass - rare
+#pragma unroll
+      for (int c = 0; c < RV; ++c) a2[c] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < RV; ++c) {
+          if constexpr (X32) {
+            const float d0 = u2f(cur[c][k]) - mean;
+            a2[c] = __builtin_fmaf(d0, d0, a2[c]);
+          } else {
+            const float d0 = fma_h_lo(cur[c][k], 1.0f, -mean), d1 = fma_h_hi(cur[c][k], 1.0f, -mean);
+            a2[c] = __builtin_fmaf(d0, d0, a2[c]);
+            a2[c] = __builtin_fmaf(d1, d1, a2[c]);
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < RV; ++c)                        // the zero padding is not part of the row
+        if ((c * 64 + lane) * (X32 ? 4 : 8) >= (int)ad.cols) a2[c] = 0.0f;
+      s2 = a2[0];
+#pragma unroll
+      for (int c = 1; c < RV; ++c) s2 += a2[c];
+      var = wave_sum_dpp(s2) * inv_c;
+    }
+    const float ve = var + ad.eps;
+    float rstd = __builtin_amdgcn_rsqf(ve);
+    rstd = __builtin_fmaf(rstd * __builtin_fmaf(-ve * rstd, rstd, 1.0f), 0.5f, rstd);
+    const float nm = -mean * rstd;
+    FPQ_STAMP(2);                                   // statistics, reduction, rstd
+
+    // ---- modulate into the operand image: h * D = half(fma(fma(x, rstd, nm), A, B)) ----
+    FPQ_PHASE("modulate_to_image");
+    const __amdgpu_buffer_rsrc_t h_dst = rq_rsrc(EMIT && h_out ? (const char*)(h_out + row * vpr) : nullptr, EMIT && h_out ? vpr * 16 : 0);
+    u32x4 hw_slot = {0, 0, 0, 0};   // MAXC == 5: chunk 256 + lane of the row (groups 16 .. 19), transformed as butterflies
+    if constexpr (X32) {
+      auto half_chunk = [&](int n) {
+        const u32x4 A = *(const u32x4*)(pl + pl_x + n * 512), B = *(const u32x4*)(pl + pl_x + n * 512 + 2 * PV * 16);
+        const u32x4 w = cur[n];
+        u32x2 hw2;
+        hw2[0] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[0]), rstd, nm), u2f(A[0]), u2f(B[0])), __builtin_fmaf(__builtin_fmaf(u2f(w[1]), rstd, nm), u2f(A[1]), u2f(B[1])));
+        hw2[1] = f2h2(__builtin_fmaf(__builtin_fmaf(u2f(w[2]), rstd, nm), u2f(A[2]), u2f(B[2])), __builtin_fmaf(__builtin_fmaf(u2f(w[3]), rstd, nm), u2f(A[3]), u2f(B[3])));
+        if constexpr (EMIT)   // half lane & 1 of chunk 32 n + lane / 2 = bytes lane * 8 + n * 512 of the row
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{hw2[0] ^ sx2[0], hw2[1] ^ sx2[1]}, h_dst, lane * 8 + n * 512, 0, kRqNt);
+        return hw2;
+      };
+      if constexpr (MAXC == 5) {   // the slot first: its halves meet in the (still free) image, one chunk per lane out
+#pragma unroll
+        for (int n = 8; n < RV; ++n) *(u32x2*)(img + lane * 8 + (n - 8) * 512) = half_chunk(n);
+        __builtin_amdgcn_wave_barrier();
+        hw_slot = *(const u32x4*)(img + la.lane16);
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        u32x2 hw2 = {0, 0};
+        if (n < RV) hw2 = half_chunk(n);
+        *(u32x2*)(img + la.in_w8 + n * (2 * INS)) = hw2;
+      }
+    } else {
+      auto chunk = [&](int c) {
+        const u32x4 A0 = *(const u32x4*)(pl + la.lane16 + (0 * PV + c * 64) * 16), A1 = *(const u32x4*)(pl + la.lane16 + (1 * PV + c * 64) * 16);
+        const u32x4 B0 = *(const u32x4*)(pl + la.lane16 + (2 * PV + c * 64) * 16), B1 = *(const u32x4*)(pl + la.lane16 + (3 * PV + c * 64) * 16);
+        const u32x4 w = cur[c];
+        u32x4 hw;
+        hw[0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])), __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
+        hw[1] = f2h2(__builtin_fmaf(fma_h_lo(w[1], rstd, nm), u2f(A0[2]), u2f(B0[2])), __builtin_fmaf(fma_h_hi(w[1], rstd, nm), u2f(A0[3]), u2f(B0[3])));
+        hw[2] = f2h2(__builtin_fmaf(fma_h_lo(w[2], rstd, nm), u2f(A1[0]), u2f(B1[0])), __builtin_fmaf(fma_h_hi(w[2], rstd, nm), u2f(A1[1]), u2f(B1[1])));
+        hw[3] = f2h2(__builtin_fmaf(fma_h_lo(w[3], rstd, nm), u2f(A1[2]), u2f(B1[2])), __builtin_fmaf(fma_h_hi(w[3], rstd, nm), u2f(A1[3]), u2f(B1[3])));
+        if constexpr (EMIT)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{hw[0] ^ sx[0], hw[1] ^ sx[1], hw[2] ^ sx[2], hw[3] ^ sx[3]}, h_dst,
+                                                 la.lane16 + c * 1024, 0, kRqNt);
+        return hw;
+      };
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x4 hw = {0, 0, 0, 0};
+        if (c < MAXC) hw = chunk(c);
+        *(u32x4*)(img + la.in_w + c * (4 * INS)) = hw;
+      }
+      if constexpr (MAXC == 5) hw_slot = chunk(4);
+    }
+    if constexpr (!DB) {
+      FPQ_PHASE("prefetch_next_row");
+      if (next_row >= 0) load_row(cur, next_row);   // wave-uniform; lands under the rest of this row
+    }
+    __builtin_amdgcn_wave_barrier();
+    FPQ_STAMP(3);                                   // modulate (plane reads), image writes, next row requested
+
+    // ---- transform on the matrix cores; this lane then holds 32 outputs of group lane % 16 ----
+    uint32_t yw[8][2];
+    const float mf = hadamard128_mfma(img, la.in_r, ha, r.c_h, yw);
+    __builtin_amdgcn_wave_barrier();
+    FPQ_STAMP(4);                                   // operand reads, 8 MFMAs, 4-point butterfly, maximum, c_h rounding
+    if constexpr (EMIT) {
+      if (y_out) rq_store_tile(img, yw, rq_rsrc(y_out + row * vpr, vpr * 16), la);
+    }
+    FPQ_PHASE("group_max_scale");
+    uint32_t m = mul2_to_h2(mf, 0.0f, r.c_h) & 0xFFFFu;       // see rotate_quant_mfma_kernel
+    if (__builtin_expect((yw[0][0] & 0x7C00u) == 0x7C00u, 0)) {
+      m = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) m = pk_max_u16(m, pk_max_u16(yw[c][0] & 0x7FFF7FFFu, yw[c][1] & 0x7FFF7FFFu));
+      const uint32_t lo16 = m & 0xFFFFu, hi16 = m >> 16;
+      m = lo16 > hi16 ? lo16 : hi16;
+    }
+    // ---- groups 16 .. 19 (d36: C = 2304 = 18 groups): one chunk per lane, the transform as butterflies (a second tile
+    // would run its epilogue for 64 lanes to serve 8 - 16 of them); quantized after the tile ----
+    u32x4 y1 = {0, 0, 0, 0};
+    uint32_t m1 = 0;
+    if constexpr (MAXC == 5) {
+      const u32x4 hwa[1] = {hw_slot};
+      float t1[1][8];
+      fwht128_h_n<1>(hwa, t1, 1, lane & 15);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y1[k] = mul2_to_h2(t1[0][2 * k], t1[0][2 * k + 1], r.c_h);
+      m1 = vec_absmax16(y1);
+    }
+    RowScale16 s, s1;
+    if constexpr (TOKEN) {
+      m = row_max_dpp<64>(m > m1 ? m : m1);   // fp6_quant_*_per_token_cuda on the rotated row: one scale for the whole row
+      s = s1 = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      if (r.code_scales && lane == 0) r.code_scales[row] = (uint16_t)(s.s16x2 & 0xFFFFu);
+    } else {
+      auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+      m = sw[0] > sw[1] ? sw[0] : sw[1];
+      sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+      m = sw[0] > sw[1] ? sw[0] : sw[1];
+      s = s1 = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      if constexpr (MAXC == 5) {
+        uint32_t ms[1] = {m1};
+        row_max_dpp16_n<1>(ms, 1);
+        s1 = row_scale16(ms[0], a.fpos.gmax, a.inv_gpos);
+      }
+      if constexpr (HW4) {
+        scale_nan_if_not_finite(s);
+        if constexpr (MAXC == 5) scale_nan_if_not_finite(s1);
+      }
+    }
+    FPQ_STAMP(5);                                   // group maximum across the quarters, scale and its reciprocal
+    const int64_t slot_at = row * vpr + 256 + lane;            // MAXC == 5: this lane's chunk of groups 16 .. 19
+    const bool slot_live = 256 + lane < vpr;
+    if constexpr (CODES && TOKEN) {   // per-token operands: E4M3 bytes or dense 6-bit codes, the row scale is out already
+      if (r.code_bits == 6) rq_store_codes6((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 6), vpr * 6), lane);
+      else rq_store_codes8((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 8), vpr * 8), lane);
+      if constexpr (MAXC == 5) {
+        if (slot_live) {
+          uint32_t cb[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t rb = div_pair16(y1[k], s1.inv, s1.inv_lo, s1.inv, s1.inv_lo);
+            const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+            cb[2 * k] = lut[(u & 0xFFFFu) >> a.shift];
+            cb[2 * k + 1] = lut[u >> (16 + a.shift)];
+          }
+          if (r.code_bits == 6) {
+            // 8 six-bit codes = 48 bits per lane, rows packed densely: the four lanes of a quad own 24 contiguous bytes;
+            // lane q of the quad takes the (3 - q) upper 16-bit words of its own string and the q + 1 lower words of its
+            // right neighbour's, so that lanes 0..2 each store 8 aligned bytes (cols % 32 == 0: a quad is live or dead
+            // as a whole)
+            const uint64_t own = (uint64_t)(cb[0] | (cb[1] << 6) | (cb[2] << 12) | (cb[3] << 18)) |
+                                 ((uint64_t)(cb[4] | (cb[5] << 6) | (cb[6] << 12) | (cb[7] << 18)) << 24);
+            const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)own, 0xF9, 0xF, 0xF, false);   // quad_perm [1,2,3,3]
+            const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(own >> 32), 0xF9, 0xF, 0xF, false);
+            const uint64_t nb = ((uint64_t)nhi << 32) | nlo;
+            const int qp = lane & 3, sr = 16 * qp;
+            const uint64_t w6 = (own >> sr) | (nb << (48 - sr));
+            if (qp < 3) {
+              uint8_t* dst = (uint8_t*)out + row * ((int64_t)vpr * 6) + (int64_t)4 * (64 * 6) + 24 * (lane >> 2) + 8 * qp;
+              __builtin_nontemporal_store(u32x2{(uint32_t)w6, (uint32_t)(w6 >> 32)}, (u32x2*)dst);
+            }
+          } else {
+            const u32x2 o2 = {cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24), cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24)};
+            __builtin_nontemporal_store(o2, (u32x2*)out + slot_at);
+          }
+        }
+      }
+    } else if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
+      rq_store_codes((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
+                     rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
+      if constexpr (MAXC == 5) {
+        const uint32_t cd = codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
+        if (slot_live) {
+          ((uint32_t*)out)[slot_at] = cd;
+          if ((lane & 15) == 0) r.code_scales[slot_at >> 4] = (uint16_t)(s1.s16x2 & 0xFFFFu);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          FPQ_PHASE("quant_divide");
+          const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+          if constexpr (HW4) {
+            FPQ_PHASE("quant_level_hw");
+            const uint32_t lv = e2m1_levels_hw(rb);
+            FPQ_PHASE("quant_dequant_mul");
+            yw[c][rr] = pk_fma0_f16(lv, s.s16x2);
+          } else {
+            FPQ_PHASE("quant_lookup");
+            const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+            const uint32_t lv = rq_lut_pair(lut, u, a.shift);
+            FPQ_PHASE("quant_dequant_mul");
+            yw[c][rr] = pk_mul_f16(lv, s.s16x2);
+          }
+        }
+      FPQ_STAMP(6);                                 // divide, level, dequantize
+#ifdef FPQ_ADALN_NOMEM
+      rq_store_tile(img, yw, rq_rsrc(out + row * vpr, 0), la);
+#else
+      rq_store_tile(img, yw, rq_rsrc(out + row * vpr, vpr * 16), la);
+#endif
+      FPQ_STAMP(7);                                 // output image round trip, stores issued
+      FPQ_PHASE("row_end");
+      if constexpr (MAXC == 5) {
+        u32x4 o1;
+        if constexpr (HW4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o1[k] = pk_fma0_f16(e2m1_levels_hw(div_pair16(y1[k], s1.inv, s1.inv_lo, s1.inv, s1.inv_lo)), s1.s16x2);
+        } else {
+          o1 = quant_vec16<false>(y1, lut, a.shift, s1.inv, s1.inv_lo, s1.s16x2, 0.f, 0.f, 0u);
+        }
+        if (slot_live) {
+          if constexpr (EMIT) {
+            if (h_out) __builtin_nontemporal_store(u32x4{hw_slot[0] ^ sx[0], hw_slot[1] ^ sx[1], hw_slot[2] ^ sx[2], hw_slot[3] ^ sx[3]}, h_out + slot_at);
+            if (y_out) __builtin_nontemporal_store(y1, y_out + slot_at);
+          }
+          __builtin_nontemporal_store(o1, out + slot_at);
+        }
+      }
+    }
+  };
+
+  // ---- the workgroup's rows: wavefront w takes rows lo + w, lo + w + 4, ... ----
+  u32x4 cur[RV], alt[DB ? RV : 1];
+  int64_t i = lo + wave;
+  if (i < hi) load_row(cur, i);                  // requested before the staging below
+  if constexpr (!HW4) lut16_stage(lut, tab, a.shift);
+#if !defined(FPQ_ADALN_COPYONLY) || FPQ_ADALN_COPYONLY < 2
+  stage(b);
+  __syncthreads();
+#endif
+  if constexpr (DB) {
+    for (; i < hi; i += 2 * W) {                 // two register sets alternate: no row is copied between registers
+      do_row(cur, alt, i, i + W < hi ? i + W : -1);
+      if (i + W < hi) do_row(alt, cur, i + W, i + 2 * W < hi ? i + 2 * W : -1);
+    }
+  } else if (i < hi) {
+    // first pass peeled: both edges into the loop then carry "loads, then this row's stores", and the wait for the
+    // prefetched row leaves the stores in flight (fpq_rotate_mfma.h, rotate_quant_mfma_kernel)
+    do_row(cur, cur, i, i + W < hi ? i + W : -1);
+    for (i += W; i < hi; i += W) do_row(cur, cur, i, i + W < hi ? i + W : -1);
+  }
+#ifdef FPQ_ADALN_STAMPS
+  if constexpr (!EMIT) {
+    if (y_out && lane == 0) {
+      unsigned long long* dst = (unsigned long long*)y_out + ((int64_t)blockIdx.x * W + wave) * 10;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dst[k] = st_sum[k];
+      dst[8] = st_rows;
+      dst[9] = st_last;
+    }
+  }
+#endif
 }

@@ -108,17 +108,31 @@ __device__ __forceinline__ float resid_h_hi(uint32_t w, float y, float s) {
   return d;
 }
 
-// xn = half(x / s) for the two halves of w: 1/s travels as an unevaluated sum inv_hi + inv_lo (error ~2^-46), the
-// fma x * inv_hi + (x * inv_lo) is exact up to that, and v_fma_mixlo/hi_f16 round ONCE, straight to fp16.  x and s
-// carry 11-bit significands, so x / s is never a rounding tie of fp16 and lies more than 2^-24 (relative) away from
-// every rounding boundary: the result is the correctly rounded quotient - torch's fp16 division - in 2 instructions
-// per element (tests/test_gpu_parity.py::test_every_fp16_pair_fast_path_vs_ieee_path sweeps all 1.0e9 pairs).
+// D = (float)half_lo(w) * b + c  /  (float)half_hi(w) * b + c (fp32 result)
+__device__ __forceinline__ float fmaf_h_lo(uint32_t w, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fmaf_h_hi(uint32_t w, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+  return d;
+}
+
+// xn = half(x / s) for the two halves of w: 1/s travels as an unevaluated sum inv_hi + inv_lo (error ~2^-46),
+// y = fp32(x * inv_hi + x * inv_lo) is the quotient to one fp32 rounding, and the pair is converted with ONE
+// v_cvt_pk_f16_f32.  x and s carry 11-bit significands: x / s is either exactly a 12-bit number - then y IS that number
+// (it is representable, and 2^-46 away) and the fp16 tie goes to even as IEEE division's does - or it lies at least
+// 2^-22.9993 (relative) from every 12-bit number, i.e. from every fp16 rounding boundary (|2^k a - b c| >= 1 for 11-bit
+// integers a, b and a 12-bit c), twice the fp32 rounding of y.  Either way half(y) is the correctly rounded quotient -
+// torch's fp16 division (tests/test_gpu_parity.py::test_every_fp16_pair_fast_path_vs_ieee_path sweeps all 1.0e9 pairs).
+// Round 2 rounded straight to fp16 (v_fma_mixlo/hi_f16): the same values, but that instruction occupies the vector
+// pipe for 8.2 cycles against 4.3 for v_fma_mix_f32 and 4.6 for the packed conversion
+// (tools/probe/valu_issue_cost.hip, profiles/r03_valu_issue_cost.txt): 25.1 -> 21.8 cycles per pair.
 __device__ __forceinline__ uint32_t div_pair16(uint32_t w, float ih0, float il0, float ih1, float il1) {
   const float t0 = mul_h_lo(w, il0), t1 = mul_h_hi(w, il1);
-  uint32_t d;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(ih0), "v"(t0));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(w), "v"(ih1), "v"(t1));
-  return d;
+  return f2h2(fmaf_h_lo(w, ih0, t0), fmaf_h_hi(w, ih1, t1));
 }
 
 // the two table entries of a packed pair of bucket patterns as ONE packed register: byte offsets straight from the
@@ -870,15 +884,13 @@ __device__ __forceinline__ void fwht128(float (&t)[8], int lane_in_group) {
   for (int j = 0; j < 4; ++j) { t[j] = p[j].x; t[j + 4] = p[j].y; }
 }
 
-// half(a * b) packed from two fp32 values with ONE rounding each (v_fma_mixlo/hi_f16): the rotated value
-// half(c_h * FWHT(...)).  No torch op sequence is mirrored here (the reference's GEMM rounds its fp32 accumulator
-// once, too), so the single rounding is the better one.
-__device__ __forceinline__ uint32_t mul2_to_h2(float lo, float hi, float b) {
-  uint32_t d;
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(lo), "v"(b));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(hi), "v"(b));
-  return d;
-}
+// half(a * b) packed from two fp32 values: the rotated value half(c_h * FWHT(...)).  Two v_mul_f32 and one
+// v_cvt_pk_f16_f32 (2 x 2.5 + 4.6 cycles of the vector pipe) instead of v_fma_mixlo/hi_f16 (2 x 8.2,
+// profiles/r03_valu_issue_cost.txt).  The product is rounded to fp32 before it is rounded to fp16: the two roundings
+// differ from one in ~2^-13 of the values, by one fp16 ulp; no torch op sequence is mirrored here (the reference's GEMM
+// rounds its own fp32 accumulator) and the contract - within half an ulp (1.001) + the accumulation bound of the exact
+// product, quantization exact on the values produced - holds as before.
+__device__ __forceinline__ uint32_t mul2_to_h2(float lo, float hi, float b) { return f2h2(lo * b, hi * b); }
 
 // D = s * (float)half(w) + (float)half(pw), lo / hi halves: both fp16 operands are widened by the instruction itself
 __device__ __forceinline__ float fmix_hsh_lo(uint32_t w, float s, uint32_t pw) {

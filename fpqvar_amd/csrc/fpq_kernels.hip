@@ -998,37 +998,83 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
     // second generation (fpq_adaln.h): fp16 or fp32 rows of up to 2560 channels, one batch entry per workgroup
     constexpr bool X32 = sizeof(Tin) == 4;
     if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !FPQ_ENV("FPQ_ADALN_V1")) {
-      const char* rows_env = FPQ_ENV("FPQ_ADALN_ROWS");
-      // 16 rows per workgroup amortise the staging of the modulation planes; small launches (the early scale steps of a
-      // generation: 100 .. 3600 rows) are latency-bound instead and want every CU busy: 4 rows = one per wavefront
-      // (measured as one graph-replayed call, profiles/r02_small_steps.json: 900 rows 10.1 -> 5.9 us)
-      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 32768 ? 16 : rows >= 8192 ? 8 : 4);
-      if (rows_per_wg < 1) rows_per_wg = 1;
+      if (h.args.shift < 6) return FPQ_ERR_TABLE;   // symmetric tables only (<= 2 x 512 buckets)
       const int64_t L = ad.rows_per_batch;
       const int64_t n_batches = (rows + L - 1) / L;
+      static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
+      const char* rows_env = FPQ_ENV("FPQ_ADALN_ROWS");
+      // Large launches: chunks of 16 rows (4 per wavefront) amortise the staging of the modulation; small launches (the
+      // early scale steps of a generation: 100 .. 3600 rows) are latency-bound and want every CU busy: one row per wavefront
+      // (profiles/r02_small_steps.json).  FPQ_ADALN_ROWS=n: n rows per workgroup everywhere; FPQ_ADALN_TAIL=rows: how many
+      // rows at the end of the grid go to each of the two finer tiers (default 8192: two generations of resident
+      // workgroups at 4 rows and one at 8).
+      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 32768 ? 16 : rows >= 8192 ? 8 : 4);
+      if (rows_per_wg < 1) rows_per_wg = 1;
       const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
-      const dim3 g2((unsigned)(n_batches * per_batch));
-      const size_t lds2 = 0;   // table and modulation planes live in static LDS
-      // value output: the rotation runs on the matrix cores (rows of 17 .. 20 groups: the first 16 of them)
-      static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
+      AdalnTiers tiers = {};
+      static const int tail_rows = FPQ_ENV("FPQ_ADALN_TAIL") ? atoi(FPQ_ENV("FPQ_ADALN_TAIL")) : 8192;
+      int64_t nb2 = 0, nb1 = 0;
+      if (!rows_env && !adaln_butterfly && tail_rows > 0 && rows_per_wg > 4) {
+        nb2 = (tail_rows + L - 1) / L;                                   // batch entries cut into chunks of 4 rows
+        if (rows_per_wg > 8) nb1 = (tail_rows + L - 1) / L;              // ... of 8 rows
+        if (nb2 > n_batches) nb2 = n_batches;
+        if (nb1 > n_batches - nb2) nb1 = n_batches - nb2;
+      }
+      tiers.rows[0] = rows_per_wg;
+      tiers.rows[1] = 8;
+      tiers.rows[2] = 4;
+      for (int t = 0; t < 3; ++t) tiers.per_batch[t] = (int)((L + tiers.rows[t] - 1) / tiers.rows[t]);
+      tiers.batches[0] = (int)(n_batches - nb1 - nb2);
+      tiers.batches[1] = (int)nb1;
+      const int64_t n_wg3 = (int64_t)tiers.batches[0] * tiers.per_batch[0] + nb1 * tiers.per_batch[1] + nb2 * tiers.per_batch[2];
+      if (n_wg3 > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+      const dim3 g2((unsigned)(n_batches * per_batch));         // second generation (butterfly form): flat grid of equal chunks
+      const dim3 g3((unsigned)n_wg3);
+      const size_t lds2 = 0;   // table, modulation planes and images live in static LDS
+      // E2M1 values per group: levels from the FP4 conversion hardware, no table (fpq_adaln.h)
+      const bool hw4 = table_id == FPQ_E2M1 && !code_scales && !token_mode && !FPQ_ENV("FPQ_ADALN_NO_HW4");
+      static const bool tight_ok = FPQ_ADALN_TIGHT && !FPQ_ENV("FPQ_ADALN_NO_TIGHT");
+      static const bool nw8 = FPQ_ENV("FPQ_ADALN_NW8") != nullptr;
+#define FPQ_ADALN3(M, CODES, EMIT, TOKEN, HW4, TIGHT)                                                                  \
+  hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, CODES, EMIT, TOKEN, X32, HW4, TIGHT>), g3, dim3(kBlock), lds2, st,    \
+                     (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, tiers)
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
-    {                                                                                                                  \
-      if (!adaln_butterfly) {                                                                                          \
-        hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, true, X32>), g2, dim3(kBlock), lds2, st,    \
-                           (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,       \
-                           rows_per_wg, (int)per_batch);                                                               \
-        break;                                                                                                         \
+    if (!adaln_butterfly) {                                                                                            \
+      if constexpr (!(CODES) && !(TOKEN)) {                                                                            \
+        if constexpr (M == 4 && !X32 && !(EMIT)) {                                                                     \
+          if (hw4 && tight_ok && r.vec_per_row == 240) {   /* VAR-d30: 32 KiB of LDS, five workgroups per CU */        \
+            if (nw8) {                                                                                                 \
+              hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, false, false, false, false, true, true, 8>), g3,          \
+                                 dim3(512), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,      \
+                                 rows, ad, r, h.args, tab, tiers);                                                     \
+              break;                                                                                                   \
+            }                                                                                                          \
+            FPQ_ADALN3(M, CODES, EMIT, TOKEN, true, true);                                                             \
+            break;                                                                                                     \
+          }                                                                                                            \
+        }                                                                                                              \
+        if (hw4) {                                                                                                     \
+          FPQ_ADALN3(M, CODES, EMIT, TOKEN, true, false);                                                              \
+          break;                                                                                                       \
+        }                                                                                                              \
       }                                                                                                                \
+      FPQ_ADALN3(M, CODES, EMIT, TOKEN, false, false);                                                                 \
+      break;                                                                                                           \
     }                                                                                                                  \
-    hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, false, X32>), g2, dim3(kBlock), lds2, st,       \
+    hipLaunchKernelGGL((adaln_rq16_kernel<Tmod, M, CODES, EMIT, TOKEN, X32>), g2, dim3(kBlock), lds2, st,              \
                        (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab,           \
                        rows_per_wg, (int)per_batch);                                                                   \
   } while (0)
+#ifdef FPQ_ADALN_STAMPS
+#define FPQ_ADALN_EMIT (h_out != nullptr)   /* diagnostic build: y_out alone is the stamp buffer */
+#else
+#define FPQ_ADALN_EMIT (h_out || y_out)
+#endif
 #define FPQ_ADALN2(M)                                                                                                  \
   do {                                                                                                                 \
-    const bool emit = h_out || y_out;                                                                                  \
+    const bool emit = FPQ_ADALN_EMIT;                                                                                  \
     if (token_mode >= 2) FPQ_ADALN2K(M, true, false, true);                                                            \
     else if (token_mode == 1 && emit) FPQ_ADALN2K(M, false, true, true);                                               \
     else if (token_mode == 1) FPQ_ADALN2K(M, false, false, true);                                                      \
@@ -1043,6 +1089,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
         case 4: FPQ_ADALN2(4); break;
         default: FPQ_ADALN2(5); break;
       }
+#undef FPQ_ADALN3
 #undef FPQ_ADALN2
 #undef FPQ_ADALN2K
       return check_launch();

@@ -37,6 +37,46 @@ typedef float rq_f4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kRqTileVec = 256;   // 16 groups x 16 vectors of 8 halves per wavefront
 
+// The wavefront's LDS image (round 3: padded rows instead of xor swizzles).  Round 2 kept chunk (g, p) at slot
+// p * 16 + (g ^ p): conflict-free, but every one of the ~24 LDS accesses of a tile had its own xor-ed address - 3 of the
+// 14.6 (rotate) / 21.8 (adaLN) vector instructions per element were address arithmetic (profiles/r03_adaln_isa_census.txt).
+// Now a group is a row of the image and every access of a phase is ONE lane-constant base + an immediate offset:
+//   operand image, 288 bytes per group (18 x 16): chunk p of group g at g * 288 + 16 p.
+//       row-order writes (vector i * 64 + lane of the tile = chunk lane % 16 of group 4 i + lane / 16): base + i * 1152,
+//       consecutive lanes, consecutive 16 bytes;  B-operand reads (chunk 4 s + lane / 16 of group lane % 16): base + 64 s,
+//       dword (8 g + 4 quarter) mod 64: the 16 lanes of each ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) hit 16
+//       different 16-byte slots of the 256-byte bank row.
+//   output image, 272 bytes per group (17 x 16): outputs 8 p' .. 8 p' + 7 of group g at g * 272 + 16 p'.
+//       8-byte pieces in (piece c of lane (g, quarter) = outputs 16 c + 4 quarter ..): base + 32 c (two lanes per bank
+//       pair - the store's own transfer time covers it);  16-byte vectors out in row order: base + i * 1088.
+constexpr int kRqInStride = 288, kRqOutStride = 272;
+constexpr int kRqImageBytes = 16 * kRqInStride;           // 4608 per wavefront
+constexpr int kRqImageVec = kRqImageBytes / 16;
+
+struct RqLaneAddr {
+  int in_w;    // row-order 16-byte writes of the operand image
+  int in_w8;   // the same image written by half-chunks (fp32 input: 8 bytes per lane and load)
+  int in_r;    // B-operand reads
+  int out_w;   // 8-byte pieces of the output image
+  int out_r;   // row-order 16-byte reads of the output image
+  int lane16;  // lane * 16: global offset of this lane's vector inside a 1 KiB row-order slab
+};
+// INS: bytes per group of the operand image.  288 is conflict-free; 272 (the output image's stride: one image size for
+// both) costs the B-operand reads one extra LDS cycle per instruction and saves 256 bytes per wavefront - which is what
+// lets the adaLN producer fit a fifth workgroup per CU at C = 1920 (fpq_adaln.h).
+template <int INS = kRqInStride>
+__device__ __forceinline__ RqLaneAddr rq_lane_addr(int lane) {
+  const int g = lane & 15, q = lane >> 4;
+  RqLaneAddr a;
+  a.in_w = q * INS + g * 16;
+  a.in_w8 = (lane >> 5) * INS + ((lane >> 1) & 15) * 16 + (lane & 1) * 8;
+  a.in_r = g * INS + q * 16;
+  a.out_w = g * kRqOutStride + q * 8;
+  a.out_r = q * kRqOutStride + g * 16;
+  a.lane16 = lane * 16;
+  return a;
+}
+
 // -DFPQ_ISA_CENSUS: phase markers for tools/isa_census.py --phases (a comment line in the assembly between two
 // scheduling barriers, so that every instruction is counted in the phase it belongs to); nothing in a regular build
 #ifdef FPQ_ISA_CENSUS
@@ -81,20 +121,17 @@ __device__ __forceinline__ HadOperand had_operand(int lane) {
   return h;
 }
 
-// 16 groups of 128 sign-applied fp16 inputs (in `buf`, B-operand layout) -> this lane's 32 rotated outputs of group
+// 16 groups of 128 sign-applied fp16 inputs (operand image in `img`) -> this lane's 32 rotated outputs of group
 // lane % 16 as packed fp16 words yw[c][r], c = u + 2 t: outputs 16 c + 4 (lane / 16) + 2 r, + 1; returns the
-// maximum |sum| before the scaling by c_h.
-__device__ __forceinline__ float hadamard128_mfma(const u32x4* buf, const HadOperand& ha, float c_h, int lane,
+// maximum |sum| before the scaling by c_h.  `in_r` = RqLaneAddr::in_r.
+__device__ __forceinline__ float hadamard128_mfma(const char* img, int in_r, const HadOperand& ha, float c_h,
                                                   uint32_t (&yw)[8][2]) {
   FPQ_PHASE("mfma");
-  lane = rq_opaque(lane);
-  const int g = lane & 15, quarter = lane >> 4;
   rq_f4_t acc[2][4];
   const rq_f4_t zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int p = 4 * s + quarter;
-    const rq_h8_t b = __builtin_bit_cast(rq_h8_t, buf[p * 16 + (g ^ p)]);
+    const rq_h8_t b = __builtin_bit_cast(rq_h8_t, *(const u32x4*)(img + in_r + 64 * s));
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rq_h8_t, ha.a[u]), b, zero, 0, 0, 0);
@@ -136,24 +173,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rq_rsrc(const void* tile_ptr, 
 constexpr int kRqNt = 2;   // cache policy: non-temporal
 
 // this lane's 16 words (8-byte pieces c) into the output image, then 4 coalesced 16-byte vectors per lane out
-__device__ __forceinline__ void rq_store_tile(u32x4* buf, const uint32_t (&w)[8][2], __amdgpu_buffer_rsrc_t dst,
-                                              int lane) {
+__device__ __forceinline__ void rq_store_tile(char* img, const uint32_t (&w)[8][2], __amdgpu_buffer_rsrc_t dst,
+                                              const RqLaneAddr& la) {
   FPQ_PHASE("store_tile");
-  lane = rq_opaque(lane);
-  const int g = lane & 15, quarter = lane >> 4;
-  u32x2* b2 = (u32x2*)buf;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int pc = 2 * c + (quarter >> 1);
-    b2[(g * 16 + (pc ^ g)) * 2 + (quarter & 1)] = u32x2{w[c][0], w[c][1]};
-  }
+  for (int c = 0; c < 8; ++c) *(u32x2*)(img + la.out_w + 32 * c) = u32x2{w[c][0], w[c][1]};
   __builtin_amdgcn_wave_barrier();
-  lane = rq_opaque(lane);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int gg = 4 * i + (lane >> 4), pc = lane & 15;
-    const u32x4 o = buf[gg * 16 + (pc ^ gg)];
-    __builtin_amdgcn_raw_buffer_store_b128(o, dst, lane * 16 + i * 1024, 0, kRqNt);
+    const u32x4 o = *(const u32x4*)(img + la.out_r + i * (4 * kRqOutStride));
+    __builtin_amdgcn_raw_buffer_store_b128(o, dst, la.lane16 + i * 1024, 0, kRqNt);
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -293,7 +322,7 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
                                                                                  int64_t n_vec, RotArgs r, Lut16Args a,
                                                                                  Lut16Tab tab) {
   __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];
-  __shared__ u32x4 xpose[kBlock / 64][kRqTileVec];   // 4 KiB per wavefront, private to it
+  __shared__ u32x4 xpose[kBlock / 64][kRqImageVec];   // 4.5 KiB per wavefront, private to it
 #ifndef FPQ_ROT_PREFETCH16
 #define FPQ_ROT_PREFETCH16 1
 #endif
@@ -304,7 +333,8 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
   constexpr int VW = sizeof(Tin) == 2 ? 1 : 2;           // 16-byte words per input vector
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  u32x4* buf = xpose[wave];
+  char* img = (char*)xpose[wave];
+  u32x4* buf = xpose[wave];                        // the code-emitting epilogues keep their own (smaller) layouts
   const int n_tiles = (int)((n_vec + kRqTileVec - 1) / kRqTileVec);
   const int tile_step = (int)gridDim.x * (kBlock / 64);
   int tile = (int)blockIdx.x * (kBlock / 64) + wave;
@@ -336,8 +366,9 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
     const int64_t base_vec = (int64_t)tile * kRqTileVec;
     const int rem = rem_of(tile);
     if (!PREFETCH) rq_load_tile<Tin>(in_rsrc(tile), lane, raw);
-    // 1. + 2.: (smooth,) sign, into the B-operand image
-    const int lane_w = rq_opaque(lane);
+    // 1. + 2.: (smooth,) sign, into the operand image (lane-constant addresses are rebuilt per phase from an opaque
+    // lane index: two or three instructions, instead of registers held across the whole tile at 6 wavefronts per SIMD)
+    const RqLaneAddr la1 = rq_lane_addr(rq_opaque(lane));
     if constexpr (sizeof(Tin) == 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -349,10 +380,10 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
           for (int k = 0; k < 4; ++k)
             w[k] = f2h(h2f(w[k] & 0xFFFFu) * sp[2 * k]) | (f2h(h2f(w[k] >> 16) * sp[2 * k + 1]) << 16);
         }
-        const int g = 4 * i + (lane_w >> 4), p = lane_w & 15;
-        buf[p * 16 + (g ^ p)] = u32x4{w[0] ^ sx[0], w[1] ^ sx[1], w[2] ^ sx[2], w[3] ^ sx[3]};
+        *(u32x4*)(img + la1.in_w + i * (4 * kRqInStride)) = u32x4{w[0] ^ sx[0], w[1] ^ sx[1], w[2] ^ sx[2], w[3] ^ sx[3]};
       }
     } else {            // fp32 producer output: h = half(x * s), half-chunks of 8 bytes
+      const int lane_w = rq_opaque(lane);
       const int hsel = lane_w & 1, k2 = lane_w >> 1;
       const uint32_t sb2 = (r.sign[(k2 & 15) >> 2] >> (((k2 & 15) & 3) * 8 + 4 * hsel)) & 0xFu;
       const uint32_t sy[2] = {((sb2 & 1u) << 15) | (((sb2 >> 1) & 1u) << 31), (((sb2 >> 2) & 1u) << 15) | (((sb2 >> 3) & 1u) << 31)};
@@ -365,8 +396,8 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
 #pragma unroll
           for (int k = 0; k < 4; ++k) f[k] *= sp[k];
         }
-        const int g = 2 * n + (k2 >> 4), p = k2 & 15;
-        ((u32x2*)buf)[(p * 16 + (g ^ p)) * 2 + hsel] =
+        // half h = lane & 1 of chunk 32 n + lane / 2 = chunk (lane / 2) % 16 of group 2 n + lane / 32
+        *(u32x2*)(img + la1.in_w8 + n * (2 * kRqInStride)) =
             u32x2{(f2h(f[0]) | (f2h(f[1]) << 16)) ^ sy[0], (f2h(f[2]) | (f2h(f[3]) << 16)) ^ sy[1]};
       }
     }
@@ -376,9 +407,9 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
 
     // 3. + 4.
     uint32_t yw[8][2];
-    const float mf = hadamard128_mfma(buf, ha, r.c_h, lane, yw);
+    const float mf = hadamard128_mfma(img, rq_lane_addr(rq_opaque(lane)).in_r, ha, r.c_h, yw);
     __builtin_amdgcn_wave_barrier();
-    if (EMIT) rq_store_tile(buf, yw, rq_rsrc(rot_out + base_vec, rem * 16), lane);
+    if (EMIT) rq_store_tile(img, yw, rq_rsrc(rot_out + base_vec, rem * 16), rq_lane_addr(rq_opaque(lane)));
     // rounding is monotonic: half(c_h max |sum|) == max |half(c_h sum)|.  v_max drops NaN where the maximum of the integer patterns
     // (and torch's amax) keeps it; every output of a group contains every input, so one non-finite input makes ALL
     // outputs of the group non-finite: one output per lane tells whether the (rare) pattern scan is needed.
@@ -410,7 +441,7 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
           yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
         }
       // 5.
-      rq_store_tile(buf, yw, rq_rsrc(out + base_vec, rem * 16), lane);
+      rq_store_tile(img, yw, rq_rsrc(out + base_vec, rem * 16), rq_lane_addr(rq_opaque(lane)));
     }
   };
   if (tile < n_tiles) {

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where a wavefront's row time goes in the adaLN producer: needs a library built with -DFPQ_ADALN_STAMPS
+(tools/build_variant.sh stamps -DFPQ_ADALN_STAMPS), whose kernel sums s_memtime differences per phase and wavefront.
+usage: adaln_stamps.py tools/ab/libstamps.so [fp16|fp32] [B L C]"""
+import ctypes
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fpqvar_amd import _lib, rotation as rot
+
+lib = ctypes.CDLL(os.path.abspath(sys.argv[1]))
+for name, (res, args) in _lib._SIGS.items():
+    if hasattr(lib, name):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+dt = sys.argv[2] if len(sys.argv) > 2 else "fp16"
+B, L, C = (int(a) for a in sys.argv[3:6]) if len(sys.argv) > 5 else (100, 655, 1920)
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn(B, L, C, device=dev, generator=g)
+x = x.half() if dt == "fp16" else x
+scale = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
+shift = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
+s = torch.rand(C, device=dev, generator=g) + 0.5
+out = torch.empty(B, L, C, dtype=torch.float16, device=dev)
+stamps = torch.zeros(10 * (1 << 19), dtype=torch.int64, device=dev)
+mask = rot._mask_arg(None)
+for it in range(30):
+    if it == 29:
+        stamps.zero_()
+    _lib.check(lib.fpq_adaln_rotate_quant_rows(x.data_ptr(), out.data_ptr(), None, stamps.data_ptr(), B * L, C,
+                                               _lib.dtype_id(x.dtype), scale.data_ptr(), shift.data_ptr(), _lib.F16, L, 1e-6,
+                                               s.data_ptr(), mask, _lib.TABLE_IDS["e2m1"], _lib.stream_ptr(dev)), "stamps")
+torch.cuda.synchronize()
+st = stamps.view(-1, 10).cpu()
+st = st[st[:, 8] > 0].double()
+rows = st[:, 8].sum()
+names = ["between rows / prologue", "wait for the row (vmcnt 0)", "statistics + rstd", "modulate -> image (+ prefetch issue)",
+         "MFMA + butterfly + round", "group max + scale", "divide + level + dequant", "store tile"]
+tot = st[:, :8].sum()
+print(f"{dt} [{B}x{L}x{C}]: {int(rows)} rows on {st.shape[0]} wavefronts; {tot / rows:.0f} cycles per row and wavefront")
+for k, n in enumerate(names):
+    print(f"  {n:40s} {st[:, k].sum() / rows:8.0f} cycles per row  {100 * st[:, k].sum() / tot:5.1f} %")

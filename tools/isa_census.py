@@ -28,6 +28,26 @@ def classify(op):
     return "other"
 
 
+# Vector-pipe cycles per wave-instruction at saturation (4 wavefronts per SIMD), measured by tools/probe/valu_issue_cost.hip
+# on MI355X (profiles/r03_valu_issue_cost.txt).  What the census' "pipe" column adds up: a kernel bound by vector issue
+# takes about this many cycles per SIMD, not "instructions x 4".
+def valu_cost(op):
+    if op.startswith(("v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_cvt_scalef32_pk_fp4", "v_cvt_scalef32_pk_fp6", "v_cvt_scalef32_pk32")):
+        return 8.3
+    if op.startswith(("v_permlane", "v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")):
+        return 8.5
+    if op.startswith("v_cndmask"):
+        return 4.3          # (the probe's vcc form read 23 cycles: not understood, not used here)
+    if op.startswith("v_pk_") and any(t in op for t in ("_f16", "add_u16", "add_i16")):
+        return 4.85
+    if "_dpp" in op or "_sdwa" in op or op.startswith(("v_pk_", "v_fma_mix_f32", "v_max", "v_min", "v_med3", "v_dot2", "v_perm_b32", "v_bfe_",
+                                                      "v_lshl_or", "v_lshl_add", "v_add3", "v_and_or", "v_or3", "v_xad", "v_cvt_", "v_alignbit",
+                                                      "v_mad_", "v_mul_lo", "v_mul_hi", "v_mul_u32", "v_readfirstlane", "v_cmp", "v_mbcnt", "v_bcnt",
+                                                      "v_ashrrev_i64", "v_lshlrev_b64", "v_lshl_add_u64", "v_mov_b64")):
+        return 4.4
+    return 2.5
+
+
 def kernel_body(lines, needle):
     start = None
     for i, l in enumerate(lines):
@@ -75,6 +95,10 @@ def main():
         key = (cur, phase if phases else "-")
         blocks.setdefault(key, collections.Counter())[classify(op)] += 1
         blocks[key]["op:" + op] += 1
+        if classify(op) == "VALU":
+            blocks[key]["pipe"] += valu_cost(op)
+        elif classify(op) == "MFMA":
+            blocks[key]["pipe"] += 8.0      # an MFMA holds the SIMD's vector issue for 8 of its 16 cycles
         if op.startswith(("s_cbranch", "s_branch")):      # the fall-through part is a block of its own
             nsplit[cur.split("+")[0]] += 1
             cur = cur.split("+")[0] + "+" + str(nsplit[cur.split("+")[0]])
@@ -83,7 +107,8 @@ def main():
         n = sum(v for k, v in c.items() if not k.startswith("op:"))
         if n < 8 and not phases:
             continue
-        print(f"{blk:14s} {ph:14s} " + " ".join(f"{k}={c[k]}" for k in ("VALU", "MFMA", "LDS", "VMEM", "SALU", "WAIT") if c[k]))
+        print(f"{blk:14s} {ph:14s} " + " ".join(f"{k}={c[k]}" for k in ("VALU", "MFMA", "LDS", "VMEM", "SALU", "WAIT") if c[k]) +
+              (f"  pipe~{c['pipe']:.0f}cyc" if c["pipe"] else ""))
         for k, v in c.items():
             tot[k] += v
     if phases:
@@ -95,7 +120,8 @@ def main():
                 d[k] += v
         print("\nper phase, whole kernel (row-loop phases appear twice: two register sets):")
         for ph, c in per.items():
-            print(f"  {ph:24s} " + " ".join(f"{k}={c[k]}" for k in ("VALU", "MFMA", "LDS", "VMEM", "SALU", "WAIT") if c[k]))
+            print(f"  {ph:24s} " + " ".join(f"{k}={c[k]}" for k in ("VALU", "MFMA", "LDS", "VMEM", "SALU", "WAIT") if c[k]) +
+                  (f"  pipe~{c['pipe']:.0f}cyc" if c["pipe"] else ""))
     if "--ops" in sys.argv:
         want = [a for a in sys.argv[3:] if a.startswith(".LBB") or a.startswith("phase=")]
         agg = collections.Counter()

@@ -7,7 +7,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from fpqvar_amd import ops, quant_utils as qu, rotation as rot  # noqa: E402
+from fpqvar_amd import _lib, ops, quant_utils as qu, rotation as rot  # noqa: E402
+
+if os.environ.get("FPQ_PROF_LIB"):   # a variant build of the library (tools/build_variant.sh), for A/B profiling
+    import ctypes
+    _l = ctypes.CDLL(os.path.abspath(os.environ["FPQ_PROF_LIB"]))
+    for _name, (_res, _args) in _lib._SIGS.items():
+        if hasattr(_l, _name):
+            _fn = getattr(_l, _name)
+            _fn.restype, _fn.argtypes = _res, _args
+    _lib._lib = _l
 
 which = sys.argv[1] if len(sys.argv) > 1 else "sym"
 dev = torch.device("cuda:0")

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Time adaln_rotate_quant (fp16 rows, e2m1) through a given build of the library: time_lib.py <lib.so> [B L C]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fpqvar_amd import _lib, rotation as rot
+l = ctypes.CDLL(os.path.abspath(sys.argv[1]))
+for name, (res, args) in _lib._SIGS.items():
+    if hasattr(l, name):
+        fn = getattr(l, name); fn.restype, fn.argtypes = res, args
+_lib._lib = l
+dev = torch.device("cuda:0")
+B, L, C = (int(a) for a in sys.argv[2:5]) if len(sys.argv) > 4 else (100, 655, 1920)
+xs = [torch.randn(B, L, C, device=dev).half() for _ in range(3)]
+sc = (torch.randn(B, 1, C, device=dev) * 0.3).half(); sh = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+k = 0
+def run():
+    global k; k += 1
+    return rot.adaln_rotate_quant(xs[k % 3], sc, sh, "e2m1")
+for _ in range(200): run()
+torch.cuda.synchronize()
+best = 1e9
+for _ in range(4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): run()
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) / 50 * 1e3)
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FPQ_"))
+print(f"{os.path.basename(sys.argv[1]):22s} {tag:24s} [{B}x{L}x{C}] {best:7.1f} us  frac {B*L*C*4/best/1e6/8:.3f}", flush=True)
