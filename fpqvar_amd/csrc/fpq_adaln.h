@@ -521,20 +521,6 @@ struct AdalnTiers {
   int batches[2];     // batch entries in tiers 0 and 1 (tier 2: the rest)
 };
 
-// the 8 E2M1 levels of a packed pair of normalised values, hardware rounding with the tie-breaking bias (see above)
-__device__ __forceinline__ uint32_t e2m1_levels_hw(uint32_t xn2) {
-  const float t0 = fma_h_lo(xn2, 1.0f, 0x1p-14f), t1 = fma_h_hi(xn2, 1.0f, 0x1p-14f);
-  const uint32_t code = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(xn2, t0, t1, 1.0f, 0);   // byte 0 of a dead register
-  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(code, 1.0f, 0));
-}
-__device__ __forceinline__ uint32_t pk_fma0_f16(uint32_t a, uint32_t b) {   // a * b + (+0): a -0 product becomes +0
-  const h2_t z = {(_Float16)0.0f, (_Float16)0.0f};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), z));
-}
-__device__ __forceinline__ void scale_nan_if_not_finite(RowScale16& s) {
-  if (!(s.sf < __builtin_inff())) s.s16x2 = 0x7E007E00u;
-}
-
 // 4 wavefronts per SIMD (128 registers) wherever the row fits: d30 on fp16 rows takes 96, on fp32 rows 118.  fp32 rows of
 // 17 .. 20 groups hold 40 registers of raw row and get 168 (3 wavefronts); the emitting forms are for tests and
 // calibration dumps.

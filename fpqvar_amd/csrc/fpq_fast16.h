@@ -120,19 +120,34 @@ __device__ __forceinline__ float fmaf_h_hi(uint32_t w, float b, float c) {
   return d;
 }
 
-// xn = half(x / s) for the two halves of w: 1/s travels as an unevaluated sum inv_hi + inv_lo (error ~2^-46),
-// y = fp32(x * inv_hi + x * inv_lo) is the quotient to one fp32 rounding, and the pair is converted with ONE
-// v_cvt_pk_f16_f32.  x and s carry 11-bit significands: x / s is either exactly a 12-bit number - then y IS that number
-// (it is representable, and 2^-46 away) and the fp16 tie goes to even as IEEE division's does - or it lies at least
-// 2^-22.9993 (relative) from every 12-bit number, i.e. from every fp16 rounding boundary (|2^k a - b c| >= 1 for 11-bit
-// integers a, b and a 12-bit c), twice the fp32 rounding of y.  Either way half(y) is the correctly rounded quotient -
-// torch's fp16 division (tests/test_gpu_parity.py::test_every_fp16_pair_fast_path_vs_ieee_path sweeps all 1.0e9 pairs).
-// Round 2 rounded straight to fp16 (v_fma_mixlo/hi_f16): the same values, but that instruction occupies the vector
-// pipe for 8.2 cycles against 4.3 for v_fma_mix_f32 and 4.6 for the packed conversion
-// (tools/probe/valu_issue_cost.hip, profiles/r03_valu_issue_cost.txt): 25.1 -> 21.8 cycles per pair.
+// xn = half(x / s) for the two halves of w, as far as any table can tell: y = fp32(x * inv), inv = RN32(1 / s), then ONE
+// v_cvt_pk_f16_f32 for the pair.
+//   * inv is the correctly rounded reciprocal (row_scale16: one Newton step on v_rcp_f32 leaves (1/s)(1 - 2^-44), and
+//     2^k / b for an 11-bit b is further than that from every fp32 rounding boundary), the product is rounded once:
+//     |y / (x/s) - 1| <= (1 + 2^-24)^2 - 1 = 2^-23 + 2^-48.
+//   * What the quantizers take from xn is its bucket: the level only changes where half(x/s) crosses a rounding
+//     threshold T of the table, i.e. where x/s crosses T moved by the half fp16 ulp of the rounding to fp16: a number
+//     c / 2^p with a 12-bit ODD c (T itself has a few bits).  x = a 2^i and s = b 2^j with 11-bit a, b: x/s = c / 2^p would
+//     need a = g c for g = gcd(a, b) - impossible, c > 2047 >= a - so |x/s - c/2^p| / (x/s) = |2^q a - b c| / (2^q a) is
+//     at least 1 / (4096 * 2047) = 2^-22.9993.  2^-23 + 2^-48 < 2^-22.9993: y is on the same side of every such number
+//     as x/s, so half(y) falls into the bucket of half(x/s) - it may be the neighbouring fp16 value INSIDE a bucket,
+//     which no caller can observe (they all go xn -> bucket -> level).
+//   * The margin is 0.05 %, so the argument is backed by exhaustion: tests/test_gpu_parity.py::
+//     test_every_fp16_pair_fast_path_vs_ieee_path pushes all 1.0e9 (group maximum, element) pairs through this path and
+//     through the IEEE division for seven table configurations, and ..._hw_levels the same pairs through the
+//     hardware-level form of the producers.
+// Round 2 carried 1/s as inv + inv_lo and rounded x * inv + x * inv_lo straight to fp16 (the exact quotient, 25 cycles of
+// the vector pipe per pair: v_fma_mixlo/hi_f16 cost 8.2 each, tools/probe/valu_issue_cost.hip); this form: 13.
+// -DFPQ_DIV_WITH_LO restores the two-term reciprocal (21.8 cycles per pair) for A/B runs.
 __device__ __forceinline__ uint32_t div_pair16(uint32_t w, float ih0, float il0, float ih1, float il1) {
+#ifdef FPQ_DIV_WITH_LO
   const float t0 = mul_h_lo(w, il0), t1 = mul_h_hi(w, il1);
   return f2h2(fmaf_h_lo(w, ih0, t0), fmaf_h_hi(w, ih1, t1));
+#else
+  (void)il0;
+  (void)il1;
+  return f2h2(mul_h_lo(w, ih0), mul_h_hi(w, ih1));
+#endif
 }
 
 // the two table entries of a packed pair of bucket patterns as ONE packed register: byte offsets straight from the
@@ -182,13 +197,32 @@ __device__ __forceinline__ void lut16_fill(uint16_t* lut, const Lut16Args& a) {
   }
 }
 
+// E2M1 levels from the FP4 conversion hardware instead of the bucket table:  level = f16_fp4(fp4_f32(float(xn) + 2^-14)).
+// The reference's scan sends a tie to the LARGER value on both sides of zero (quant/quant_kernel.cu:25-37); the
+// conversion rounds to nearest even.  fp16 values >= 0.25 are multiples of 2^-12 and every rounding boundary of E2M1 is a
+// multiple of 0.25, so adding 2^-14 - exact in fp32 - removes every tie and sends it to the side the scan picks; below
+// 0.25 nothing is a boundary.  tools/probe/cvt_fp4_probe.hip checks all 63 488 finite fp16 values against the scan on the
+// hardware (profiles/r03_cvt_fp4_probe.txt), and the exhaustive (maximum, element) sweep of tests/test_gpu_parity.py runs
+// through this path.  Levels that round to zero from below come back as -0: the dequantizing multiply is an fma with +0.
+// Non-finite quotients (which saturate to 6 here, where the scan gives 0) only occur under a non-finite scale, and that
+// is replaced by NaN (the reference's 0 * inf): scale_nan_if_not_finite.  No table, no LDS traffic.
+__device__ __forceinline__ uint32_t e2m1_levels_hw(uint32_t xn2) {
+  const float t0 = fmaf_h_lo(xn2, 1.0f, 0x1p-14f), t1 = fmaf_h_hi(xn2, 1.0f, 0x1p-14f);
+  const uint32_t code = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(xn2, t0, t1, 1.0f, 0);   // byte 0 of a dead register
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(code, 1.0f, 0));
+}
+__device__ __forceinline__ uint32_t pk_fma0_f16(uint32_t a, uint32_t b) {   // a * b + (+0): a -0 product becomes +0
+  const h2_t z = {(_Float16)0.0f, (_Float16)0.0f};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), z));
+}
 // Quantize the 8 halves of one 16-byte vector.  s16x2 = scale replicated in both halves; inv_hi + inv_lo = 1 / scale
 // (0 for a zero scale).  In DUAL mode each element picks the negative or positive side's scale.
 __device__ __forceinline__ uint32_t fbits16(float f) { return __builtin_bit_cast(uint32_t, f); }
 
-template <bool DUAL>
+template <bool DUAL, bool HW4 = false>
 __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut, int shift, float ih_n, float il_n,
                                              uint32_t s16x2_n, float ih_p, float il_p, uint32_t s16x2_p) {
+  static_assert(!(DUAL && HW4), "hardware levels: the symmetric E2M1 table only");
   u32x4 o;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -203,8 +237,12 @@ __device__ __forceinline__ u32x4 quant_vec16(const u32x4& w, const uint16_t* lut
       sc = (s16x2_n & mp) | (s16x2_p & ~mp);
     }
     const uint32_t rb = div_pair16(wk, h0, l0, h1, l1);
-    const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
-    o[k] = pk_mul_f16(lut_pair16(lut, u, shift), sc);
+    if constexpr (HW4) {
+      o[k] = pk_fma0_f16(e2m1_levels_hw(rb), sc);
+    } else {
+      const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
+      o[k] = pk_mul_f16(lut_pair16(lut, u, shift), sc);
+    }
   }
   return o;
 }
@@ -296,6 +334,10 @@ __device__ __forceinline__ RowScale16 row_scale16(uint32_t amax_bits, float g, f
   return r;
 }
 
+__device__ __forceinline__ void scale_nan_if_not_finite(RowScale16& s) {
+  if (!(s.sf < __builtin_inff())) s.s16x2 = 0x7E007E00u;
+}
+
 // dual format: a non-finite scale on either side poisons the whole row (0 * inf = NaN
 // is added to every element by the reference's `q_neg*s_neg + q_pos*s_pos`)
 __device__ __forceinline__ void dual_poison(RowScale16& n, RowScale16& p) {
@@ -385,11 +427,16 @@ inline void lut16_build_host(uint16_t* lut, const Lut16Args& a) {
 // workgroups are dispatched in address order, so the chip sweeps the tensor front
 // to back.  All U loads are issued before the table is staged and the barrier.
 // ---------------------------------------------------------------------------------
-template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true>
+// HW4: E2M1 levels from the conversion hardware (above) - no table, no LDS, no barrier.
+template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true, bool HW4 = false>
 __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4* __restrict__ x,
                                                                    u32x4* __restrict__ out, int64_t n_vec,
                                                                    Lut16Args a, Lut16Tab tab) {
-  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
+  uint16_t* lut = nullptr;
+  if constexpr (!HW4) {
+    __shared__ __attribute__((aligned(16))) uint16_t lut_s[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
+    lut = lut_s;
+  }
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   bool first = true;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -402,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
       live[u] = v < n_vec;
       raw[u] = live[u] ? (NTL ? __builtin_nontemporal_load(x + v) : x[v]) : u32x4{0, 0, 0, 0};
     }
-    if (first) {
+    if (first && !HW4) {
       if (TAB_ARG) {
         lut16_stage(lut, tab, a.shift);
       } else {
@@ -414,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       u32x4 o;
-      if (DUAL) {
+      if constexpr (DUAL) {
         uint32_t un = 0, sg = 0, mn, mp;
         dual_max_acc(raw[u], un, sg);
         dual_max_finish(un, sg, mn, mp);
@@ -431,7 +478,8 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
       } else {
         uint32_t m = row_max_dpp<LPR>(vec_absmax16(raw[u]));
         RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-        o = quant_vec16<false>(raw[u], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
+        if constexpr (HW4) scale_nan_if_not_finite(s);
+        o = quant_vec16<false, HW4>(raw[u], lut, a.shift, s.inv, s.inv_lo, s.s16x2, 0.f, 0.f, 0u);
       }
       if (live[u]) {
         if (NTS) __builtin_nontemporal_store(o, out + v0 + u * kBlock);

@@ -914,6 +914,12 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
                          (u32x4*)out, n_vec, args, h.tab);
     return check_launch();
   };
+  // the headline shape - E2M1, groups of 128 - takes its levels from the FP4 conversion hardware (fpq_fast16.h); FPQ_NO_HW4
+  // (read at every call: the exhaustive test sweeps both forms in one process) keeps the bucket table
+  if constexpr (!DUAL) {
+    if (lpr == 16 && neg_id == FPQ_E2M1 && pos_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4"))
+      return go(rows16_lut_subwave_kernel<16, false, U, true, NTL, NTS, true>, rows16_lut_subwave_kernel<16, false, U, true, NTL, NTS, true>);
+  }
 #define FPQ_FAST16_CASE(L) \
   case L: return go(rows16_lut_subwave_kernel<L, DUAL, U, true, NTL, NTS>, rows16_lut_subwave_kernel<L, DUAL, U, false, NTL, NTS>);
   switch (lpr) {
@@ -959,8 +965,11 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
 #define FPQ_ROT_MFMA(EMIT, SMOOTH, ...)                                                                             \
   hipLaunchKernelGGL((rotate_quant_mfma_kernel<Tin, EMIT, SMOOTH, ##__VA_ARGS__>), mgrid, dim3(kBlock), lds, st, x, \
                      (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, tab)
+    const bool hw4 = table_id == FPQ_E2M1 && !code_scales && !getenv("FPQ_NO_HW4");   // E2M1 values: hardware levels
     if (code_scales) { if (smooth) FPQ_ROT_MFMA(false, true, true); else FPQ_ROT_MFMA(false, false, true); }
+    else if (rot_out && hw4) { if (smooth) FPQ_ROT_MFMA(true, true, false, true); else FPQ_ROT_MFMA(true, false, false, true); }
     else if (rot_out) { if (smooth) FPQ_ROT_MFMA(true, true); else FPQ_ROT_MFMA(true, false); }
+    else if (hw4) { if (smooth) FPQ_ROT_MFMA(false, true, false, true); else FPQ_ROT_MFMA(false, false, false, true); }
     else { if (smooth) FPQ_ROT_MFMA(false, true); else FPQ_ROT_MFMA(false, false); }
 #undef FPQ_ROT_MFMA
     return check_launch();
@@ -1008,12 +1017,13 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       // (profiles/r02_small_steps.json).  FPQ_ADALN_ROWS=n: n rows per workgroup everywhere; FPQ_ADALN_TAIL=rows: how many
       // rows at the end of the grid go to each of the two finer tiers (default 8192: two generations of resident
       // workgroups at 4 rows and one at 8).
-      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 32768 ? 16 : rows >= 8192 ? 8 : 4);
+      // (third generation, large launches: 12 rows on fp16 rows, 8 on fp32 rows - profiles/r03_adaln_partition.txt)
+      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 32768 ? (adaln_butterfly ? 16 : X32 ? 8 : 12) : rows >= 8192 ? 8 : 4);
       if (rows_per_wg < 1) rows_per_wg = 1;
       const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
       AdalnTiers tiers = {};
-      static const int tail_rows = FPQ_ENV("FPQ_ADALN_TAIL") ? atoi(FPQ_ENV("FPQ_ADALN_TAIL")) : 8192;
+      static const int tail_rows = FPQ_ENV("FPQ_ADALN_TAIL") ? atoi(FPQ_ENV("FPQ_ADALN_TAIL")) : 0;
       int64_t nb2 = 0, nb1 = 0;
       if (!rows_env && !adaln_butterfly && tail_rows > 0 && rows_per_wg > 4) {
         nb2 = (tail_rows + L - 1) / L;                                   // batch entries cut into chunks of 4 rows
@@ -1033,7 +1043,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       const dim3 g3((unsigned)n_wg3);
       const size_t lds2 = 0;   // table, modulation planes and images live in static LDS
       // E2M1 values per group: levels from the FP4 conversion hardware, no table (fpq_adaln.h)
-      const bool hw4 = table_id == FPQ_E2M1 && !code_scales && !token_mode && !FPQ_ENV("FPQ_ADALN_NO_HW4");
+      const bool hw4 = table_id == FPQ_E2M1 && !code_scales && !token_mode && !getenv("FPQ_NO_HW4");
       static const bool tight_ok = FPQ_ADALN_TIGHT && !FPQ_ENV("FPQ_ADALN_NO_TIGHT");
       static const bool nw8 = FPQ_ENV("FPQ_ADALN_NW8") != nullptr;
 #define FPQ_ADALN3(M, CODES, EMIT, TOKEN, HW4, TIGHT)                                                                  \

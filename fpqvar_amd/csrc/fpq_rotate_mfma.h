@@ -101,23 +101,36 @@ struct HadOperand {
   u32x4 a[2];   // [u]: output bit 4
 };
 
+// The A operands are lane constants: (-1)^(popcount(i & 7 & k') + i3 q0 + u q1) as +-1.0 pairs, i = lane % 16, quarter
+// q = lane / 16, eight k' per register quad.  Built at compile time into a 2 KiB table in the code object (immutable):
+// a wavefront fetches its 32 bytes per lane with two loads at kernel start instead of ~30 vector instructions - which in
+// the adaLN producer are paid per workgroup, i.e. per 3 - 4 rows.
+struct HadTable {
+  uint32_t w[64][8];
+};
+constexpr uint32_t had_parity(uint32_t v) { return (v ^ (v >> 1) ^ (v >> 2)) & 1u; }
+constexpr HadTable make_had_table() {
+  HadTable t = {};
+  for (int lane = 0; lane < 64; ++lane) {
+    const uint32_t i = (uint32_t)lane & 15u, quarter = (uint32_t)lane >> 4;
+    const uint32_t f0 = ((i >> 3) & quarter & 1u) ? 0x80008000u : 0u;   // i3 q0
+    const uint32_t f1 = f0 ^ ((quarter & 2u) ? 0x80008000u : 0u);       // + q1 for u = 1
+    for (uint32_t w = 0; w < 4; ++w) {
+      const uint32_t b0 = had_parity((i & 7u) & (2u * w)), b1 = had_parity((i & 7u) & (2u * w + 1u));
+      const uint32_t base = 0x3C003C00u ^ (b0 << 15) ^ (b1 << 31);      // +-1.0, +-1.0
+      t.w[lane][w] = base ^ f0;
+      t.w[lane][4 + w] = base ^ f1;
+    }
+  }
+  return t;
+}
+__device__ const HadTable kHadTable = make_had_table();
+
 __device__ __forceinline__ HadOperand had_operand(int lane) {
-  const int i = lane & 15, quarter = lane >> 4;
-  u32x4 base;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const uint32_t b0 = (uint32_t)__builtin_popcount((i & 7) & (2 * w)) & 1u;
-    const uint32_t b1 = (uint32_t)__builtin_popcount((i & 7) & (2 * w + 1)) & 1u;
-    base[w] = 0x3C003C00u ^ (b0 << 15) ^ (b1 << 31);          // +-1.0, +-1.0
-  }
-  const uint32_t f0 = ((i >> 3) & quarter & 1) ? 0x80008000u : 0u;   // i3 q0
-  const uint32_t f1 = f0 ^ ((quarter & 2) ? 0x80008000u : 0u);       // + q1 for u = 1
+  const u32x4* p = (const u32x4*)kHadTable.w[lane];
   HadOperand h;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    h.a[0][w] = base[w] ^ f0;
-    h.a[1][w] = base[w] ^ f1;
-  }
+  h.a[0] = p[0];
+  h.a[1] = p[1];
   return h;
 }
 
@@ -315,13 +328,19 @@ __device__ __forceinline__ void rq_store_codes6(u32x4* buf, const uint32_t (&yw)
 
 // CODES: `out` receives packed E2M1 codes (4 bytes per 8 elements), r.code_scales one fp16 scale per group; the staged
 // table is the code table
-template <typename Tin, bool EMIT, bool SMOOTH, bool CODES = false>
+// HW4 (values, E2M1): levels from the FP4 conversion hardware (fpq_fast16.h) - no table lookups
+template <typename Tin, bool EMIT, bool SMOOTH, bool CODES = false, bool HW4 = false>
 __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kernel(const void* __restrict__ xv,
                                                                                  u32x4* __restrict__ out,
                                                                                  u32x4* __restrict__ rot_out,
                                                                                  int64_t n_vec, RotArgs r, Lut16Args a,
                                                                                  Lut16Tab tab) {
-  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];
+  static_assert(!HW4 || !CODES, "hardware levels: fake-quantized values only");
+  uint16_t* lut = nullptr;
+  if constexpr (!HW4) {
+    __shared__ __attribute__((aligned(16))) uint16_t lut_s[kLutLdsEntries];
+    lut = lut_s;
+  }
   __shared__ u32x4 xpose[kBlock / 64][kRqImageVec];   // 4.5 KiB per wavefront, private to it
 #ifndef FPQ_ROT_PREFETCH16
 #define FPQ_ROT_PREFETCH16 1
@@ -353,8 +372,10 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
 
   RqRaw<Tin> raw;
   if (PREFETCH) rq_load_tile<Tin>(in_rsrc(tile), lane, raw);
-  lut16_stage(lut, tab, a.shift);
-  __syncthreads();   // the table (workgroup-wide, once); everything below is private to the wavefront
+  if constexpr (!HW4) {
+    lut16_stage(lut, tab, a.shift);
+    __syncthreads();   // the table (workgroup-wide, once); everything below is private to the wavefront
+  }
   const HadOperand ha = had_operand(lane);
 
   // The body as a lambda, run once in front of the loop: the compiler merges its s_waitcnt bookkeeping over the edges
@@ -427,7 +448,8 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
       sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
       m = sw[0] > sw[1] ? sw[0] : sw[1];
     }
-    const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+    RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+    if constexpr (HW4) scale_nan_if_not_finite(s);
     if constexpr (CODES) {
       rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + base_vec, rem * 4),
                      rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), lane);
@@ -437,8 +459,12 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const uint32_t rb = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
-          const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
-          yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
+          if constexpr (HW4) {
+            yw[c][rr] = pk_fma0_f16(e2m1_levels_hw(rb), s.s16x2);
+          } else {
+            const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));
+            yw[c][rr] = pk_mul_f16(rq_lut_pair(lut, u, a.shift), s.s16x2);
+          }
         }
       // 5.
       rq_store_tile(img, yw, rq_rsrc(out + base_vec, rem * 16), rq_lane_addr(rq_opaque(lane)));
