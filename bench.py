@@ -299,6 +299,34 @@ def other_kernels(dev):
         hbm("adaln_rotate_quant_e2m1_fp32rows_65500x1920",
             timed(lambda: rot.adaln_rotate_quant(nxt(xf), scale, shift, "e2m1", smooth=s)), B * L * COLS * 6)
 
+    def operands():
+        # The same producers emitting what the matrix-core GEMMs consume instead of fake-quantized values:
+        # FP4: packed E2M1 codes + one fp16 scale per group of 128 = 0.516 B written per element; per token: E4M3 bytes
+        # (1 B) or dense 6-bit codes (0.75 B) + one fp16 scale per row.  Denominator = bytes read + bytes written.
+        xs = [torch.randn(ROWS, COLS, device=dev, generator=g).half() for _ in range(3)]
+        n = xs[0].numel()
+        wr4 = 0.5 + 2.0 / GROUP
+        hbm("rotate_quant_codes_mx_fp16_65536x1920", timed(lambda: rot.rotate_quant_mx(nxt(xs))), n * (2 + wr4))
+        B, L = 100, 655
+        na = B * L * COLS
+        xa = [xs[i][:B * L].view(B, L, COLS) for i in range(3)]
+        scale = (torch.randn(B, 1, COLS, device=dev, generator=g) * 0.3).half()
+        shift = (torch.randn(B, 1, COLS, device=dev, generator=g) * 0.3).half()
+        s = torch.rand(COLS, device=dev, generator=g) + 0.5
+        hbm("adaln_rotate_quant_codes_mx_fp16_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant_mx(nxt(xa), scale, shift, smooth=s)), na * (2 + wr4))
+        hbm("adaln_rotate_quant_token_codes_fp8_fp16_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant_token(nxt(xa), scale, shift, "e2m3", smooth=s, emit="fp8")), na * (2 + 1) + B * L * 2)
+        hbm("adaln_rotate_quant_token_codes_fp6_fp16_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant_token(nxt(xa), scale, shift, "e2m3", smooth=s, emit="fp6")), na * (2 + 0.75) + B * L * 2)
+        del xs
+        xf = [xa[i].float() for i in range(2)]
+        del xa
+        hbm("adaln_rotate_quant_codes_mx_fp32rows_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant_mx(nxt(xf), scale, shift, smooth=s)), na * (4 + wr4))
+        hbm("adaln_rotate_quant_token_codes_fp8_fp32rows_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant_token(nxt(xf), scale, shift, "e2m3", smooth=s, emit="fp8")), na * (4 + 1) + B * L * 2)
+
     def weights():
         ws = [torch.randn(ROWS // 2, COLS, device=dev, generator=g) * 0.02 for _ in range(3)]
         n = ws[0].numel()
@@ -321,6 +349,7 @@ def other_kernels(dev):
     guarded("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4)
     guarded("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6)
     guarded("activations_fp16_65536x1920", act16)
+    guarded("operand_emitting_producers_65536x1920", operands)
     guarded("weights_fp32_32768x1920", weights)
     guarded("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", consumers)
     return out

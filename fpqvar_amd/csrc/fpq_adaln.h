@@ -560,7 +560,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
                                                               int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a,
                                                               Lut16Tab tab, AdalnTiers tiers) {
   static_assert(MAXC >= 1 && MAXC <= 5, "rows of at most 20 groups");
-  static_assert(!HW4 || (!CODES && !TOKEN), "hardware E2M1 levels: fake-quantized values per group only");
+  static_assert(!HW4 || !TOKEN, "hardware E2M1 levels / codes: per group only");
   static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 32 KiB form: fp16 rows of 15 groups, no table");
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   static_assert(NW == 4 || (NW == 8 && TIGHT), "8 wavefronts per workgroup: the 32 KiB form only");
@@ -939,10 +939,14 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
         }
       }
     } else if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
-      rq_store_codes((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
-                     rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
+      if constexpr (HW4)
+        rq_store_codes_hw(img, yw, s, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
+                          rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
+      else
+        rq_store_codes((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
+                       rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
       if constexpr (MAXC == 5) {
-        const uint32_t cd = codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
+        const uint32_t cd = HW4 ? codes_vec16_hw(y1, s1.inv) : codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
         if (slot_live) {
           ((uint32_t*)out)[slot_at] = cd;
           if ((lane & 15) == 0) r.code_scales[slot_at >> 4] = (uint16_t)(s1.s16x2 & 0xFFFFu);

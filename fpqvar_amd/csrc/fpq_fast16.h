@@ -211,6 +211,28 @@ __device__ __forceinline__ uint32_t e2m1_levels_hw(uint32_t xn2) {
   const uint32_t code = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(xn2, t0, t1, 1.0f, 0);   // byte 0 of a dead register
   return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(code, 1.0f, 0));
 }
+// ... and the hardware E2M1 CODES themselves (sign-magnitude nibbles, the operand format of the FP4 matrix cores,
+// fpq_gemm_fp4.h): the two codes of a packed pair land in byte SEL of `acc`; four calls fill a register with the codes of
+// 8 consecutive elements, low nibble first.  e2m1_codes_canon turns the -0 codes (negative values that round to zero)
+// into +0, as the code table of the table-driven form has them (decode bit-equal to the fake-quantized values).
+template <int SEL>
+__device__ __forceinline__ uint32_t e2m1_codes_hw(uint32_t acc, uint32_t xn2) {
+  const float t0 = fmaf_h_lo(xn2, 1.0f, 0x1p-14f), t1 = fmaf_h_hi(xn2, 1.0f, 0x1p-14f);
+  return __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(acc, t0, t1, 1.0f, SEL);
+}
+__device__ __forceinline__ uint32_t e2m1_codes_canon(uint32_t w) {
+  const uint32_t t = (w & 0x77777777u) + 0x77777777u;   // bit 3 of a nibble: its magnitude is not zero (no carry between nibbles)
+  return w & (t | 0x77777777u);
+}
+// the 8 codes of one 16-byte vector (cf. codes_vec16)
+__device__ __forceinline__ uint32_t codes_vec16_hw(const u32x4& w, float inv) {
+  uint32_t c = 0;
+  c = e2m1_codes_hw<0>(c, div_pair16(w[0], inv, 0.f, inv, 0.f));
+  c = e2m1_codes_hw<1>(c, div_pair16(w[1], inv, 0.f, inv, 0.f));
+  c = e2m1_codes_hw<2>(c, div_pair16(w[2], inv, 0.f, inv, 0.f));
+  c = e2m1_codes_hw<3>(c, div_pair16(w[3], inv, 0.f, inv, 0.f));
+  return e2m1_codes_canon(c);
+}
 __device__ __forceinline__ uint32_t pk_fma0_f16(uint32_t a, uint32_t b) {   // a * b + (+0): a -0 product becomes +0
   const h2_t z = {(_Float16)0.0f, (_Float16)0.0f};
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), z));

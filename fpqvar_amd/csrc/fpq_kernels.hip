@@ -965,8 +965,9 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
 #define FPQ_ROT_MFMA(EMIT, SMOOTH, ...)                                                                             \
   hipLaunchKernelGGL((rotate_quant_mfma_kernel<Tin, EMIT, SMOOTH, ##__VA_ARGS__>), mgrid, dim3(kBlock), lds, st, x, \
                      (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, tab)
-    const bool hw4 = table_id == FPQ_E2M1 && !code_scales && !getenv("FPQ_NO_HW4");   // E2M1 values: hardware levels
-    if (code_scales) { if (smooth) FPQ_ROT_MFMA(false, true, true); else FPQ_ROT_MFMA(false, false, true); }
+    const bool hw4 = table_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4");   // E2M1 values or FP4 operands: levels / codes from the conversion hardware
+    if (code_scales && hw4) { if (smooth) FPQ_ROT_MFMA(false, true, true, true); else FPQ_ROT_MFMA(false, false, true, true); }
+    else if (code_scales) { if (smooth) FPQ_ROT_MFMA(false, true, true); else FPQ_ROT_MFMA(false, false, true); }
     else if (rot_out && hw4) { if (smooth) FPQ_ROT_MFMA(true, true, false, true); else FPQ_ROT_MFMA(true, false, false, true); }
     else if (rot_out) { if (smooth) FPQ_ROT_MFMA(true, true); else FPQ_ROT_MFMA(true, false); }
     else if (hw4) { if (smooth) FPQ_ROT_MFMA(false, true, false, true); else FPQ_ROT_MFMA(false, false, false, true); }
@@ -1025,7 +1026,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       AdalnTiers tiers = {};
       static const int tail_rows = FPQ_ENV("FPQ_ADALN_TAIL") ? atoi(FPQ_ENV("FPQ_ADALN_TAIL")) : 0;
       int64_t nb2 = 0, nb1 = 0;
-      if (!rows_env && !adaln_butterfly && tail_rows > 0 && rows_per_wg > 4) {
+      if (!adaln_butterfly && tail_rows > 0 && rows_per_wg > 4) {
         nb2 = (tail_rows + L - 1) / L;                                   // batch entries cut into chunks of 4 rows
         if (rows_per_wg > 8) nb1 = (tail_rows + L - 1) / L;              // ... of 8 rows
         if (nb2 > n_batches) nb2 = n_batches;
@@ -1043,7 +1044,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       const dim3 g3((unsigned)n_wg3);
       const size_t lds2 = 0;   // table, modulation planes and images live in static LDS
       // E2M1 values per group: levels from the FP4 conversion hardware, no table (fpq_adaln.h)
-      const bool hw4 = table_id == FPQ_E2M1 && !code_scales && !token_mode && !getenv("FPQ_NO_HW4");
+      const bool hw4 = table_id == FPQ_E2M1 && !token_mode && !getenv("FPQ_NO_HW4");
       static const bool tight_ok = FPQ_ADALN_TIGHT && !FPQ_ENV("FPQ_ADALN_NO_TIGHT");
       static const bool nw8 = FPQ_ENV("FPQ_ADALN_NW8") != nullptr;
 #define FPQ_ADALN3(M, CODES, EMIT, TOKEN, HW4, TIGHT)                                                                  \
@@ -1052,8 +1053,8 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
     if (!adaln_butterfly) {                                                                                            \
-      if constexpr (!(CODES) && !(TOKEN)) {                                                                            \
-        if constexpr (M == 4 && !X32 && !(EMIT)) {                                                                     \
+      if constexpr (!(TOKEN)) {                                                                                        \
+        if constexpr (M == 4 && !X32 && !(EMIT) && !(CODES)) {                                                                     \
           if (hw4 && tight_ok && r.vec_per_row == 240) {   /* VAR-d30: 32 KiB of LDS, five workgroups per CU */        \
             if (nw8) {                                                                                                 \
               hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, false, false, false, false, true, true, 8>), g3,          \

@@ -260,6 +260,35 @@ __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[
   __builtin_amdgcn_wave_barrier();
 }
 
+// The same output with the codes taken from the FP4 conversion hardware (fpq_fast16.h: e2m1_codes_hw): no table, no
+// lookups, no nibble packing - the conversion writes the two codes of a pair into a byte of the lane's code registers.
+// The lane's eight 16-bit pieces (4 elements each) go to bytes 8 c + 2 quarter of its group's 64; groups are rows of 80
+// bytes in the image (20 dwords: the 64 lanes of a 2-byte write hit 32 dwords, two lanes each sharing one), every
+// address a lane constant + an immediate.
+constexpr int kRqCodeStride = 80;
+__device__ __forceinline__ void rq_store_codes_hw(char* img, const uint32_t (&yw)[8][2], const RowScale16& s,
+                                                  __amdgpu_buffer_rsrc_t codes_dst, __amdgpu_buffer_rsrc_t scales_dst,
+                                                  int lane) {
+  const int g = lane & 15, quarter = lane >> 4;
+  const int cw = g * kRqCodeStride + 2 * quarter;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {        // pieces 2 k and 2 k + 1: outputs 32 k + 4 quarter .. + 3 and 32 k + 16 + 4 quarter .. + 3
+    uint32_t w = 0;
+    w = e2m1_codes_hw<0>(w, div_pair16(yw[2 * k][0], s.inv, 0.f, s.inv, 0.f));
+    w = e2m1_codes_hw<1>(w, div_pair16(yw[2 * k][1], s.inv, 0.f, s.inv, 0.f));
+    w = e2m1_codes_hw<2>(w, div_pair16(yw[2 * k + 1][0], s.inv, 0.f, s.inv, 0.f));
+    w = e2m1_codes_hw<3>(w, div_pair16(yw[2 * k + 1][1], s.inv, 0.f, s.inv, 0.f));
+    w = e2m1_codes_canon(w);
+    *(uint16_t*)(img + cw + 16 * k) = (uint16_t)w;
+    *(uint16_t*)(img + cw + 16 * k + 8) = (uint16_t)(w >> 16);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const u32x4 o = *(const u32x4*)(img + (lane >> 2) * kRqCodeStride + (lane & 3) * 16);   // chunk lane % 4 of group lane / 4
+  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, lane * 16, 0, kRqNt);
+  if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Per-token operand outputs of the adaLN producer (one scale per row, fpq_gemm_fp8.h / fpq_gemm_fp6.h): `lut` holds the
 // code table, `s` the row's scale.  E4M3 bytes: a lane's eight pieces are one dword each, at dword 4 c + quarter of its
 // group's 32 (index xor-swizzled with bits 1 .. 3 of the group: 64 lanes, 64 banks); the tile's 2 KiB leave as two
@@ -328,14 +357,13 @@ __device__ __forceinline__ void rq_store_codes6(u32x4* buf, const uint32_t (&yw)
 
 // CODES: `out` receives packed E2M1 codes (4 bytes per 8 elements), r.code_scales one fp16 scale per group; the staged
 // table is the code table
-// HW4 (values, E2M1): levels from the FP4 conversion hardware (fpq_fast16.h) - no table lookups
+// HW4 (E2M1 values or FP4 operands): levels / codes from the FP4 conversion hardware (fpq_fast16.h) - no table lookups
 template <typename Tin, bool EMIT, bool SMOOTH, bool CODES = false, bool HW4 = false>
 __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kernel(const void* __restrict__ xv,
                                                                                  u32x4* __restrict__ out,
                                                                                  u32x4* __restrict__ rot_out,
                                                                                  int64_t n_vec, RotArgs r, Lut16Args a,
                                                                                  Lut16Tab tab) {
-  static_assert(!HW4 || !CODES, "hardware levels: fake-quantized values only");
   uint16_t* lut = nullptr;
   if constexpr (!HW4) {
     __shared__ __attribute__((aligned(16))) uint16_t lut_s[kLutLdsEntries];
@@ -450,7 +478,10 @@ __global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kerne
     }
     RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
     if constexpr (HW4) scale_nan_if_not_finite(s);
-    if constexpr (CODES) {
+    if constexpr (CODES && HW4) {
+      rq_store_codes_hw(img, yw, s, rq_rsrc((const uint32_t*)out + base_vec, rem * 4),
+                        rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), rq_opaque(lane));
+    } else if constexpr (CODES) {
       rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + base_vec, rem * 4),
                      rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), lane);
     } else {
