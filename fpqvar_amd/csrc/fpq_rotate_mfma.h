@@ -358,8 +358,10 @@ __device__ __forceinline__ void rq_store_codes6(u32x4* buf, const uint32_t (&yw)
 // CODES: `out` receives packed E2M1 codes (4 bytes per 8 elements), r.code_scales one fp16 scale per group; the staged
 // table is the code table
 // HW4 (E2M1 values or FP4 operands): levels / codes from the FP4 conversion hardware (fpq_fast16.h) - no table lookups
+// SMOOTH (the GALT vector applied in front of the rotation: 32 more floats per lane and tile in flight) takes 5 wavefronts
+// per SIMD = 96 registers: at 80 it spilled 3 - 8 of them (tests/test_no_spill.py reads every kernel's metadata).
 template <typename Tin, bool EMIT, bool SMOOTH, bool CODES = false, bool HW4 = false>
-__global__ __launch_bounds__(kBlock, FPQ_ROT_WAVES) void rotate_quant_mfma_kernel(const void* __restrict__ xv,
+__global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES) void rotate_quant_mfma_kernel(const void* __restrict__ xv,
                                                                                  u32x4* __restrict__ out,
                                                                                  u32x4* __restrict__ rot_out,
                                                                                  int64_t n_vec, RotArgs r, Lut16Args a,
