@@ -1,0 +1,272 @@
+// quant_cuda_ext.cpp - the compiled host binding of the boundary: fpqvar_amd/_native.*.so.
+//
+// The reference's `quant_cuda` is a compiled pybind extension (quant/quant.cpp:17-29) and its quant_utils.py functions are
+// Python around it.  Round 2's binding of this library was Python + ctypes: 8 us of host time per eager call against
+// ~4 us for the HIP launch itself (profiles/r02_small_steps.json) - and the early scale steps of a generation are small
+// launches.  This module is what a torch extension of the reference's kind looks like on top of the C ABI
+// (include/fpq.h, libfpq_hip.so): argument checks, output allocation, torch's current stream, ONE C call.  It exports
+//   quant(x, y) -> (z, idx)                                   quant/quant.cpp:27-29
+//   the reference-named per-group / per-token / dual functions  tr/quant_utils.py:265-282,313-330,361-378,415-452,503-646
+//   quant_rows / quant_rows_dual                               the generic forms fpqvar_amd.ops wraps
+// PyTorch is plumbing here (tensors in, tensors out, device memory, streams); no kernel and no arithmetic lives in this
+// file.  fpqvar_amd.quant_utils / quant_cuda bind these when the module is built and fall back to the ctypes path
+// otherwise (same C entry points either way; tests cover both).
+#include <torch/extension.h>
+// torch-ROCm presents its HIP devices as "cuda": the guard and stream accessors of that masquerade
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
+
+#include <array>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "fpq.h"
+
+namespace {
+
+int dtype_id(at::ScalarType t, const char* what) {
+  switch (t) {
+    case at::kHalf: return FPQ_F16;
+    case at::kFloat: return FPQ_F32;
+    case at::kDouble: return FPQ_F64;
+    default: TORCH_CHECK(false, what, ": unsupported dtype ", t);
+  }
+}
+
+void check(int status, const char* what) {
+  TORCH_CHECK(status == 0, what, ": fpq error ", status, ": ", fpq_strerror(status));
+}
+
+void require_gpu(const at::Tensor& t, const char* what) {
+  TORCH_CHECK(t.is_cuda(), what, ": expected a tensor on the GPU, got device ", t.device(),
+              " (fpqvar_amd has no CPU path; the CPU restatement lives in oracle/ for tests only)");
+}
+
+fpq_stream_t current_stream(const at::Tensor& x) {
+  return (fpq_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream();
+}
+
+// ---- quant_cuda.quant (quant/quant.cpp:17-29, quant/quant_kernel.cu:42-62) ----
+std::tuple<at::Tensor, at::Tensor> quant(const at::Tensor& x, const at::Tensor& y) {
+  require_gpu(x, "quant_nearest(x)");
+  require_gpu(y, "quant_nearest(table)");
+  TORCH_CHECK(x.scalar_type() == at::kFloat || x.scalar_type() == at::kDouble, "quant_nearest: x must be float32 or float64, got ",
+              x.scalar_type());
+  TORCH_CHECK(x.is_contiguous(), "quant_nearest: x must be contiguous");
+  TORCH_CHECK(y.device() == x.device(), "quant_nearest: table must live on x's device");
+  const int64_t k = y.numel();
+  TORCH_CHECK(k >= 1 && k <= 256, "quant_nearest: table must hold 1..256 entries, got ", k);
+  const at::Tensor tab = (y.scalar_type() == at::kFloat && y.is_contiguous() && y.dim() == 1) ? y : y.detach().reshape({-1}).to(at::kFloat).contiguous();
+  at::Tensor z = at::empty_like(x);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  check(fpq_quant_nearest(x.data_ptr(), (const float*)tab.data_ptr(), z.data_ptr(), x.numel(), (int)k,
+                          dtype_id(x.scalar_type(), "quant_nearest"), current_stream(x)), "fpq_quant_nearest");
+  // the reference's second output is allocated and never written (quant_kernel.cu:18,49): a zero-stride view of one zero
+  at::Tensor idx = at::zeros({}, x.options()).expand(x.sizes());
+  return {z, idx};
+}
+
+// ---- one scale per row of `cols` elements, symmetric table ----
+at::Tensor quant_rows(const at::Tensor& x, int64_t table_id, int64_t cols, c10::optional<at::ScalarType> out_dtype) {
+  require_gpu(x, "quant_rows");
+  TORCH_CHECK(x.scalar_type() == at::kHalf || x.scalar_type() == at::kFloat, "quant_rows: x must be float16 or float32, got ",
+              x.scalar_type());
+  const at::ScalarType od = out_dtype.value_or(x.scalar_type());
+  const int64_t n = x.numel();
+  TORCH_CHECK(cols > 0 && n % cols == 0, "quant_rows: numel ", n, " is not a multiple of the row length ", cols);
+  const at::Tensor xc = x.is_contiguous() ? x : x.contiguous();   // the reference reshapes (copying when needed) before its kernel
+  at::Tensor out = at::empty(x.sizes(), x.options().dtype(od));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  check(fpq_quant_rows(xc.data_ptr(), out.data_ptr(), n / cols, cols, (int)table_id, dtype_id(x.scalar_type(), "quant_rows"),
+                       dtype_id(od, "quant_rows"), current_stream(x)), "fpq_quant_rows");
+  return out;
+}
+
+// 8 zeroed bytes per (device, stream) for fpq_quant_rows_dual's NaN flag (include/fpq.h): the fix-up launch leaves
+// them zero, so one allocation serves every call on that stream.  A stream that is being captured gets scratch of its
+// own per capture-time call: a graph bakes the pointer in and may be replayed beside eager calls on the same stream.
+at::Tensor nan_scratch(const at::Tensor& x, fpq_stream_t st) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+    static std::mutex m;
+    static std::vector<at::Tensor> keep;   // lives as long as the graphs that reference it may
+    at::Tensor t;
+    {
+      c10::hip::HIPStreamCaptureModeGuard relaxed(hipStreamCaptureModeRelaxed);
+      t = at::zeros({2}, x.options().dtype(at::kInt));
+    }
+    std::lock_guard<std::mutex> lock(m);
+    keep.push_back(t);
+    return t;
+  }
+  static std::mutex m;
+  static std::map<std::pair<int, void*>, at::Tensor> cache;
+  std::lock_guard<std::mutex> lock(m);
+  auto key = std::make_pair((int)x.device().index(), (void*)st);
+  auto it = cache.find(key);
+  if (it == cache.end()) it = cache.emplace(key, at::zeros({2}, x.options().dtype(at::kInt))).first;
+  return it->second;
+}
+
+at::Tensor quant_rows_dual(const at::Tensor& x, int64_t neg_id, int64_t pos_id, int64_t cols, c10::optional<double> clipping_strength,
+                           c10::optional<at::ScalarType> out_dtype) {
+  require_gpu(x, "quant_rows_dual");
+  TORCH_CHECK(x.scalar_type() == at::kHalf || x.scalar_type() == at::kFloat, "quant_rows_dual: x must be float16 or float32, got ",
+              x.scalar_type());
+  const at::ScalarType od = out_dtype.value_or(x.scalar_type());
+  const int64_t n = x.numel();
+  TORCH_CHECK(cols > 0 && n % cols == 0, "quant_rows_dual: numel ", n, " is not a multiple of the row length ", cols);
+  const at::Tensor xc = x.is_contiguous() ? x : x.contiguous();
+  at::Tensor out = at::empty(x.sizes(), x.options().dtype(od));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  const fpq_stream_t st = current_stream(x);
+  const int in_id = dtype_id(x.scalar_type(), "quant_rows_dual");
+  const void* clip_ptr = nullptr;
+  float strength = 1.0f;
+  void* flag_ptr = nullptr;
+  at::Tensor scratch, amax;
+  if (clipping_strength.has_value() && (float)*clipping_strength == 1.0f) {
+    scratch = nan_scratch(x, st);
+    flag_ptr = scratch.data_ptr();
+  } else if (clipping_strength.has_value()) {
+    amax = at::empty({x.scalar_type() == at::kHalf ? 2 : 1}, x.options());   // fpq_absmax writes through 4 bytes
+    check(fpq_absmax(xc.data_ptr(), n, in_id, amax.data_ptr(), st), "fpq_absmax");
+    clip_ptr = amax.data_ptr();
+    strength = (float)*clipping_strength;
+  }
+  const int status = fpq_quant_rows_dual(xc.data_ptr(), out.data_ptr(), n / cols, cols, (int)neg_id, (int)pos_id, in_id,
+                                         dtype_id(od, "quant_rows_dual"), clip_ptr, strength, flag_ptr, st);
+  if (status != 0 && flag_ptr) (void)hipMemsetAsync(flag_ptr, 0, 8, (hipStream_t)st);   // a failed launch must not leave the words raised
+  check(status, "fpq_quant_rows_dual");
+  return out;
+}
+
+// the reference's `assert n_bits == 4` / `== 6` (tr/quant_utils.py:266,314,362,416,504,...): an AssertionError, as there
+void assert_bits(int64_t n_bits, int64_t want) {
+  if (n_bits != want) {
+    PyErr_SetString(PyExc_AssertionError, want == 4 ? "n_bits == 4" : "n_bits == 6");
+    throw py::error_already_set();
+  }
+}
+
+// ---- the reference's names (tr/quant_utils.py); table ids: include/fpq.h ----
+at::Tensor fp_quant_e3_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size) {
+  assert_bits(n_bits, 4);
+  return quant_rows(x, FPQ_E3M0, group_size, c10::nullopt);
+}
+at::Tensor fp_quant_e2_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size) {
+  assert_bits(n_bits, 4);
+  return quant_rows(x, FPQ_E2M1, group_size, c10::nullopt);
+}
+at::Tensor fp_quant_e1_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size) {
+  assert_bits(n_bits, 4);
+  return quant_rows(x, FPQ_E1M2, group_size, c10::nullopt);
+}
+at::Tensor fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size, double clipping_strength) {
+  assert_bits(n_bits, 4);
+  return quant_rows_dual(x, FPQ_E1M2_NEG, FPQ_E2M1_POS, group_size, clipping_strength, c10::nullopt);
+}
+at::Tensor fp4_afpq_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size, double clipping_strength) {
+  assert_bits(n_bits, 4);
+  return quant_rows_dual(x, FPQ_E2M1_NEG, FPQ_E2M1_POS, group_size, clipping_strength, c10::nullopt);
+}
+at::Tensor fp6_quant_e2m3_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size) {
+  assert_bits(n_bits, 6);
+  return quant_rows(x, FPQ_E2M3, group_size, at::kHalf);
+}
+at::Tensor fp6_quant_e3m2_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size) {
+  assert_bits(n_bits, 6);
+  return quant_rows(x, FPQ_E3M2, group_size, at::kHalf);
+}
+at::Tensor fp6_quant_int_neg_e2m3_pos_per_group_cuda(const at::Tensor& x, int64_t n_bits, int64_t group_size) {
+  assert_bits(n_bits, 6);
+  return quant_rows_dual(x, FPQ_INT_NEG, FPQ_E2M3_POS, group_size, c10::nullopt, c10::nullopt);
+}
+// per token: the reference flattens with .view(-1), which torch refuses for some non-contiguous layouts
+// (fpqvar_amd.quant_utils._require_viewable decides with torch's own stride rule): contiguous input only here
+at::Tensor fp6_quant_per_token_contig(const at::Tensor& x, int64_t n_bits, int64_t table_id) {
+  assert_bits(n_bits, 6);
+  TORCH_CHECK(x.is_contiguous() && x.dim() >= 1, "fp6 per token (native): contiguous input only");
+  return quant_rows(x, table_id, x.size(-1), at::kHalf);
+}
+at::Tensor fp6_quant_int_neg_e2m3_pos_per_token_contig(const at::Tensor& x, int64_t n_bits) {
+  assert_bits(n_bits, 6);
+  TORCH_CHECK(x.is_contiguous() && x.dim() >= 1, "fp6 dual per token (native): contiguous input only");
+  return quant_rows_dual(x, FPQ_INT_NEG, FPQ_E2M3_POS, x.size(-1), c10::nullopt, c10::nullopt);
+}
+
+// ---- the fused producers (tr/basic_var.py:263,266 + tr/quant_utils.py:765), value output, contiguous arguments: the hot
+// calls of a generation step; everything else (intermediates, operand outputs, odd layouts) stays with rotation.py ----
+at::Tensor rotate_quant(const at::Tensor& x, int64_t table_id, const std::array<uint32_t, 4>& sign_mask, const c10::optional<at::Tensor>& smooth) {
+  require_gpu(x, "rotate_quant");
+  TORCH_CHECK(x.scalar_type() == at::kHalf || x.scalar_type() == at::kFloat, "rotate_quant: x must be float16 or float32, got ", x.scalar_type());
+  TORCH_CHECK(x.dim() >= 1 && x.size(-1) % 128 == 0, "rotate_quant: the last dimension must be a multiple of 128");
+  const int64_t c = x.size(-1);
+  const at::Tensor xc = x.is_contiguous() ? x : x.contiguous();
+  const float* sm = nullptr;
+  if (smooth.has_value()) {
+    TORCH_CHECK(smooth->scalar_type() == at::kFloat && smooth->is_contiguous() && smooth->numel() == c && smooth->device() == x.device(),
+                "rotate_quant (native): smooth must be a contiguous float32 [C] tensor on x's device");
+    sm = (const float*)smooth->data_ptr();
+  }
+  at::Tensor out = at::empty(x.sizes(), x.options().dtype(at::kHalf));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  check(fpq_rotate_quant_rows(xc.data_ptr(), out.data_ptr(), nullptr, x.numel() / c, c, dtype_id(x.scalar_type(), "rotate_quant"), sm,
+                              sign_mask.data(), (int)table_id, current_stream(x)), "fpq_rotate_quant_rows");
+  return out;
+}
+
+at::Tensor adaln_rotate_quant(const at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, int64_t table_id,
+                              const std::array<uint32_t, 4>& sign_mask, const c10::optional<at::Tensor>& smooth, double eps) {
+  require_gpu(x, "adaln_rotate_quant");
+  TORCH_CHECK(x.dim() == 3, "adaln_rotate_quant: x must be [B, L, C]");
+  TORCH_CHECK(x.scalar_type() == at::kHalf || x.scalar_type() == at::kFloat, "adaln_rotate_quant: x must be float16 or float32, got ", x.scalar_type());
+  const int64_t b = x.size(0), l = x.size(1), c = x.size(2);
+  TORCH_CHECK(c % 128 == 0 && c <= 4096, "adaln_rotate_quant: C must be a multiple of 128 and at most 4096");
+  TORCH_CHECK(scale.scalar_type() == shift.scalar_type() && (scale.scalar_type() == at::kHalf || scale.scalar_type() == at::kFloat),
+              "adaln_rotate_quant: scale and shift must both be float16 or both float32");
+  TORCH_CHECK(x.is_contiguous() && scale.is_contiguous() && shift.is_contiguous() && scale.numel() == b * c && shift.numel() == b * c &&
+              scale.device() == x.device() && shift.device() == x.device(),
+              "adaln_rotate_quant (native): contiguous x and [B, C] modulation rows on x's device");
+  const float* sm = nullptr;
+  if (smooth.has_value()) {
+    TORCH_CHECK(smooth->scalar_type() == at::kFloat && smooth->is_contiguous() && smooth->numel() == c && smooth->device() == x.device(),
+                "adaln_rotate_quant (native): smooth must be a contiguous float32 [C] tensor on x's device");
+    sm = (const float*)smooth->data_ptr();
+  }
+  at::Tensor out = at::empty(x.sizes(), x.options().dtype(at::kHalf));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  check(fpq_adaln_rotate_quant_rows(x.data_ptr(), out.data_ptr(), nullptr, nullptr, b * l, c, dtype_id(x.scalar_type(), "adaln_rotate_quant"),
+                                    scale.data_ptr(), shift.data_ptr(), dtype_id(scale.scalar_type(), "adaln_rotate_quant"), l, (float)eps, sm,
+                                    sign_mask.data(), (int)table_id, current_stream(x)), "fpq_adaln_rotate_quant_rows");
+  return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "compiled binding of libfpq_hip.so for the reference's quant_cuda / quant_utils boundary";
+  m.def("fpq_version", [] { return fpq_version(); });
+  m.def("quant", &quant, py::arg("x"), py::arg("y"));
+  m.def("quant_rows", &quant_rows, py::arg("x"), py::arg("table_id"), py::arg("cols"), py::arg("out_dtype") = py::none());
+  m.def("quant_rows_dual", &quant_rows_dual, py::arg("x"), py::arg("neg_table_id"), py::arg("pos_table_id"), py::arg("cols"),
+        py::arg("clipping_strength") = py::none(), py::arg("out_dtype") = py::none());
+  m.def("fp_quant_e3_per_group_cuda", &fp_quant_e3_per_group_cuda, py::arg("x"), py::arg("n_bits"), py::arg("group_size") = 128);
+  m.def("fp_quant_e2_per_group_cuda", &fp_quant_e2_per_group_cuda, py::arg("x"), py::arg("n_bits"), py::arg("group_size") = 128);
+  m.def("fp_quant_e1_per_group_cuda", &fp_quant_e1_per_group_cuda, py::arg("x"), py::arg("n_bits"), py::arg("group_size") = 128);
+  m.def("fp_quant_e1m2_neg_e2m1_pos_per_group_cuda", &fp_quant_e1m2_neg_e2m1_pos_per_group_cuda, py::arg("x"), py::arg("n_bits"),
+        py::arg("group_size") = 128, py::arg("clipping_strength") = 1.0);
+  m.def("fp4_afpq_per_group_cuda", &fp4_afpq_per_group_cuda, py::arg("x"), py::arg("n_bits"), py::arg("group_size") = 128,
+        py::arg("clipping_strength") = 1.0);
+  m.def("fp6_quant_e2m3_per_group_cuda", &fp6_quant_e2m3_per_group_cuda, py::arg("x"), py::arg("n_bits"), py::arg("group_size") = 128);
+  m.def("fp6_quant_e3m2_per_group_cuda", &fp6_quant_e3m2_per_group_cuda, py::arg("x"), py::arg("n_bits"), py::arg("group_size") = 128);
+  m.def("fp6_quant_int_neg_e2m3_pos_per_group_cuda", &fp6_quant_int_neg_e2m3_pos_per_group_cuda, py::arg("x"), py::arg("n_bits"),
+        py::arg("group_size") = 128);
+  m.def("rotate_quant", &rotate_quant, py::arg("x"), py::arg("table_id"), py::arg("sign_mask"), py::arg("smooth") = py::none());
+  m.def("adaln_rotate_quant", &adaln_rotate_quant, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("table_id"),
+        py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
+  m.def("fp6_quant_per_token_contig", &fp6_quant_per_token_contig, py::arg("x"), py::arg("n_bits"), py::arg("table_id"));
+  m.def("fp6_quant_int_neg_e2m3_pos_per_token_contig", &fp6_quant_int_neg_e2m3_pos_per_token_contig, py::arg("x"), py::arg("n_bits"));
+}

@@ -15,6 +15,11 @@ import torch
 
 from . import ops
 
+try:   # the compiled binding (csrc/quant_cuda_ext.cpp, built by __graft_entry__.build_native): same C entry points, a
+    from . import _native   # third of the host time per call; absent -> the ctypes path of ops.py (tests run both)
+except ImportError:         # pragma: no cover - build() always produces it
+    _native = None
+
 # value tables, exactly as tr/quant_utils.py:233-235,458-500 spells them (host tensors)
 fp4_e3m0_grid = torch.tensor([-16.0, -8.0, -4.0, -2.0, -1.0, -0.5, -0.25, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0])
 fp4_e2m1_grid = torch.tensor([-6.0, -4.0, -3.0, -2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
@@ -108,6 +113,12 @@ def fp_quant_e1_per_group_cuda(x, n_bits, group_size=128):
     return ops.quant_rows(x, "e1m2", group_size)
 
 
+if _native is not None:   # the compiled functions carry the same names, defaults and checks
+    fp_quant_e3_per_group_cuda = _native.fp_quant_e3_per_group_cuda
+    fp_quant_e2_per_group_cuda = _native.fp_quant_e2_per_group_cuda
+    fp_quant_e1_per_group_cuda = _native.fp_quant_e1_per_group_cuda
+
+
 # ---- FP4 asymmetric dual format for the fc2 input (tr/quant_utils.py:415-452) ----
 
 def fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, n_bits, group_size=128, clipping_strength=1.0):
@@ -116,6 +127,10 @@ def fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(x, n_bits, group_size=128, clippin
     default strength 1.0 avoids the extra pass while keeping the NaN behaviour)."""
     assert n_bits == 4
     return ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", group_size, clipping_strength)
+
+
+if _native is not None:
+    fp_quant_e1m2_neg_e2m1_pos_per_group_cuda = _native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda
 
 
 def quantize_to_nearest_grid(x, quant_grid):
@@ -138,6 +153,10 @@ def fp4_afpq_per_group_cuda(x, n_bits, group_size=128, clipping_strength=1.0):
     return ops.quant_rows_dual(x, "e2m1_neg", "e2m1_pos", group_size, clipping_strength)
 
 
+if _native is not None:
+    fp4_afpq_per_group_cuda = _native.fp4_afpq_per_group_cuda
+
+
 def fp_neg_reverse_quant_per_group_cuda(x, n_bits, group_size=128):
     """models_fp_quant/quant_utils.py:454-495: x <= 0 is shifted up by |group min|, quantized on E2M1
     and shifted back; x > 0 is quantized on E2M1 as usual."""
@@ -149,12 +168,16 @@ def fp_neg_reverse_quant_per_group_cuda(x, n_bits, group_size=128):
 
 def fp6_quant_e2m3_per_token_cuda(x, n_bits):
     assert n_bits == 6
+    if _native is not None and x.is_contiguous():
+        return _native.fp6_quant_per_token_contig(x, n_bits, 3)
     _require_viewable(x)
     return ops.quant_rows(x, "e2m3", x.shape[-1], torch.float16)
 
 
 def fp6_quant_e3m2_per_token_cuda(x, n_bits):
     assert n_bits == 6
+    if _native is not None and x.is_contiguous():
+        return _native.fp6_quant_per_token_contig(x, n_bits, 4)
     _require_viewable(x)
     return ops.quant_rows(x, "e3m2", x.shape[-1], torch.float16)
 
@@ -176,8 +199,16 @@ def fp6_quant_int_neg_e2m3_pos_per_group_cuda(x, n_bits, group_size=128):
     return ops.quant_rows_dual(x, "int_neg", "e2m3_pos", group_size, None)
 
 
+if _native is not None:
+    fp6_quant_e2m3_per_group_cuda = _native.fp6_quant_e2m3_per_group_cuda
+    fp6_quant_e3m2_per_group_cuda = _native.fp6_quant_e3m2_per_group_cuda
+    fp6_quant_int_neg_e2m3_pos_per_group_cuda = _native.fp6_quant_int_neg_e2m3_pos_per_group_cuda
+
+
 def fp6_quant_int_neg_e2m3_pos_per_token_cuda(x, n_bits):
     assert n_bits == 6
+    if _native is not None and x.is_contiguous():
+        return _native.fp6_quant_int_neg_e2m3_pos_per_token_contig(x, n_bits)
     _require_viewable(x, dual=True)
     return ops.quant_rows_dual(x, "int_neg", "e2m3_pos", x.shape[-1], None)
 

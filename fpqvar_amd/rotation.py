@@ -189,6 +189,26 @@ def transform_model(model, mat_qkv_best_s, fc1_best_s) -> None:
 
 
 _DEFAULT_MASK = None
+_DEFAULT_MASK_TUPLE = None
+
+try:   # the compiled binding (csrc/quant_cuda_ext.cpp) for the hot, plain calls of the producers
+    from . import _native
+except ImportError:   # pragma: no cover - build() always produces it
+    _native = None
+
+
+def _native_ok(x, d, smooth, c) -> bool:
+    """The compiled fast path takes the usual arguments only: default sign vector, contiguous x, float32 [C] smooth."""
+    return _native is not None and d is None and x.is_cuda and x.is_contiguous() and (
+        smooth is None or (smooth.dtype is torch.float32 and smooth.dim() == 1 and smooth.shape[0] == c and
+                           smooth.device == x.device and smooth.is_contiguous()))
+
+
+def _default_mask_tuple():
+    global _DEFAULT_MASK_TUPLE
+    if _DEFAULT_MASK_TUPLE is None:
+        _DEFAULT_MASK_TUPLE = tuple(int(v) for v in sign_mask(sign_vector(128, 42)))
+    return _DEFAULT_MASK_TUPLE
 
 
 def _mask_arg(d: Optional[torch.Tensor]):
@@ -214,6 +234,8 @@ def rotate_quant(x: torch.Tensor, table: str = "e2m1", d: Optional[torch.Tensor]
     c = x.shape[-1]
     if c % 128 != 0:
         raise RuntimeError("rotate_quant: the last dimension must be a multiple of 128")
+    if not return_rotated and _native_ok(x, d, smooth, c):
+        return _native.rotate_quant(x, TABLE_IDS[table], _default_mask_tuple(), smooth)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
@@ -355,6 +377,8 @@ def adaln_rotate_quant(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor
         raise RuntimeError("adaln_rotate_quant: scale and shift must both be float16 or both float32")
     sc = _mod_rows(scale, bsz, c)
     sh = _mod_rows(shift, bsz, c)
+    if not return_intermediates and sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c):
+        return _native.adaln_rotate_quant(x, sc, sh, TABLE_IDS[table], _default_mask_tuple(), smooth, float(eps))
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)

@@ -13,8 +13,13 @@ import torch
 
 from fpqvar_amd import ops as _ops
 
+try:   # the compiled binding (fpqvar_amd/csrc/quant_cuda_ext.cpp): what the reference's pybind module is to its kernel
+    from fpqvar_amd import _native
+except ImportError:   # pragma: no cover - __graft_entry__.build() always produces it
+    _native = None
 
-def quant(x: torch.Tensor, y: torch.Tensor):
+
+def _quant_ctypes(x: torch.Tensor, y: torch.Tensor):
     """z[i] = the entry of y nearest to x[i] (last index wins ties; NaN/Inf/out of
     reach -> 0.0).  The second output is all zeros, as in the reference, whose
     kernel never writes it (quant/quant_kernel.cu:18,49): it is returned as a
@@ -22,3 +27,6 @@ def quant(x: torch.Tensor, y: torch.Tensor):
     z = _ops.quant_nearest(x, y)
     idx = torch.zeros((), dtype=x.dtype, device=x.device).expand(x.shape)
     return z, idx
+
+
+quant = _quant_ctypes if _native is None else _native.quant   # same C entry point (fpq_quant_nearest) either way

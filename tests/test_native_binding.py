@@ -1,0 +1,113 @@
+"""The compiled host binding (fpqvar_amd/_native, csrc/quant_cuda_ext.cpp) against the ctypes path of ops.py: same C entry
+points, same results, same error behaviour as the reference's module (quant/quant.cpp:17-29: RuntimeError from torch's
+checks; the quant_utils.py functions: AssertionError for a wrong n_bits)."""
+import os
+
+import pytest
+import torch
+
+from tests.conftest import assert_bits_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+NAMES = ("quant", "quant_rows", "quant_rows_dual", "fp_quant_e1_per_group_cuda", "fp_quant_e2_per_group_cuda",
+         "fp_quant_e3_per_group_cuda", "fp_quant_e1m2_neg_e2m1_pos_per_group_cuda", "fp4_afpq_per_group_cuda",
+         "fp6_quant_e2m3_per_group_cuda", "fp6_quant_e3m2_per_group_cuda", "fp6_quant_int_neg_e2m3_pos_per_group_cuda",
+         "fp6_quant_per_token_contig", "fp6_quant_int_neg_e2m3_pos_per_token_contig")
+
+
+def test_native_module_is_built_and_bound():
+    """__graft_entry__.build() produces the module; quant_cuda.quant and the hot quant_utils names ARE its functions."""
+    from fpqvar_amd import _lib, _native, quant_utils as qu
+    import quant_cuda
+    assert _native.fpq_version() == _lib.lib().fpq_version()
+    for n in NAMES:
+        assert callable(getattr(_native, n)), n
+    assert quant_cuda.quant is _native.quant
+    assert qu.fp_quant_e2_per_group_cuda is _native.fp_quant_e2_per_group_cuda
+    assert qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda is _native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda
+    # no CPU path in the compiled module either
+    x = torch.randn(4, 128)
+    with pytest.raises(RuntimeError, match="GPU"):
+        _native.fp_quant_e2_per_group_cuda(x.half(), 4)
+    with pytest.raises(RuntimeError, match="GPU"):
+        _native.quant(x.view(-1), qu.fp4_e2m1_grid)
+    with pytest.raises(AssertionError):
+        _native.fp_quant_e2_per_group_cuda(x.half(), 8)
+    with pytest.raises(AssertionError):
+        _native.fp6_quant_e2m3_per_group_cuda(x.half(), 4)
+
+
+@pytest.mark.gpu
+def test_native_equals_ctypes_path():
+    from fpqvar_amd import _native, ops, quant_utils as qu
+    import quant_cuda
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x16 = (torch.randn(3, 37, 1920, generator=g) * 1.7).half().to(dev)
+    x32 = (torch.randn(64, 1024, generator=g) * 0.02).to(dev)
+    h = torch.nn.functional.gelu(torch.randn(50, 7680, generator=g), approximate="tanh").half().to(dev)
+    h[7, 300] = float("nan")
+    for x in (x16, x32):
+        for name, tab in (("fp_quant_e1_per_group_cuda", "e1m2"), ("fp_quant_e2_per_group_cuda", "e2m1"), ("fp_quant_e3_per_group_cuda", "e3m0")):
+            got = getattr(_native, name)(x, 4, 128)
+            assert_bits_equal(got, ops.quant_rows(x, tab, 128), name)
+            assert_bits_equal(getattr(qu, name)(x, 4), got, name + " via quant_utils, default group")
+        for name, tab in (("fp6_quant_e2m3_per_group_cuda", "e2m3"), ("fp6_quant_e3m2_per_group_cuda", "e3m2")):
+            assert_bits_equal(getattr(_native, name)(x, 6), ops.quant_rows(x, tab, 128, torch.float16), name)
+        assert_bits_equal(qu.fp6_quant_e2m3_per_token_cuda(x, 6), ops.quant_rows(x, "e2m3", x.shape[-1], torch.float16), "per token")
+        assert_bits_equal(qu.fp6_quant_e3m2_per_token_cuda(x, 6), ops.quant_rows(x, "e3m2", x.shape[-1], torch.float16), "per token e3m2")
+        assert_bits_equal(_native.quant_rows(x, 0, 128, torch.float16), ops.quant_rows(x, "e2m1", 128, torch.float16), "out dtype")
+    hc = h.clone()
+    hc[7, 300] = 0.5
+    for t in (h, hc):     # with and without a NaN: the default clipping strength's all-zero rule and the self-cleaning scratch
+        for _ in range(2):
+            assert_bits_equal(_native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(t, 4), ops.quant_rows_dual(t, "e1m2_neg", "e2m1_pos", 128, 1.0), "dual fp4")
+        assert_bits_equal(_native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(t, 4, 128, 0.75), ops.quant_rows_dual(t, "e1m2_neg", "e2m1_pos", 128, 0.75), "dual clip 0.75")
+        assert_bits_equal(_native.fp4_afpq_per_group_cuda(t, 4), ops.quant_rows_dual(t, "e2m1_neg", "e2m1_pos", 128, 1.0), "afpq")
+        assert_bits_equal(_native.fp6_quant_int_neg_e2m3_pos_per_group_cuda(t, 6), ops.quant_rows_dual(t, "int_neg", "e2m3_pos", 128, None), "dual fp6")
+        assert_bits_equal(qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(t, 6), ops.quant_rows_dual(t, "int_neg", "e2m3_pos", t.shape[-1], None), "dual fp6 per token")
+    # non-contiguous input: reshape semantics for per-group (copy), torch's .view(-1) rule for per-token (quant_utils decides)
+    xt = torch.randn(256, 64, generator=g).half().to(dev).t()
+    assert_bits_equal(qu.fp_quant_e2_per_group_cuda(xt, 4, 128), ops.quant_rows(xt.contiguous(), "e2m1", 128), "transposed")
+    with pytest.raises(RuntimeError):
+        qu.fp6_quant_e2m3_per_token_cuda(torch.randn(2, 3, 4, 64, device=dev).half().permute(0, 2, 1, 3), 6)
+    # quant_cuda.quant through both bindings
+    tab = qu.fp4_e2m1_grid.to(dev)
+    xs = torch.randn(1000, generator=g).to(dev) * 3
+    z, idx = quant_cuda.quant(xs, tab)
+    z2, idx2 = quant_cuda._quant_ctypes(xs, tab)
+    assert_bits_equal(z, z2, "quant")
+    assert idx.shape == idx2.shape == xs.shape and not idx.any() and idx.dtype == xs.dtype
+    with pytest.raises(RuntimeError):
+        quant_cuda.quant(xs.half(), tab)
+    with pytest.raises(RuntimeError):
+        quant_cuda.quant(xs, torch.zeros(257, device=dev))
+
+
+@pytest.mark.gpu
+def test_native_dual_under_graph_capture():
+    """The default fc2 quantizer inside a captured graph: the NaN scratch of a capturing stream is the capture's own, and a
+    replay behaves like the eager call, with and without a NaN in the input."""
+    from fpqvar_amd import _native, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    static = torch.nn.functional.gelu(torch.randn(40, 7680, generator=g)).half().to(dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(static, 4)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = _native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(static, 4)
+    for trial, poison in enumerate((False, True, False)):
+        t = torch.nn.functional.gelu(torch.randn(40, 7680, generator=g)).half()
+        if poison:
+            t[3, 77] = float("nan")
+        static.copy_(t.to(dev))
+        graph.replay()
+        eager = ops.quant_rows_dual(static, "e1m2_neg", "e2m1_pos", 128, 1.0)     # eager call beside the replays, same stream
+        torch.cuda.synchronize()
+        assert_bits_equal(y, eager, f"replay {trial}")
+        assert bool((y == 0).all()) == poison

@@ -5,7 +5,9 @@ quantizer / producer call costs when the tensor is tiny.  Three clocks per (op, 
   graph_us   the same calls captured in ONE hipGraph and replayed: GPU time per call incl. the inter-kernel gaps
   kernels    launches per call
 and the floor: an empty-range launch of the same library (rows = 1) replayed the same way.
-usage: bench_small_steps.py > profiles/r02_small_steps.json"""
+"eager_ctypes_us" is the same call through the Python + ctypes path of fpqvar_amd.ops (round 2's only binding); "eager_us" goes
+through quant_utils, i.e. the compiled binding fpqvar_amd._native where it covers the function.
+usage: bench_small_steps.py > profiles/r03_small_steps.json"""
 import json
 import os
 import sys
@@ -62,6 +64,8 @@ res = {"note": "VAR-d30 256x256, B = 50 with CFG (100 conditioned rows per token
 tiny = torch.randn(1, 128, device=dev, generator=g).half()
 res["launch_floor_graph_us"] = round(graph_time(lambda: qu.fp_quant_e2_per_group_cuda(tiny, 4, 128)), 2)
 res["launch_floor_eager_us"] = round(eager_time(lambda: qu.fp_quant_e2_per_group_cuda(tiny, 4, 128)), 2)
+res["launch_floor_eager_ctypes_us"] = round(eager_time(lambda: ops.quant_rows(tiny, "e2m1", 128)), 2)
+res["compiled_binding"] = getattr(qu, "_native", None) is not None
 scale = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
 shift = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
 smooth = torch.rand(C, device=dev, generator=g) + 0.5
@@ -71,12 +75,16 @@ for pn in PN:
     x = torch.randn(B, L, C, device=dev, generator=g).half()
     hid = torch.nn.functional.gelu(torch.randn(rows, HID, device=dev, generator=g), approximate="tanh").half()
     ops_ = {
-        "act_quant_e2m1_g128 (proj input)": (lambda: qu.fp_quant_e2_per_group_cuda(x, 4, 128), 1),
-        "adaln_rotate_quant (mat_qkv / fc1 input)": (lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=smooth), 1),
-        "dual_fp4_g128 (fc2 input, default clip)": (lambda: qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(hid, 4, 128), 2),
+        "act_quant_e2m1_g128 (proj input)": (lambda: qu.fp_quant_e2_per_group_cuda(x, 4, 128), 1,
+                                              lambda: ops.quant_rows(x, "e2m1", 128)),
+        "adaln_rotate_quant (mat_qkv / fc1 input)": (lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=smooth), 1, None),
+        "dual_fp4_g128 (fc2 input, default clip)": (lambda: qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(hid, 4, 128), 2,
+                                                     lambda: ops.quant_rows_dual(hid, "e1m2_neg", "e2m1_pos", 128, 1.0)),
     }
     step = {"pn": pn, "rows": rows}
-    for name, (fn, launches) in ops_.items():
+    for name, (fn, launches, slow) in ops_.items():
         step[name] = {"eager_us": round(eager_time(fn), 2), "graph_us": round(graph_time(fn), 2), "kernels": launches}
+        if slow is not None:
+            step[name]["eager_ctypes_us"] = round(eager_time(slow), 2)
     res["steps"].append(step)
 print(json.dumps(res, indent=1))
