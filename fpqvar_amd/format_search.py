@@ -33,19 +33,47 @@ def quantizer(fmt: str) -> Callable[[torch.Tensor], torch.Tensor]:
 
 @torch.no_grad()
 def search_layer(xs: Sequence[torch.Tensor], w: torch.Tensor, formats: Sequence[str] = FP6_FORMATS,
-                 quant: Callable[[str], Callable] = quantizer) -> Tuple[str, str, Dict[Tuple[str, str], float]]:
-    """(best weight format, best activation format, {(w_fmt, a_fmt): summed MSE})."""
-    losses: Dict[Tuple[str, str], float] = {}
-    refs = [x.to(w.dtype) @ w.t() for x in xs]
-    for wf in formats:
-        wq = quant(wf)(w).to(w.dtype)
-        for af in formats:
-            qa = quant(af)
-            total = torch.zeros((), dtype=torch.float32, device=w.device)
-            for x, ref in zip(xs, refs):
-                y = qa(x).to(w.dtype) @ wq.t()
-                total += torch.mean((ref.float() - y.float()) ** 2)
-            losses[(wf, af)] = float(total)
+                 quant: Callable[[str], Callable] = quantizer, batched: bool = True
+                 ) -> Tuple[str, str, Dict[Tuple[str, str], float]]:
+    """(best weight format, best activation format, {(w_fmt, a_fmt): summed MSE}).
+
+    The reference walks the calibration samples one by one for every (w_fmt, a_fmt) pair: per sample one quantizer call
+    (~11 torch ops + the scan kernel), two GEMMs, an MSE and a host sync (`.item()`), search_fp6_format.py:589-608.
+    batched=True (default) does the same arithmetic on ALL samples of the layer at once: every quantizer here works row
+    by row (per token) or group by group, so the samples are concatenated along their rows - ONE quantizer launch per
+    activation format for the whole calibration set (and one per weight format), ONE GEMM per pair, the per-sample
+    means as a weighted row reduction, all `len(formats)^2` losses kept on the device and read back with ONE copy.
+    batched=False is the sample-by-sample loop (same quantizers), kept for comparison and for tests."""
+    nf = len(formats)
+    if not batched:
+        losses: Dict[Tuple[str, str], float] = {}
+        refs = [x.to(w.dtype) @ w.t() for x in xs]
+        for wf in formats:
+            wq = quant(wf)(w).to(w.dtype)
+            for af in formats:
+                qa = quant(af)
+                total = torch.zeros((), dtype=torch.float32, device=w.device)
+                for x, ref in zip(xs, refs):
+                    y = qa(x).to(w.dtype) @ wq.t()
+                    total += torch.mean((ref.float() - y.float()) ** 2)
+                losses[(wf, af)] = float(total)
+    else:
+        c = w.shape[-1]
+        rows = [x.numel() // c for x in xs]
+        x_all = torch.cat([x.reshape(-1, c) for x in xs]).to(w.dtype)                 # [sum rows, C]
+        # sum_j mean_j((y - y_q)^2) = sum over rows of (row's squared error) / (rows_j * out): one weight per row
+        w_row = torch.repeat_interleave(torch.tensor([1.0 / (r * w.shape[0]) for r in rows], dtype=torch.float32, device=w.device),
+                                        torch.tensor(rows, device=w.device))
+        ref = x_all @ w.t()
+        xq = {af: quant(af)(x_all).to(w.dtype) for af in formats}                     # one launch per activation format
+        out = torch.empty(nf, nf, dtype=torch.float32, device=w.device)
+        for i, wf in enumerate(formats):
+            wq = quant(wf)(w).to(w.dtype)
+            for j, af in enumerate(formats):
+                d = (ref - xq[af] @ wq.t()).float()
+                out[i, j] = torch.dot((d * d).sum(dim=1), w_row)
+        host = out.cpu()                                                               # the layer's one synchronisation
+        losses = {(wf, af): float(host[i, j]) for i, wf in enumerate(formats) for j, af in enumerate(formats)}
     best = min(losses, key=lambda k: (losses[k], formats.index(k[0]), formats.index(k[1])))
     return best[0], best[1], losses
 

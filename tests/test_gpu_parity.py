@@ -831,8 +831,34 @@ def test_format_search_layer(dev):
         assert abs(losses[key] - want[key]) <= 0.05 * want[key] + 1e-6, (key, losses[key], want[key])
     best = min(want, key=want.get)
     assert (wf, af) == best
+    # the sample-by-sample loop (the reference's order of operations) gives the same numbers as the batched form
+    _, _, loop = fs.search_layer([x.to(dev).half() for x in xs], w.to(dev).half(), fs.FP6_FORMATS, batched=False)
+    for key in want:
+        assert abs(loop[key] - losses[key]) <= 2e-3 * want[key] + 1e-7, (key, loop[key], losses[key])
+    # FP4 twin (search/search_fp4_format.py:782-821): 3 x 3 formats, per-group-128 quantizers on weights and activations
     wf4, af4, l4 = fs.search_layer([x.to(dev).half() for x in xs], w.to(dev).half(), fs.FP4_FORMATS)
-    assert len(l4) == 9 and wf4 in fs.FP4_FORMATS and af4 in fs.FP4_FORMATS
+    tab4 = {"fp_e1": "e1m2", "fp_e2": "e2m1", "fp_e3": "e3m0"}
+    want4 = {}
+    for a in fs.FP4_FORMATS:
+        wq = orc.per_group_kernel_sem(w.half(), tab4[a], 128).float()
+        for b in fs.FP4_FORMATS:
+            tot = 0.0
+            for x in xs:
+                xh = x.half()
+                ref = xh.float() @ w.half().float().t()
+                y = orc.per_group_kernel_sem(xh, tab4[b], 128).float() @ wq.t()
+                tot += float(torch.mean((ref - y) ** 2))
+            want4[(a, b)] = tot
+    assert set(l4) == set(want4) and len(l4) == 9
+    for key in want4:
+        assert abs(l4[key] - want4[key]) <= 0.05 * want4[key] + 1e-6, (key, l4[key], want4[key])
+    assert (wf4, af4) == min(want4, key=want4.get)
+    # ragged calibration sets (different token counts per sample, as the dumps of different scale steps have)
+    xr = [torch.randn(2, n, 512, generator=g) for n in (1, 4, 9, 16)]
+    _, _, lb = fs.search_layer([x.to(dev).half() for x in xr], w.to(dev).half(), fs.FP4_FORMATS)
+    _, _, ll = fs.search_layer([x.to(dev).half() for x in xr], w.to(dev).half(), fs.FP4_FORMATS, batched=False)
+    for key in lb:
+        assert abs(lb[key] - ll[key]) <= 2e-3 * ll[key] + 1e-7, (key, lb[key], ll[key])
 
 
 # ------------------------------------------------------------------ hipGraph capture (no alloc / sync inside the ABI)
