@@ -49,6 +49,22 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+class Stage:
+    """What the run is doing right now (for the watchdog): assigning stage[0] restarts its clock."""
+
+    def __init__(self):
+        self.name, self.t0, self.done = "starting", time.monotonic(), threading.Event()
+
+    def __setitem__(self, _, name):
+        self.name, self.t0 = name, time.monotonic()
+
+    def __getitem__(self, _):
+        return self.name
+
+    def age(self):
+        return time.monotonic() - self.t0
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def launch_ranks(args, script, argv):
     """`bench.py --gpus N` without a launcher: start N ranks as a child process and hand its exit code back.
@@ -63,7 +79,17 @@ def launch_ranks(args, script, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
-    return subprocess.run(cmd, env=env).returncode
+    # relay the child's output line by line; a rank that gave up on a blocked collective says so in its JSON line and
+    # leaves with EXIT_COLLECTIVE_TIMEOUT, which torch.distributed.run flattens to 1: restore it here
+    timed_out = False
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        if '"error": "timeout after' in line:
+            timed_out = True
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    return EXIT_COLLECTIVE_TIMEOUT if (rc != 0 and timed_out) else rc
 
 
 # ------------------------------------------------------------------------------------------------ platform seam
@@ -367,7 +393,7 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
     import torch
     depth = CALIB_DEPTH if depth is None else depth
     dev = plat.dev
-    dt, dt_g = float("nan"), float("nan")
+    dt, dt_g, dt_c = float("nan"), float("nan"), float("nan")
     total = 0
     err = None
     own, shapes, cal = {}, {}, None
@@ -418,6 +444,22 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_g = float(t.item())
                 del plan
+                # the same with the packed exchange format (nibble codes + one fp32 scale per group: 0.53 B per element
+                # on the wire instead of 2, decoded locally, bit-identical): a second curve for the same run
+                stage[0] = "sharded calibration, codes exchange + all_gather_into_tensor"
+                codes_run = getattr(plat, "codes_calibration", None) or \
+                    (lambda: cal.calibrate_sharded(own_all(shapes, own, dev), exchange="codes"))
+                codes_run()
+                plat.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    codes_run()
+                plat.synchronize()
+                dist.barrier()
+                t = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_c = float(t.item())
             except Exception as e:
                 err = f"gathered calibration: {e!r}"[:300]
     stage[0] = "done"
@@ -437,10 +479,28 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
            "frac_of_8TBps_per_gpu": round(total * 6 / dt / 1e9 / world / HBM_PEAK_GBS, 3),
            "scaling": "strong"}
     if dt_g == dt_g:
+        res["exchange"] = "fp16 (the de-quantized weights, 2 B per element), in-place all_gather_into_tensor"
         res["ms_with_all_gather"] = round(dt_g * 1e3, 3)
         res["Gelem_s_with_all_gather"] = round(total / dt_g / 1e9, 1)
         res["gathered_bytes_per_rank"] = 2 * total
+        ag = max(dt_g - dt, 1e-9)
+        res["all_gather_ms"] = round(ag * 1e3, 3)                                  # = ms_with_all_gather - ms
+        res["all_gather_GBps_per_rank"] = round(2 * total * (world - 1) / world / ag / 1e9, 1)   # bytes a rank receives / time
+    if dt_c == dt_c:
+        res["codes_exchange"] = {"exchange": "nibble codes + fp32 group scales (0.53 B per element), decoded locally",
+                                 "ms_with_all_gather": round(dt_c * 1e3, 3), "Gelem_s_with_all_gather": round(total / dt_c / 1e9, 1),
+                                 "gathered_bytes_per_rank": int(total * (0.5 + 4.0 / GROUP)),
+                                 "note": "per-layer quantizer launches + slab assembly are inside this time (the fp16 form "
+                                         "is one launch into a prebuilt slab)"}
     return res
+
+
+def own_all(shapes, own, dev):
+    """calibrate_sharded wants every name (shapes are read from the tensors; only owned values are touched): layers of
+    other ranks as zero-stride placeholders of the right shape - no memory, never read."""
+    import torch
+    z = torch.zeros((), device=dev)
+    return {n: own[n] if n in own else z.expand(shapes[n]) for n in shapes}
 
 
 def pmc_traffic():
@@ -513,24 +573,50 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank "
                          f"run as a {args.gpus}-GPU figure")
     import torch
+    # N > 1: every collective of this run - rendezvous, barriers, the MAX over ranks, the all-gather - sits under a
+    # watchdog from here on.  `stage` names what is running and restarts the clock; a stage that does not finish within
+    # WATCHDOG_S ends the process with EXIT_COLLECTIVE_TIMEOUT and the reason in rank 0's JSON line: a hang is never
+    # reported as success.
+    stage = Stage()
+    partial = [None]        # a function building the line from what has been measured so far
+
+    def watchdog():
+        limit = WATCHDOG_S if rank == 0 else 1.5 * WATCHDOG_S + 5.0   # rank 0 reports first: the line is its to print
+        while not stage.done.wait(0.5):
+            if stage.age() > limit:
+                err = {"error": f"timeout after {WATCHDOG_S:.0f} s in {stage[0]}"}
+                if rank == 0:
+                    line = partial[0](err) if partial[0] is not None else dict(
+                        metric="Gelements/s + achieved HBM GB/s, per-group FP4 quant [65536x1920,g=128]", value=None,
+                        n_gpus=world, **err)
+                    print(json.dumps(line), flush=True)
+                os._exit(EXIT_COLLECTIVE_TIMEOUT)
+
+    if world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
+    stage[0] = "device initialisation"
     plat = platform_factory(local_rank)
     dist = None
     rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        stage[0] = "init_process_group"
         plat.init_dist(dist)
         rccl_ranks = dist.get_world_size()
         if rccl_ranks != world:
             raise SystemExit(f"bench.py: the process group has {rccl_ranks} ranks, WORLD_SIZE says {world}")
 
+    stage[0] = "warm-up"
     step, elems, x0 = plat.hot_path(rank)
     for _ in range(args.warmup):
         step()
     plat.synchronize()
+    stage[0] = "barrier before the timed region"
     if dist is not None:
         dist.barrier()
     plat.synchronize()
+    stage[0] = "timed region"
     start, stop, elapsed_ms = plat.timer()
     t0 = time.perf_counter()
     start()                       # same stream the kernel is launched on
@@ -538,6 +624,7 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
         step()
     stop()
     plat.synchronize()
+    stage[0] = "barrier after the timed region"
     if dist is not None:
         dist.barrier()
     plat.synchronize()
@@ -545,6 +632,7 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
     kernel_ms = elapsed_ms() / args.steps                 # average launch duration, HIP events
 
     if dist is not None:
+        stage[0] = "all_reduce(MAX) of the elapsed time"
         t = torch.tensor([elapsed], device=plat.dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -552,21 +640,10 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
     def headline(calib):
         return build_result(args, world, elems, elapsed, kernel_ms, calib, rccl_ranks, plat.data)
 
+    partial[0] = headline
     # The sharded calibration (with its all-gather at N > 1) is a secondary measurement taken AFTER the timed region.
-    # Should a collective in it block, the watchdog reports that IN the line and ends the process with a non-zero
-    # exit code: a hang is never reported as success.
-    calib_done, stage = threading.Event(), ["starting"]
-
-    def watchdog():
-        if not calib_done.wait(WATCHDOG_S):
-            if rank == 0:
-                print(json.dumps(headline({"error": f"timeout after {WATCHDOG_S:.0f} s in {stage[0]}"})), flush=True)
-            os._exit(EXIT_COLLECTIVE_TIMEOUT)
-
-    if world > 1:
-        threading.Thread(target=watchdog, daemon=True).start()
     calib = weight_calibration(plat, dist, world, rank, stage)
-    calib_done.set()
+    stage.done.set()
 
     if rank == 0:
         res = headline(calib)
@@ -582,6 +659,8 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
             except Exception as e:
                 res["other_kernels"] = {"error": repr(e)[:200]}
             res["cpu_baseline"] = cpu_baseline()
+        if world > 1:
+            res["omitted_at_n_gt_1"] = ["cpu_baseline", "other_kernels", "unfused_gpu"]   # N = 1 lines carry them
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

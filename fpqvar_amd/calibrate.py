@@ -85,6 +85,20 @@ def default_weight_quantizer(weight_quant: str = "per_group", weight_fp_type: st
     return quantize
 
 
+def gather_slab(slab: torch.Tensor, rank: int, group=None) -> None:
+    """THE collective of this path: every rank's slot of the [world, width] slab to every rank, in place.
+
+    The input of all_gather_into_tensor is the rank's own slot of the output (no staging copy).  That aliasing is
+    what RCCL's in-place all-gather is defined for (sendbuff == recvbuff + rank * count), but through torch.distributed
+    it has only run on one-rank groups and on gloo so far (no multi-GPU box was available to this build): setting
+    FPQ_GATHER_NO_ALIAS=1 sends from a separate copy of the slot instead (one extra slot-sized copy per call)."""
+    import os
+    send = slab[rank]
+    if os.environ.get("FPQ_GATHER_NO_ALIAS"):
+        send = send.clone()
+    dist.all_gather_into_tensor(slab.view(-1), send, group=group)
+
+
 def _world(group) -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
@@ -187,22 +201,39 @@ class ShardedCalibration:
     only (``plan_owners(shapes, world)[rank]``)."""
 
     def __init__(self, shapes: Mapping[str, Tuple[int, ...]], weights: Mapping[str, torch.Tensor], group=None,
-                 weight_fp_type: str = "fp_e2"):
+                 weight_fp_type: str = "fp_e2", device: Optional[torch.device] = None):
         self.group = group
         self.rank, self.world = _world(group)
         self.plan = _Plan(shapes, self.world)
         mine = self.plan.owners[self.rank]
-        ref = next((weights[n] for n in mine), None)
-        if ref is None:
-            ref = next(iter(weights.values()))
-        self.slab = torch.empty((self.world, self.plan.width), dtype=torch.float16, device=ref.device)
+        # every check that can fail happens HERE, on every rank alike, before any collective: a rank that raised later
+        # would leave the others blocked in the all-gather
+        missing = [n for n in mine if n not in weights]
+        if missing:
+            raise RuntimeError(f"ShardedCalibration: rank {self.rank} owns {missing[:3]}... but was not given them")
+        for n in mine:
+            if weights[n].numel() != self.plan.numel[n]:
+                raise RuntimeError(f"ShardedCalibration: {n} has {weights[n].numel()} elements, `shapes` says "
+                                   f"{self.plan.shapes[n]} = {self.plan.numel[n]}")
+        if device is None:   # a rank may own no layer (more ranks than layers) and hold no weights at all
+            ref = next((weights[n] for n in mine), None)
+            if ref is None:
+                ref = next(iter(weights.values()), None)
+            if ref is not None:
+                device = ref.device
+            elif torch.cuda.is_available():
+                device = torch.device("cuda", torch.cuda.current_device())
+            else:
+                raise RuntimeError("ShardedCalibration: this rank holds no weights; pass `device=`")
+        self.device = torch.device(device)
+        self.slab = torch.empty((self.world, self.plan.width), dtype=torch.float16, device=self.device)
         self.local = LocalShard(OrderedDict((n, weights[n]) for n in mine), self.plan.shapes, weight_fp_type,
                                 out=self.slab[self.rank])
 
     def run(self) -> Dict[str, torch.Tensor]:
         self.local.quantize()
         if self.world > 1:
-            dist.all_gather_into_tensor(self.slab.view(-1), self.slab[self.rank], group=self.group)   # THE collective
+            gather_slab(self.slab, self.rank, self.group)   # THE collective
         return self.views()
 
     def views(self) -> Dict[str, torch.Tensor]:
@@ -253,7 +284,7 @@ def calibrate_sharded(weights: Mapping[str, torch.Tensor],
     for n, q in local.items():
         off = plan.where[n][1]
         slab[rank, off:off + plan.numel[n]] = q.reshape(-1)
-    dist.all_gather_into_tensor(slab.view(-1), slab[rank], group=group)          # the one collective of this path
+    gather_slab(slab, rank, group)                                                # the one collective of this path
     return {n: slab[plan.where[n][0], plan.where[n][1]:plan.where[n][1] + plan.numel[n]].view(plan.shapes[n])
             for n in plan.names}
 
@@ -289,7 +320,7 @@ def _calibrate_codes(weights, rank, world, group, gather):
         b = local_scales[n].contiguous().view(torch.uint8)
         slab[rank, soff:soff + b.numel()] = b
         soff += b.numel()
-    dist.all_gather_into_tensor(slab.view(-1), slab[rank], group=group)
+    gather_slab(slab, rank, group)
     out = {}
     for r in range(world):
         off, soff = 0, wc

@@ -253,18 +253,28 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
         elif clipping_strength is not None:
             am = absmax(xc)
             clip_ptr, strength = am.data_ptr(), float(clipping_strength)
-        check(lib().fpq_quant_rows_dual(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[neg_table],
-                                        TABLE_IDS[pos_table], dtype_id(x.dtype), dtype_id(out_dtype), clip_ptr,
-                                        strength, flag_ptr, stream_ptr(x.device)), "fpq_quant_rows_dual")
+        status = lib().fpq_quant_rows_dual(xc.data_ptr(), out.data_ptr(), n // cols, cols, TABLE_IDS[neg_table],
+                                           TABLE_IDS[pos_table], dtype_id(x.dtype), dtype_id(out_dtype), clip_ptr,
+                                           strength, flag_ptr, stream_ptr(x.device))
+        if status != 0 and flag_ptr is not None:
+            _NAN_SCRATCH.clear()        # a failed launch may have left the words raised: never reuse them
+        check(status, "fpq_quant_rows_dual")
     return out
 
 
 _NAN_SCRATCH = {}
+_NAN_SCRATCH_CAPTURED = []
 
 
 def _nan_scratch(device: torch.device) -> torch.Tensor:
     """8 zeroed bytes per (device, stream) for fpq_quant_rows_dual's NaN flag: the fix-up launch leaves them zero, so
     one allocation serves every call on that stream (include/fpq.h)."""
+    if torch.cuda.is_current_stream_capturing():
+        # a graph bakes the pointer in and may be replayed beside eager calls on the same stream: scratch of its own,
+        # kept alive with the process (8 bytes per captured call)
+        t = torch.zeros(2, dtype=torch.int32, device=device)
+        _NAN_SCRATCH_CAPTURED.append(t)
+        return t
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _NAN_SCRATCH.get(key)
     if t is None:

@@ -105,6 +105,11 @@ class CpuPlatform:
     def release_hot_path(self):
         pass
 
+    def codes_calibration(self):      # the packed-exchange variant is HIP only: the rehearsal meets in a collective of the same kind
+        import torch.distributed as dist
+        t = torch.zeros(dist.get_world_size(), 8)
+        dist.all_gather_into_tensor(t.view(-1), torch.ones(8))
+
     def timer(self):
         t = [0.0, 0.0]
         return (lambda: t.__setitem__(0, time.perf_counter())), (lambda: t.__setitem__(1, time.perf_counter())), \\
@@ -143,7 +148,10 @@ def test_bench_gpus2_launches_two_ranks_gloo(tmp_path):
     assert "error" not in wc, wc
     assert wc["n_gpus"] == 2 and wc["scaling"] == "strong" and wc["elements"] == 12 * 64 * 64
     assert wc["ms"] > 0 and wc["ms_with_all_gather"] > 0 and wc["gathered_bytes_per_rank"] == 2 * wc["elements"]
-    assert "cpu_baseline" not in res           # N = 1 only
+    assert abs(wc["all_gather_ms"] - max(wc["ms_with_all_gather"] - wc["ms"], 1e-6)) < 5e-3 and wc["all_gather_GBps_per_rank"] > 0
+    assert "fp16" in wc["exchange"] and wc["codes_exchange"]["ms_with_all_gather"] > 0
+    assert wc["codes_exchange"]["gathered_bytes_per_rank"] < wc["gathered_bytes_per_rank"]
+    assert "cpu_baseline" not in res and "cpu_baseline" in res["omitted_at_n_gt_1"]           # N = 1 only, and the line says so
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
@@ -158,7 +166,7 @@ def test_bench_reports_a_blocked_collective_as_failure(tmp_path):
     """A rank that never reaches the all-gather: the line carries the error and the exit code is non-zero."""
     out = _rehearse(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "0"],
                     {"REHEARSAL_HANG": "1", "REHEARSAL_WATCHDOG_S": "8"}, timeout=240)
-    assert out.returncode != 0
+    assert out.returncode == 3                 # bench.EXIT_COLLECTIVE_TIMEOUT, restored by the launcher from the line
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(lines[0])
