@@ -148,7 +148,7 @@ def test_bench_gpus2_launches_two_ranks_gloo(tmp_path):
     assert "error" not in wc, wc
     assert wc["n_gpus"] == 2 and wc["scaling"] == "strong" and wc["elements"] == 12 * 64 * 64
     assert wc["ms"] > 0 and wc["ms_with_all_gather"] > 0 and wc["gathered_bytes_per_rank"] == 2 * wc["elements"]
-    assert abs(wc["all_gather_ms"] - max(wc["ms_with_all_gather"] - wc["ms"], 1e-6)) < 5e-3 and wc["all_gather_GBps_per_rank"] > 0
+    assert abs(wc["all_gather_ms"] - max(wc["ms_with_all_gather"] - wc["ms"], 1e-6)) < 5e-3 and wc["all_gather_GBps_per_rank"] >= 0
     assert "fp16" in wc["exchange"] and wc["codes_exchange"]["ms_with_all_gather"] > 0
     assert wc["codes_exchange"]["gathered_bytes_per_rank"] < wc["gathered_bytes_per_rank"]
     assert "cpu_baseline" not in res and "cpu_baseline" in res["omitted_at_n_gt_1"]           # N = 1 only, and the line says so
