@@ -3,6 +3,8 @@ CPU with gloo.  The quantizer is injected (the oracle plays the HIP kernel's
 part here; the GPU test runs the real thing)."""
 import os
 import socket
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -11,6 +13,8 @@ import torch.multiprocessing as mp
 
 from fpqvar_amd import calibrate as cal
 from oracle import fpq_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_var_shapes_and_partition_balance():
@@ -125,3 +129,44 @@ def test_format_search_sharded_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_sharded_calibration_validates_before_any_collective():
+    """A shape table that disagrees with the weights, or an owned layer that was not handed over, raises in the
+    constructor - on every rank alike, before the all-gather a late failure would leave the other ranks blocked in.
+    (No process group and no GPU needed: the checks come first.)"""
+    from fpqvar_amd import calibrate as cal
+    shapes = {"a": (4, 128), "b": (2, 128)}
+    w = {"a": torch.zeros(4, 128), "b": torch.zeros(3, 128)}
+    with pytest.raises(RuntimeError, match="`shapes` says"):
+        cal.ShardedCalibration(shapes, w)
+    with pytest.raises(RuntimeError, match="was not given"):
+        cal.ShardedCalibration(shapes, {"a": torch.zeros(4, 128)})
+
+
+def test_gather_slab_fallback_matches_in_place(tmp_path):
+    """FPQ_GATHER_NO_ALIAS=1 (a separate send buffer) and the in-place form fill the slab identically (gloo, world 2)."""
+    script = tmp_path / "g.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from fpqvar_amd import calibrate as cal
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+res = []
+for mode in ("", "1"):
+    if mode:
+        os.environ["FPQ_GATHER_NO_ALIAS"] = mode
+    slab = torch.full((w, 16), -1.0)
+    slab[r] = torch.arange(16.0) + 100 * r
+    cal.gather_slab(slab, r)
+    res.append(slab.clone())
+want = torch.stack([torch.arange(16.0) + 100 * k for k in range(w)])
+assert torch.equal(res[0], want) and torch.equal(res[1], want), (res, want)
+dist.destroy_process_group()
+''' % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FPQ_GATHER_NO_ALIAS")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29731", str(script)], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
