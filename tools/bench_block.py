@@ -8,8 +8,11 @@ random weights, three implementations of everything around the attention core:
      fp16 Linears on the de-quantized tensors (same arithmetic contract as the reference)
   Q  as F but mat_qkv / proj / fc1 run on the FP4 matrix cores (FP4Linear)
 
-Reports the time per block and the agreement of F and Q with R.  Synthetic data; no KV cache (one
-scale step of `rows` = B*L tokens).
+Reports the time per block and the agreement of F and Q with R - and attributes the F / R difference: at the two
+producer sites the rotation is also computed EXACTLY (the fp64 product of the same fp16 operands, rounded to fp16 once),
+and a block E runs on those exact rotations.  F-vs-E and R-vs-E say whose rounding moves the result: the fused kernels'
+(one fp32 accumulation + one rounding) or the reference GEMM's (fp16 tensor-core GEMM with c_h folded into the operands).
+Synthetic data; no KV cache (one scale step of `rows` = B*L tokens).
 """
 import argparse
 import json
@@ -127,6 +130,50 @@ def main():
         f = Fn.linear(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128), wq["fc2"])
         return x + f.mul(gamma2)
 
+    q16d = q32.half().double()          # the operand the reference's autocast GEMM sees: half(Q)
+
+    def exact_rotate(h16):
+        """half( exact product of the fp16 operands ): what both implementations approximate"""
+        return (h16.double().reshape(-1, C) @ q16d).half().view(h16.shape)
+
+    def ref_modulated(x, scale, shift, s):
+        with torch.autocast("cuda", dtype=torch.float16):
+            return Fn.layer_norm(x, (C,), eps=1e-6).mul(scale.add(1)).add_(shift).mul(s).half()   # the cast autocast applies in front of the GEMM
+
+    def block_exact(x):
+        """F's structure with the rotation replaced by the exact one (fp64 GEMM, one rounding), same quantizers and Linears"""
+        _, h1, _ = rot.adaln_rotate_quant(x, scale1, shift1, "e2m1", smooth=s_qkv, return_intermediates=True)
+        a = attention(Fn.linear(qu.fp_quant_e2_per_group_cuda(exact_rotate(h1), 4, 128), wq["qkv"]))
+        a = Fn.linear(qu.fp_quant_e2_per_group_cuda(a, 4, 128), wq["proj"])
+        x = x + a.mul(gamma1)
+        _, h2, _ = rot.adaln_rotate_quant(x, scale2, shift2, "e2m1", smooth=s_fc1, return_intermediates=True)
+        h = Fn.gelu(Fn.linear(qu.fp_quant_e2_per_group_cuda(exact_rotate(h2), 4, 128), wq["fc1"]), approximate="tanh")
+        f = Fn.linear(qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128), wq["fc2"])
+        return x + f.mul(gamma2)
+
+    def site_report(x, scale, shift, s):
+        """rotated values and their E2M1 codes at one producer site: each implementation against the exact rotation of ITS OWN
+        modulated rows (so only the rotation + rounding is compared), and the two modulated rows against each other"""
+        out_f, h_f, y_f = rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s, return_intermediates=True)
+        h_r = ref_modulated(x, scale, shift, s)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y_r = torch.matmul(h_r, q32)
+        e_f, e_r = exact_rotate(h_f), exact_rotate(h_r)
+
+        def neq(a, b):
+            return float((a.view(torch.int16) != b.view(torch.int16)).float().mean())
+
+        def codes_neq(a, b):   # the fake-quantized values stand for the codes (same scale <=> same code)
+            qa, qb = qu.fp_quant_e2_per_group_cuda(a, 4, 128), qu.fp_quant_e2_per_group_cuda(b, 4, 128)
+            return float((qa.view(torch.int16) != qb.view(torch.int16)).float().mean())
+        ulp = lambda a, b: float(((a.float() - b.float()).abs() / (b.float().abs().clamp_min(2.0 ** -14).log2().floor().exp2() * 2.0 ** -10)).max())
+        return {"modulated_rows_F_vs_R_differing": round(neq(h_f, h_r), 6),
+                "rotated_F_vs_exact_differing": round(neq(y_f, e_f), 6), "rotated_F_vs_exact_max_ulp": round(ulp(y_f, e_f), 2),
+                "rotated_R_vs_exact_differing": round(neq(y_r, e_r), 6), "rotated_R_vs_exact_max_ulp": round(ulp(y_r, e_r), 2),
+                "quantized_F_vs_quantized_exact_differing": round(codes_neq(y_f, e_f), 6),
+                "quantized_R_vs_quantized_exact_differing": round(codes_neq(y_r, e_r), 6),
+                "quantized_F_vs_quantized_R_differing": round(codes_neq(y_f, y_r), 6)}
+
     def timed(fn, n=5):
         fn(x)
         torch.cuda.synchronize()
@@ -136,15 +183,19 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
-    yr, yf, yq = block_ref(x).float(), block_fused(x).float(), block_fp4(x).float()
+    yr, yf, yq, ye = block_ref(x).float(), block_fused(x).float(), block_fp4(x).float(), block_exact(x).float()
     delta = (yr - x.float())
 
-    def rel(a):
-        return float((a - yr).norm() / delta.norm())     # error relative to what the block adds to the residual
+    def rel(a, b=None):
+        return float((a - (yr if b is None else b)).norm() / delta.norm())     # error relative to what the block adds to the residual
 
     res = {"rows": B * L, "residual": args.residual, "R_reference_sequence_ms": round(timed(block_ref, 3), 3), "F_fused_fake_quant_ms": round(timed(block_fused), 3),
            "Q_fp4_matrix_cores_ms": round(timed(block_fp4), 3), "F_vs_R_rel_err_of_block_update": round(rel(yf), 5),
-           "Q_vs_R_rel_err_of_block_update": round(rel(yq), 5)}
+           "Q_vs_R_rel_err_of_block_update": round(rel(yq), 5),
+           # attribution: E = the block on EXACT rotations (fp64 product of the same fp16 operands, one rounding)
+           "F_vs_E_rel_err_of_block_update": round(rel(yf, ye), 5), "R_vs_E_rel_err_of_block_update": round(rel(yr, ye), 5),
+           "site_mat_qkv_input": site_report(x, scale1, shift1, s_qkv),
+           "site_fc1_input": site_report(x, scale2, shift2, s_fc1)}
     # the same block without any quantization, for scale
     def block_fp16(x):
         with torch.autocast("cuda", dtype=torch.float16):
