@@ -552,10 +552,10 @@ struct AdalnTiers {
 #ifndef FPQ_ADALN_DB       // 1: two register sets, the next row is requested at the START of the current one (same-process A/B: 95.4 - 97.0 us against 91.9 - 97.6 for the single set, profiles/r03_adaln_ab.txt: not the default)
 #define FPQ_ADALN_DB 0
 #endif
-// NW: wavefronts per workgroup.  8 (TIGHT only) share one set of planes: 49 KiB of LDS, three workgroups = SIX wavefronts
-// per SIMD at <= 80 registers, and the staging of the modulation is paid once per 8 wavefronts.
+// NW: wavefronts per workgroup.  (8 sharing one set of planes - the staging paid once per 8 wavefronts - was measured
+// no faster than 4 and is not built any more, profiles/r03_adaln_partition.txt.)
 template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN, bool X32, bool HW4, bool TIGHT = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8 ? 6 : TIGHT ? 5 : 4) void adaln_mfma_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
+__global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ? 5 : 4) void adaln_mfma_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                               u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                               int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a,
                                                               Lut16Tab tab, AdalnTiers tiers) {
@@ -563,10 +563,14 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
   static_assert(!HW4 || !TOKEN, "hardware E2M1 levels / codes: per group only");
   static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 32 KiB form: fp16 rows of 15 groups, no table");
   constexpr bool MOD16 = sizeof(Tmod) == 2;
-  static_assert(NW == 4 || (NW == 8 && TIGHT), "8 wavefronts per workgroup: the 32 KiB form only");
+  static_assert(NW == 4, "four wavefronts per workgroup");
   constexpr int W = NW;
   constexpr int RV = X32 ? 2 * MAXC : MAXC;      // 16-byte registers of one row per lane
+#ifdef FPQ_ADALN_PV_TEST   // timing experiment only (wrong results): a smaller LDS footprint
+  constexpr int PV = FPQ_ADALN_PV_TEST;
+#else
   constexpr int PV = TIGHT ? 240 : MAXC * 64;    // vectors per modulation plane (not TIGHT: the padding carries zeros)
+#endif
   constexpr int INS = TIGHT ? kRqOutStride : kRqInStride;
   constexpr bool DB = FPQ_ADALN_DB && !X32 && !EMIT;
   uint16_t* lut = nullptr;                       // symmetric tables only: at most 2 x 512 buckets (E2M3)
@@ -575,7 +579,12 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
     lut = lut_s;
   }
   __shared__ u32x4 planes[4][PV];                // A[8v..8v+3], A[8v+4..8v+7], B[8v..8v+3], B[8v+4..8v+7]
-  __shared__ u32x4 images[W][INS];               // 16 groups x INS bytes per wavefront
+  // 16 groups x INS bytes per wavefront.  TIGHT: 15 groups x 272 = 4080 bytes in a 4096-byte slot, planes + images =
+  // 31744 bytes: the most with which FIVE workgroups are resident on a CU (tools/probe/occupancy_census.hip,
+  // profiles/r03_occupancy_census.txt: at 32256 - 32768 bytes the occupancy API still answers 5, the hardware places 4).
+  // Group 15 does not exist in such a row: its lanes write nothing into the image (their slot is the next wavefront's
+  // group 0), what the transform reads there is garbage confined to outputs the buffer range drops.
+  __shared__ u32x4 images[W][TIGHT ? 256 : INS];
   const int vpr = (int)r.vec_per_row;            // host: (MAXC - 1) * 64 < vpr <= MAXC * 64
   FPQ_PHASE("workgroup_prologue");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -706,6 +715,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
   // once the current row has left it.
 #ifdef FPQ_ADALN_STAMPS
   unsigned long long st_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_rows = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole chip
 #endif
   auto do_row = [&](u32x4 (&cur)[RV], u32x4 (&nxt)[RV], int64_t row, int64_t next_row) {
     FPQ_STAMP(0);                                   // between rows (loop control; the first row: the prologue)
@@ -839,7 +849,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
       for (int c = 0; c < 4; ++c) {
         u32x4 hw = {0, 0, 0, 0};
         if (c < MAXC) hw = chunk(c);
-        *(u32x4*)(img + la.in_w + c * (4 * INS)) = hw;
+        if (!TIGHT || c < 3 || lane < 48) *(u32x4*)(img + la.in_w + c * (4 * INS)) = hw;
       }
       if constexpr (MAXC == 5) hw_slot = chunk(4);
     }
@@ -974,9 +984,9 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
         }
       FPQ_STAMP(6);                                 // divide, level, dequantize
 #ifdef FPQ_ADALN_NOMEM
-      rq_store_tile(img, yw, rq_rsrc(out + row * vpr, 0), la);
+      rq_store_tile<TIGHT>(img, yw, rq_rsrc(out + row * vpr, 0), la);
 #else
-      rq_store_tile(img, yw, rq_rsrc(out + row * vpr, vpr * 16), la);
+      rq_store_tile<TIGHT>(img, yw, rq_rsrc(out + row * vpr, vpr * 16), la);
 #endif
       FPQ_STAMP(7);                                 // output image round trip, stores issued
       FPQ_PHASE("row_end");
@@ -1023,11 +1033,18 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : NW == 8
 #ifdef FPQ_ADALN_STAMPS
   if constexpr (!EMIT) {
     if (y_out && lane == 0) {
-      unsigned long long* dst = (unsigned long long*)y_out + ((int64_t)blockIdx.x * W + wave) * 10;
+      unsigned long long* dst = (unsigned long long*)y_out + ((int64_t)blockIdx.x * W + wave) * 16;
 #pragma unroll
       for (int k = 0; k < 8; ++k) dst[k] = st_sum[k];
       dst[8] = st_rows;
       dst[9] = st_last;
+      dst[10] = st_t0;                                   // residency timeline: when and where this wavefront lived
+      dst[11] = __builtin_amdgcn_s_memrealtime();
+      unsigned hw_id, xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      dst[12] = hw_id;
+      dst[13] = xcc_id;
     }
   }
 #endif

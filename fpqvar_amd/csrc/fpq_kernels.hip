@@ -1018,8 +1018,9 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       // (profiles/r02_small_steps.json).  FPQ_ADALN_ROWS=n: n rows per workgroup everywhere; FPQ_ADALN_TAIL=rows: how many
       // rows at the end of the grid go to each of the two finer tiers (default 8192: two generations of resident
       // workgroups at 4 rows and one at 8).
-      // (third generation, large launches: 12 rows on fp16 rows, 8 on fp32 rows - profiles/r03_adaln_partition.txt)
-      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 32768 ? (adaln_butterfly ? 16 : X32 ? 8 : 12) : rows >= 8192 ? 8 : 4);
+      // (third generation, large launches: 8 rows = two per wavefront, with five (fp16 rows) or four workgroups resident per
+      // CU - profiles/r03_adaln_partition.txt)
+      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 8192 ? (adaln_butterfly && rows >= 32768 ? 16 : 8) : 4);
       if (rows_per_wg < 1) rows_per_wg = 1;
       const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
@@ -1046,7 +1047,6 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       // E2M1 values per group: levels from the FP4 conversion hardware, no table (fpq_adaln.h)
       const bool hw4 = table_id == FPQ_E2M1 && !token_mode && !getenv("FPQ_NO_HW4");
       static const bool tight_ok = FPQ_ADALN_TIGHT && !FPQ_ENV("FPQ_ADALN_NO_TIGHT");
-      static const bool nw8 = FPQ_ENV("FPQ_ADALN_NW8") != nullptr;
 #define FPQ_ADALN3(M, CODES, EMIT, TOKEN, HW4, TIGHT)                                                                  \
   hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, CODES, EMIT, TOKEN, X32, HW4, TIGHT>), g3, dim3(kBlock), lds2, st,    \
                      (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, tiers)
@@ -1055,13 +1055,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
     if (!adaln_butterfly) {                                                                                            \
       if constexpr (!(TOKEN)) {                                                                                        \
         if constexpr (M == 4 && !X32 && !(EMIT) && !(CODES)) {                                                                     \
-          if (hw4 && tight_ok && r.vec_per_row == 240) {   /* VAR-d30: 32 KiB of LDS, five workgroups per CU */        \
-            if (nw8) {                                                                                                 \
-              hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, false, false, false, false, true, true, 8>), g3,          \
-                                 dim3(512), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,      \
-                                 rows, ad, r, h.args, tab, tiers);                                                     \
-              break;                                                                                                   \
-            }                                                                                                          \
+          if (hw4 && tight_ok && r.vec_per_row == 240) {   /* VAR-d30: 31 KiB of LDS, five workgroups per CU */        \
             FPQ_ADALN3(M, CODES, EMIT, TOKEN, true, true);                                                             \
             break;                                                                                                     \
           }                                                                                                            \

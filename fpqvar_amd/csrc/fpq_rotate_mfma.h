@@ -185,12 +185,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rq_rsrc(const void* tile_ptr, 
 }
 constexpr int kRqNt = 2;   // cache policy: non-temporal
 
-// this lane's 16 words (8-byte pieces c) into the output image, then 4 coalesced 16-byte vectors per lane out
+// this lane's 16 words (8-byte pieces c) into the output image, then 4 coalesced 16-byte vectors per lane out.
+// SKIP15: the image holds 15 groups only (4080 of a 4096-byte slot) - the four lanes of group 15 write nothing (their
+// pieces would land in the next wavefront's image); what the row-order reads fetch beyond the slot goes to stores that
+// the buffer range drops.
+template <bool SKIP15 = false>
 __device__ __forceinline__ void rq_store_tile(char* img, const uint32_t (&w)[8][2], __amdgpu_buffer_rsrc_t dst,
                                               const RqLaneAddr& la) {
   FPQ_PHASE("store_tile");
+  if (!SKIP15 || (la.lane16 & 0xF0) != 0xF0) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) *(u32x2*)(img + la.out_w + 32 * c) = u32x2{w[c][0], w[c][1]};
+    for (int c = 0; c < 8; ++c) *(u32x2*)(img + la.out_w + 32 * c) = u32x2{w[c][0], w[c][1]};
+  }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

@@ -24,7 +24,7 @@ scale = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
 shift = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
 s = torch.rand(C, device=dev, generator=g) + 0.5
 out = torch.empty(B, L, C, dtype=torch.float16, device=dev)
-stamps = torch.zeros(10 * (1 << 19), dtype=torch.int64, device=dev)
+stamps = torch.zeros(16 * (1 << 19), dtype=torch.int64, device=dev)
 mask = rot._mask_arg(None)
 for it in range(30):
     if it == 29:
@@ -33,7 +33,7 @@ for it in range(30):
                                                _lib.dtype_id(x.dtype), scale.data_ptr(), shift.data_ptr(), _lib.F16, L, 1e-6,
                                                s.data_ptr(), mask, _lib.TABLE_IDS["e2m1"], _lib.stream_ptr(dev)), "stamps")
 torch.cuda.synchronize()
-st = stamps.view(-1, 10).cpu()
+st = stamps.view(-1, 16).cpu()
 st = st[st[:, 8] > 0].double()
 rows = st[:, 8].sum()
 names = ["between rows / prologue", "wait for the row (vmcnt 0)", "statistics + rstd", "modulate -> image (+ prefetch issue)",
@@ -42,3 +42,35 @@ tot = st[:, :8].sum()
 print(f"{dt} [{B}x{L}x{C}]: {int(rows)} rows on {st.shape[0]} wavefronts; {tot / rows:.0f} cycles per row and wavefront")
 for k, n in enumerate(names):
     print(f"  {n:40s} {st[:, k].sum() / rows:8.0f} cycles per row  {100 * st[:, k].sum() / tot:5.1f} %")
+
+# ---- residency timeline: wavefronts alive per CU over the launch (s_memrealtime: 10 ns ticks, chip-wide) ----
+import collections
+t0, t1 = st[:, 10], st[:, 11]
+hw, xcc = st[:, 12].long(), st[:, 13].long() & 0xF
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 0x1
+se = (hw >> 13) & 0x7
+simd = (hw >> 4) & 0x3
+cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+start, end = float(t0.min()), float(t1.max())
+print(f"launch: {(end - start) * 0.01:.1f} us from the first wavefront's start to the last one's end; wavefront lifetime "
+      f"mean {float((t1 - t0).mean()) * 0.01:.1f} us, min {float((t1 - t0).min()) * 0.01:.1f}, max {float((t1 - t0).max()) * 0.01:.1f}")
+print(f"distinct CUs seen: {len(set(cu_key.tolist()))}; wavefronts per CU: min {min(collections.Counter(cu_key.tolist()).values())} "
+      f"max {max(collections.Counter(cu_key.tolist()).values())}")
+nb = 20
+edges = [start + (end - start) * k / nb for k in range(nb + 1)]
+print("resident wavefronts per CU (average over the chip) by twentieth of the launch:")
+row = []
+for k in range(nb):
+    a, b = edges[k], edges[k + 1]
+    overlap = (torch.clamp(t1, max=b) - torch.clamp(t0, min=a)).clamp_min(0).sum()
+    row.append(float(overlap) / (b - a) / 256)
+print("  " + " ".join(f"{v:4.1f}" for v in row))
+mid = start + 0.5 * (end - start)
+alive = ((t0 <= mid) & (t1 >= mid))
+per_cu = collections.Counter(cu_key[alive].tolist())
+vals = sorted(per_cu.values())
+print(f"at mid-launch: {int(alive.sum())} wavefronts alive on {len(per_cu)} CUs; per CU min {vals[0]} median {vals[len(vals) // 2]} max {vals[-1]}")
+per_simd = collections.Counter((cu_key[alive] * 4 + simd[alive]).tolist())
+sv = sorted(per_simd.values())
+print(f"               per SIMD min {sv[0]} median {sv[len(sv) // 2]} max {sv[-1]} ({len(per_simd)} SIMDs with at least one)")

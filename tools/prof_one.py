@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE kernel a few times (for rocprofv3 --pmc passes).
-usage: prof_one.py {adaln|adaln32|rotate|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
+usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_codes|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -31,6 +31,15 @@ if which in ("adaln", "adaln32"):
     shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
     s = torch.rand(C, device=dev) + 0.5
     fn = lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s)
+elif which == "adaln_codes":    # the producer writing packed E2M1 codes + one fp16 scale per group (2.53 B per element)
+    B, L = 100, 655
+    x = torch.randn(B, L, C, device=dev).half()
+    scale = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+    shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+    fn = lambda: rot.adaln_rotate_quant_mx(x, scale, shift)
+elif which == "rotate_codes":
+    x = torch.randn(65536, C, device=dev).half()
+    fn = lambda: rot.rotate_quant_mx(x)
 elif which == "gemm":
     from fpqvar_amd import gemm
     x = torch.randn(65536, C, device=dev).half()
