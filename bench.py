@@ -506,7 +506,7 @@ def own_all(shapes, own, dev):
 def pmc_traffic():
     """HBM bytes per launch of the headline kernel.  NOT measured by this process (rocprofv3 counters cannot be read
     from inside the run): the figure of the committed rocprofv3 --pmc passes of this same command, with its source."""
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -547,7 +547,7 @@ def build_result(args, world, elems, elapsed, kernel_ms, calib, rccl_ranks, data
                      "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                         "from an earlier run (gfx950 FETCH_SIZE x2 correction applied); a constant, not a "
                                         "measurement of this timed region") if traffic_src else None,
-                     "kernel": "rows16_lut_subwave_kernel<16 lanes/group, U=2>",
+                     "kernel": "rows16_lut_subwave_kernel<16 lanes/group, U=1, HW4: E2M1 levels from the FP4 conversion hardware>",
                      "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes": elems * BYTES_PER_ELEM},
     }

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   // the rotation's signs of this lane's chunk (16-byte vector: chunk lane % 16; fp32 rows: half lane & 1 of chunk
   // (lane / 2) % 16) - only to take them off again for the h_out of the emitting form
   uint32_t sx[4] = {0, 0, 0, 0};
-  if constexpr (EMIT || MAXC == 5) {
+  if constexpr (EMIT || MAXC == 5 || MOD16) {   // (MOD16: the staging below puts them on the packed modulation words)
     const int lg = lane & 15;
     const uint32_t sb = (r.sign[lg >> 2] >> ((lg & 3) * 8)) & 0xFFu;
 #pragma unroll
@@ -658,15 +658,33 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       if (TIGHT || v < vpr) {
         const int64_t col = (int64_t)v * 8;
         if constexpr (MOD16) {
+          // fp16 modulation: the sign vector D goes onto the PACKED words (one xor per pair; vector v of a row carries
+          // the signs of chunk v % 16 = lane % 16: the lane constants sx), and one v_fma_mix_f32 per element widens and
+          // applies the smoothing factor (h * s - 0 == h * s, signed zeros included) - about half the vector
+          // instructions of convert, multiply, per-element sign flip, in a prologue every wavefront pays per two rows
           const u32x4 ws = *(const u32x4*)((const _Float16*)ad.scale + b * ad.cols + col);
           const u32x4 wh = *(const u32x4*)((const _Float16*)ad.shift + b * ad.cols + col);
+          float sm[8];
+          if (r.smooth) {
+            const u32x4* sp = (const u32x4*)(r.smooth + col);
+            const u32x4 s0 = sp[0], s1 = sp[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              sm[k] = u2f(s0[k]);
+              sm[4 + k] = u2f(s1[k]);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sm[k] = 1.0f;
+          }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const uint32_t s1p = pk_add_f16(ws[k], 0x3C003C00u);   // scale.add(1) is an fp16 op in the reference
-            sc[2 * k] = h2f(s1p & 0xFFFFu);
-            sc[2 * k + 1] = h2f(s1p >> 16);
-            sh[2 * k] = h2f(wh[k] & 0xFFFFu);
-            sh[2 * k + 1] = h2f(wh[k] >> 16);
+            const uint32_t s1p = pk_add_f16(ws[k], 0x3C003C00u) ^ sx[k];   // scale.add(1) is an fp16 op in the reference
+            const uint32_t shp = wh[k] ^ sx[k];
+            sc[2 * k] = fma_h_lo(s1p, sm[2 * k], -0.0f);
+            sc[2 * k + 1] = fma_h_hi(s1p, sm[2 * k + 1], -0.0f);
+            sh[2 * k] = fma_h_lo(shp, sm[2 * k], -0.0f);
+            sh[2 * k + 1] = fma_h_hi(shp, sm[2 * k + 1], -0.0f);
           }
         } else {
           const u32x4* ap = (const u32x4*)((const float*)ad.scale + b * ad.cols + col);
@@ -679,26 +697,26 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
             sh[k] = u2f(b0[k]);
             sh[4 + k] = u2f(b1[k]);
           }
-        }
-        if (r.smooth) {
-          const u32x4* sp = (const u32x4*)(r.smooth + col);
-          const u32x4 s0 = sp[0], s1 = sp[1];
+          if (r.smooth) {
+            const u32x4* sp = (const u32x4*)(r.smooth + col);
+            const u32x4 s0 = sp[0], s1 = sp[1];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            sc[k] *= u2f(s0[k]);
-            sh[k] *= u2f(s0[k]);
-            sc[4 + k] *= u2f(s1[k]);
-            sh[4 + k] *= u2f(s1[k]);
+            for (int k = 0; k < 4; ++k) {
+              sc[k] *= u2f(s0[k]);
+              sh[k] *= u2f(s0[k]);
+              sc[4 + k] *= u2f(s1[k]);
+              sh[4 + k] *= u2f(s1[k]);
+            }
           }
-        }
-        // the rotation's sign vector D rides on the modulation: half(-t) == -half(t), so h * D = half(fma(ln, A*D, B*D))
-        const int j0 = (v * 8) & 127;
-        const uint32_t dbits = (r.sign[j0 >> 5] >> (j0 & 31)) & 0xFFu;
+          // the rotation's sign vector D rides on the modulation: half(-t) == -half(t), so h * D = half(fma(ln, A*D, B*D))
+          const int j0 = (v * 8) & 127;
+          const uint32_t dbits = (r.sign[j0 >> 5] >> (j0 & 31)) & 0xFFu;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t flip = ((dbits >> k) & 1u) << 31;
-          sc[k] = u2f(fbits(sc[k]) ^ flip);
-          sh[k] = u2f(fbits(sh[k]) ^ flip);
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t flip = ((dbits >> k) & 1u) << 31;
+            sc[k] = u2f(fbits(sc[k]) ^ flip);
+            sh[k] = u2f(fbits(sh[k]) ^ flip);
+          }
         }
       } else {
 #pragma unroll

@@ -895,6 +895,9 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
 #ifndef FPQ_FAST16_U   // vectors per lane of the sub-wavefront row kernels (A/B builds)
 #define FPQ_FAST16_U 2
 #endif
+#ifndef FPQ_FAST16_HW4_U   // ... of the table-free E2M1 form
+#define FPQ_FAST16_HW4_U 1
+#endif
 template <bool DUAL, int U = FPQ_FAST16_U, bool NTL = true, bool NTS = true>
 int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id, hipStream_t st,
                   int grid_cap = 1 << 20, uint32_t* nan_flag = nullptr) {
@@ -917,8 +920,16 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   // the headline shape - E2M1, groups of 128 - takes its levels from the FP4 conversion hardware (fpq_fast16.h); FPQ_NO_HW4
   // (read at every call: the exhaustive test sweeps both forms in one process) keeps the bucket table
   if constexpr (!DUAL) {
-    if (lpr == 16 && neg_id == FPQ_E2M1 && pos_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4"))
-      return go(rows16_lut_subwave_kernel<16, false, U, true, NTL, NTS, true>, rows16_lut_subwave_kernel<16, false, U, true, NTL, NTS, true>);
+    if (lpr == 16 && neg_id == FPQ_E2M1 && pos_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4")) {
+      // no table to stage, so nothing to amortise over a tile: ONE vector per lane on the full grid, the best plain-copy
+      // shape of this chip (profiles/r02_copy_persistent_probe.txt: 0.81 against 0.777 for 8 KiB tiles); same-process
+      // A/B against U = 2: 77.0 - 77.5 vs 79.0 - 79.4 us in steady state (profiles/r03_headline_u1.txt)
+      constexpr int U1 = FPQ_FAST16_HW4_U;
+      const int64_t tiles1 = (n_vec + (int64_t)kBlock * U1 - 1) / ((int64_t)kBlock * U1);
+      hipLaunchKernelGGL((rows16_lut_subwave_kernel<16, false, U1, true, NTL, NTS, true>), dim3(grid_for(tiles1, grid_cap)),
+                         dim3(kBlock), lds, st, (const u32x4*)x, (u32x4*)out, n_vec, args, h.tab);
+      return check_launch();
+    }
   }
 #define FPQ_FAST16_CASE(L) \
   case L: return go(rows16_lut_subwave_kernel<L, DUAL, U, true, NTL, NTS>, rows16_lut_subwave_kernel<L, DUAL, U, false, NTL, NTS>);
