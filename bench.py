@@ -245,13 +245,18 @@ def other_kernels(dev):
     from fpqvar_amd import ops, rotation as rot
     out = {}
 
-    def timed(fn, iters=20, max_bursts=40):
+    def timed(fn, iters=40, max_bursts=40, lead=4):
         """Steady-state time per call: bursts of `iters` calls (HIP events around each burst) until three consecutive
         bursts agree within 2 % - a kernel's first hundred launches after a change of workload run up to 25 % slow on
         this chip while the clocks settle (profiles/r02_ab_adaln_variants.txt) - then the minimum of those three and two
-        more."""
+        more.  Every burst starts with `lead` untimed calls on the same stream: the first launch after the idle gap of
+        a synchronize runs at the idle core clock (adaLN producer: 126 us against 85 for the launches behind it,
+        profiles/r03_burst_lead.txt - 2 to 4 us on the average of a short burst for the kernels that are close to
+        vector-issue-bound, nothing for the streaming ones); in a model these kernels follow each other without a gap."""
         def burst():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(lead):
+                fn()
             e0.record()
             for _ in range(iters):
                 fn()
@@ -372,12 +377,13 @@ def other_kernels(dev):
         out["gemm_fp4_w4a4_mat_qkv_65536x1920x5760"] = {"ms": round(ms, 4),
                                                         "TFLOPs": round(2.0 * ROWS * COLS * 3 * COLS / ms / 1e9, 1)}
 
-    guarded("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4)
-    guarded("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6)
-    guarded("activations_fp16_65536x1920", act16)
-    guarded("operand_emitting_producers_65536x1920", operands)
-    guarded("weights_fp32_32768x1920", weights)
-    guarded("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", consumers)
+    groups = [("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4), ("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6),
+              ("activations_fp16_65536x1920", act16), ("operand_emitting_producers_65536x1920", operands),
+              ("weights_fp32_32768x1920", weights), ("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", consumers)]
+    only = os.environ.get("FPQ_BENCH_GROUPS")   # profiling aid: a comma-separated subset of the group functions' names
+    for name, fn in groups:
+        if not only or fn.__name__ in only.split(","):
+            guarded(name, fn)
     return out
 
 

@@ -12,11 +12,14 @@ _lib._lib = l
 dev = torch.device("cuda:0")
 B, L, C = (int(a) for a in sys.argv[2:5]) if len(sys.argv) > 4 else (100, 655, 1920)
 xs = [torch.randn(B, L, C, device=dev).half() for _ in range(3)]
+if os.environ.get("TIME_X32"):
+    xs = [x.float() for x in xs]
 sc = (torch.randn(B, 1, C, device=dev) * 0.3).half(); sh = (torch.randn(B, 1, C, device=dev) * 0.3).half()
+sm = (torch.rand(C, device=dev) + 0.5) if os.environ.get("TIME_SMOOTH") else None
 k = 0
 def run():
     global k; k += 1
-    return rot.adaln_rotate_quant(xs[k % 3], sc, sh, "e2m1")
+    return rot.adaln_rotate_quant(xs[k % 3], sc, sh, "e2m1", smooth=sm)
 for _ in range(200): run()
 torch.cuda.synchronize()
 best = 1e9
@@ -26,5 +29,14 @@ for _ in range(4):
     for _ in range(50): run()
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 50 * 1e3)
+if os.environ.get("TIME_SUSTAIN"):   # the same call for seconds on end: does the time drift once the chip is warm?
+    series = []
+    for _ in range(int(os.environ["TIME_SUSTAIN"])):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200): run()
+        e1.record(); torch.cuda.synchronize()
+        series.append(round(e0.elapsed_time(e1) / 200 * 1e3, 1))
+    print("sustained, 200 launches per figure:", series, flush=True)
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FPQ_"))
 print(f"{os.path.basename(sys.argv[1]):22s} {tag:24s} [{B}x{L}x{C}] {best:7.1f} us  frac {B*L*C*4/best/1e6/8:.3f}", flush=True)
