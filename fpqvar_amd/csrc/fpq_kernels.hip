@@ -967,16 +967,21 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   // values out: the transform on the matrix cores (fpq_rotate_mfma.h), one 32-group tile per wavefront
   static const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
   if (!butterfly) {
-    // persistent wavefronts, every workgroup the same number of passes (FPQ_ROT_WAVES workgroups per CU are resident; twice as many shorter ones measured 2 % faster: 84.2 vs 85.9 us)
+    // Every workgroup the same number of passes over its tiles.  With a bucket table to stage per workgroup the grid is
+    // two generations of the FPQ_ROT_WAVES workgroups a CU holds (3072: 84.2 us against 85.9 for one generation, round 2).
+    // The table-free E2M1 forms have next to no prologue and want SHORT workgroups - the grid drains faster at its end:
+    // values out, 3072 / 7680 / 12288 / 16384 workgroups: 83.2 / 82.2 / 82.1 / 80.3 us (one pass each at [65536 x 1920]);
+    // codes out: 57.3 / 52.8 / 53.0 / 53.6 us (profiles/r03_rotate_grid.txt).  FPQ_ROT_WGS overrides.
+    const bool hw4 = table_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4");   // E2M1 values or FP4 operands: levels / codes from the conversion hardware
     const int64_t per_wg = (int64_t)(kBlock / 64) * kRqTileVec;
     const int64_t wg_tiles = (n_vec + per_wg - 1) / per_wg;
-    static const int64_t resident = [] { const char* e = FPQ_ENV("FPQ_ROT_WGS"); return e ? atoll(e) : 2 * 256ll * FPQ_ROT_WAVES; }();
+    static const int64_t resident_env = [] { const char* e = FPQ_ENV("FPQ_ROT_WGS"); return e ? atoll(e) : 0ll; }();
+    const int64_t resident = resident_env > 0 ? resident_env : !hw4 ? 2 * 256ll * FPQ_ROT_WAVES : code_scales ? 8192 : 16384;
     const int64_t passes = (wg_tiles + resident - 1) / resident;
     const dim3 mgrid((unsigned)((wg_tiles + passes - 1) / passes));
 #define FPQ_ROT_MFMA(EMIT, SMOOTH, ...)                                                                             \
   hipLaunchKernelGGL((rotate_quant_mfma_kernel<Tin, EMIT, SMOOTH, ##__VA_ARGS__>), mgrid, dim3(kBlock), lds, st, x, \
                      (u32x4*)out, (u32x4*)rot_out, n_vec, r, h.args, tab)
-    const bool hw4 = table_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4");   // E2M1 values or FP4 operands: levels / codes from the conversion hardware
     if (code_scales && hw4) { if (smooth) FPQ_ROT_MFMA(false, true, true, true); else FPQ_ROT_MFMA(false, false, true, true); }
     else if (code_scales) { if (smooth) FPQ_ROT_MFMA(false, true, true); else FPQ_ROT_MFMA(false, false, true); }
     else if (rot_out && hw4) { if (smooth) FPQ_ROT_MFMA(true, true, false, true); else FPQ_ROT_MFMA(true, false, false, true); }
@@ -1029,9 +1034,12 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       // (profiles/r02_small_steps.json).  FPQ_ADALN_ROWS=n: n rows per workgroup everywhere; FPQ_ADALN_TAIL=rows: how many
       // rows at the end of the grid go to each of the two finer tiers (default 8192: two generations of resident
       // workgroups at 4 rows and one at 8).
-      // (third generation, large launches: 8 rows = two per wavefront, with five (fp16 rows) or four workgroups resident per
-      // CU - profiles/r03_adaln_partition.txt)
-      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 8192 ? (adaln_butterfly && rows >= 32768 ? 16 : 8) : 4);
+      // (third generation, large launches: 8 rows = two per wavefront for the stream-bound forms - E2M1 values out, fp32
+      // rows; 12 for the forms bound by vector issue - operands out or a bucket table, from fp16 rows - where the
+      // prologue's instructions per row count: 73.3 -> 70.5 us for codes, 89.7 -> 87.1 for E4M3 bytes, 96.2 -> 93.4 for
+      // per-token E2M3 values; profiles/r03_adaln_partition.txt)
+      const bool issue_bound = !X32 && (code_scales != nullptr || token_mode != 0 || table_id != FPQ_E2M1);
+      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 8192 ? (adaln_butterfly && rows >= 32768 ? 16 : issue_bound && rows >= 32768 ? 12 : 8) : 4);
       if (rows_per_wg < 1) rows_per_wg = 1;
       const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;

@@ -13,6 +13,8 @@ k = 0
 def run():
     global k
     k += 1
+    if os.environ.get("SWEEP_CODES"):   # the operand-emitting form: packed E2M1 codes + fp16 group scales (2.53 B per element)
+        return rot.rotate_quant_mx(xs[k % 4])
     return rot.rotate_quant(xs[k % 4], "e2m1")
 for _ in range(200):
     run()
@@ -27,4 +29,4 @@ for _ in range(5):
     torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1) / 50 * 1e3)
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FPQ_ROT"))
-print(f"{tag or 'default':40s} " + " ".join(f"{r:6.1f}" for r in res) + f"  us   min {min(res):.1f}  frac {65536*1920*4/min(res)/1e6/8:.3f}")
+print(f"{tag or 'default':40s} " + " ".join(f"{r:6.1f}" for r in res) + f"  us   min {min(res):.1f}  frac {65536*1920*(2 + 0.5 + 2 / 128 if os.environ.get('SWEEP_CODES') else 4)/min(res)/1e6/8:.3f}")

@@ -19,6 +19,13 @@ sm = (torch.rand(C, device=dev) + 0.5) if os.environ.get("TIME_SMOOTH") else Non
 k = 0
 def run():
     global k; k += 1
+    case = os.environ.get("TIME_CASE", "values")
+    if case == "codes":      # packed E2M1 codes + fp16 group scales
+        return rot.adaln_rotate_quant_mx(xs[k % 3], sc, sh, smooth=sm)
+    if case in ("fp8", "fp6"):   # per-token operand outputs
+        return rot.adaln_rotate_quant_token(xs[k % 3], sc, sh, "e2m3", smooth=sm, emit=case)
+    if case == "token":
+        return rot.adaln_rotate_quant_token(xs[k % 3], sc, sh, "e2m3", smooth=sm)
     return rot.adaln_rotate_quant(xs[k % 3], sc, sh, "e2m1", smooth=sm)
 for _ in range(200): run()
 torch.cuda.synchronize()
@@ -38,5 +45,5 @@ if os.environ.get("TIME_SUSTAIN"):   # the same call for seconds on end: does th
         e1.record(); torch.cuda.synchronize()
         series.append(round(e0.elapsed_time(e1) / 200 * 1e3, 1))
     print("sustained, 200 launches per figure:", series, flush=True)
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FPQ_"))
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith(("FPQ_", "TIME_CASE", "TIME_X32")))
 print(f"{os.path.basename(sys.argv[1]):22s} {tag:24s} [{B}x{L}x{C}] {best:7.1f} us  frac {B*L*C*4/best/1e6/8:.3f}", flush=True)
