@@ -245,14 +245,19 @@ def other_kernels(dev):
     from fpqvar_amd import ops, rotation as rot
     out = {}
 
-    def timed(fn, iters=40, max_bursts=40, lead=4):
+    burst_env = os.environ.get("FPQ_BENCH_BURST")   # "launches,lead": protocol experiments (profiles/r03_burst_lead.txt)
+    d_iters, d_lead = (int(v) for v in burst_env.split(",")) if burst_env else (100, 10)
+
+    def timed(fn, iters=d_iters, max_bursts=40, lead=d_lead):
         """Steady-state time per call: bursts of `iters` calls (HIP events around each burst) until three consecutive
         bursts agree within 2 % - a kernel's first hundred launches after a change of workload run up to 25 % slow on
         this chip while the clocks settle (profiles/r02_ab_adaln_variants.txt) - then the minimum of those three and two
-        more.  Every burst starts with `lead` untimed calls on the same stream: the first launch after the idle gap of
-        a synchronize runs at the idle core clock (adaLN producer: 126 us against 85 for the launches behind it,
-        profiles/r03_burst_lead.txt - 2 to 4 us on the average of a short burst for the kernels that are close to
-        vector-issue-bound, nothing for the streaming ones); in a model these kernels follow each other without a gap."""
+        more.  Every burst starts with `lead` untimed calls on the same stream: after the idle gap of a synchronize the
+        core clock needs about a millisecond of load to come back (adaLN producer: first launch 126 us against 85 for
+        the ones behind it; per-call averages of 88.9 / 86.9 / 85.9 / 85.2 us for bursts of 20 / 40+4 / 100+10 / 200+20
+        launches on one box, profiles/r03_burst_lead.txt) - the kernels near the vector-issue limit feel it, the
+        streaming ones do not; in a model these kernels follow each other without a gap.  Default: 100 timed launches
+        behind 10 untimed ones."""
         def burst():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(lead):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE kernel a few times (for rocprofv3 --pmc passes).
-usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_codes|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
+usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -63,6 +63,10 @@ elif which == "dual6":
 elif which == "rotate":
     x = torch.randn(65536, C, device=dev).half()
     fn = lambda: rot.rotate_quant(x, "e2m1")
+elif which == "rotate_smooth":   # with a GALT smoothing vector: the SMOOTH = 1 instantiation (one resident workgroup fewer per CU)
+    x = torch.randn(65536, C, device=dev).half()
+    s = torch.rand(C, device=dev) + 0.5
+    fn = lambda: rot.rotate_quant(x, "e2m1", smooth=s)
 elif which == "dual":
     x = torch.nn.functional.gelu(torch.randn(65536, C, device=dev)).half()
     fn = lambda: ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", 128, None)
