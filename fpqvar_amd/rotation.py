@@ -73,7 +73,30 @@ def paley_hadamard_ii(q: int) -> torch.Tensor:
     return torch.cat([torch.cat([c + eye, c - eye], 1), torch.cat([c - eye, -c - eye], 1)], 0)
 
 
-_PALEY = {140: lambda: paley_hadamard_i(139), 108: lambda: paley_hadamard_i(107), 60: lambda: paley_hadamard_i(59),
+def williamson_hadamard(n: int, minus) -> torch.Tensor:
+    """Williamson's array  [[A, B, C, D], [-B, A, -D, C], [-C, D, A, -B], [-D, -C, B, A]]  of four symmetric circulant
+    +-1 matrices of order n (row i of a block = its first row rotated right by i); `minus[t]` is the bit mask of the -1
+    entries of block t's first row.  AA' + BB' + CC' + DD' = 4n I makes it a Hadamard matrix of order 4n.  The reference's
+    literal had52 / had156 / had172 (hadamard_utils.py:666, 2057, 2998 - Sloane's had.52.will, had.156.will,
+    had.172.will) are exactly this array for n = 13, 39, 43 with the first rows below."""
+    idx = (torch.arange(n).view(1, n) - torch.arange(n).view(n, 1)) % n          # [i, j] -> (j - i) mod n
+    blocks = []
+    for m in minus:
+        row = torch.tensor([-1.0 if (m >> i) & 1 else 1.0 for i in range(n)], dtype=torch.float64)
+        assert torch.equal(row[1:], row[1:].flip(0)), "a Williamson block is symmetric"
+        blocks.append(row[idx])
+    a, b, c, d = blocks
+    return torch.cat([torch.cat([a, b, c, d], 1), torch.cat([-b, a, -d, c], 1),
+                      torch.cat([-c, d, a, -b], 1), torch.cat([-d, -c, b, a], 1)], 0)
+
+
+_WILLIAMSON = {52: (13, (0x161a, 0x1c0e, 0xb34, 0x1ede)),
+               156: (39, (0x1afb3cdf58, 0xecf5af370, 0x1975bdae98, 0x72be247d4e)),
+               172: (43, (0x730a26450ce, 0x207ac935e04, 0x14d42f42b28, 0x385b3fcda1c))}
+
+_PALEY = {172: lambda: williamson_hadamard(*_WILLIAMSON[172]), 156: lambda: williamson_hadamard(*_WILLIAMSON[156]),
+          52: lambda: williamson_hadamard(*_WILLIAMSON[52]),
+          140: lambda: paley_hadamard_i(139), 108: lambda: paley_hadamard_i(107), 60: lambda: paley_hadamard_i(59),
           36: lambda: paley_hadamard_ii(17), 28: lambda: paley_hadamard_ii(13),
           40: lambda: torch.kron(sylvester(2), paley_hadamard_i(19)),          # the reference's had40 is the doubled had20
           20: lambda: paley_hadamard_i(19), 12: lambda: paley_hadamard_i(11)}
@@ -85,10 +108,7 @@ def get_hadK(n: int, transpose: bool = False):
     for k in (172, 156, 140, 108, 60, 52, 36, 28, 40, 20, 12):
         if n % k == 0:
             assert (n // k) & (n // k - 1) == 0
-            if k not in _PALEY:
-                raise NotImplementedError(f"the Hadamard matrix of order {k} (n = {n}) is not one of the generated "
-                                          f"constructions (orders {sorted(_PALEY)})")
-            h = _PALEY[k]()
+            h = _PALEY[k]()           # every order of the reference's ladder is generated (Paley I / II, Williamson)
             return (h.T.contiguous() if transpose else h), k
     assert n & (n - 1) == 0
     return None, 1

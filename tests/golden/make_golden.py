@@ -298,7 +298,7 @@ def main():
 
     # ---- 7. full-width (non-block) rotation: the literal Hadamard tables, Q for VAR's widths, rotate_model(False) ----
     import hashlib
-    for k in (12, 20, 28, 36, 40, 60, 108, 140):
+    for k in (12, 20, 28, 36, 40, 60, 108, 140, 52, 156, 172):
         had, kk = hu.get_hadK(k)
         assert kk == k
         out[f"had/table/{k}"] = had.numpy().astype(np.int8)

@@ -76,7 +76,7 @@ def test_model_level_preprocessing_matches_the_reference(golden):
 
 def test_full_width_hadamard_matches_the_reference(golden):
     """The non-block rotation (rotate_utils/rotation_utils.py:211-222 with hadamard_utils.get_hadK: had60 x 2^5 for
-    1920, had36 x 2^6 for 2304, ...): the generated Paley tables equal the reference's literal ones, Q for VAR's
+    1920, had36 x 2^6 for 2304, ...): the generated Paley and Williamson tables equal the reference's literal ones, Q for VAR's
     widths is bit-equal (SHA-256 of the float64 bytes + sampled rows), rotate_model(block_rotate=False) reproduces
     the reference's rotated weights."""
     import hashlib
@@ -85,16 +85,17 @@ def test_full_width_hadamard_matches_the_reference(golden):
     from fpqvar_amd import rotation as rot
     from tests.conftest import assert_bits_equal, from_bits
 
-    for k in (12, 20, 28, 36, 40, 60, 108, 140):
+    for k in (12, 20, 28, 36, 40, 60, 108, 140, 52, 156, 172):   # Paley I / II; 52, 156, 172: Williamson arrays
         had, kk = rot.get_hadK(k)
         assert kk == k and torch.equal(had, torch.from_numpy(golden[f"had/table/{k}"]).double()), k
         assert torch.equal(had @ had.T, k * torch.eye(k, dtype=torch.float64))
         assert torch.equal(rot.get_hadK(k, transpose=True)[0], had.T)
     assert rot.get_hadK(1024) == (None, 1)
     assert rot.get_hadK(1920)[1] == 60 and rot.get_hadK(2304)[1] == 36 and rot.get_hadK(1280)[1] == 40 and rot.get_hadK(1536)[1] == 12
-    for n in (2 * 52, 4 * 172, 8 * 156):
-        with pytest.raises(NotImplementedError):
-            rot.get_hadK(n)
+    for n, k in ((2 * 52, 52), (4 * 172, 172), (8 * 156, 156), (11008, 172)):   # 11008 = 172 * 64
+        assert rot.get_hadK(n)[1] == k
+        h = rot.hadamard_matrix(n) if n < 2000 else None
+        assert h is None or torch.equal(h @ h.T, n * torch.eye(n, dtype=torch.float64))
     for n in (1280, 1536, 1920, 2304):
         q = rot.random_hadamard_matrix(n, "cpu", 42)
         assert q.dtype == torch.float64 and q.shape == (n, n)

@@ -12,7 +12,7 @@ strip='s/^"(_ZN12_GLOBAL__N_[0-9]*[a-z_0-9]*)[^"]*"/\1/; s/^"void \(anonymous na
 if [ "$1" = pmc ]; then
   for k in ${2:-adaln adaln32 adaln_codes rotate rotate_codes sym}; do
     tools/pmc_run.sh $k > /dev/null 2>&1
-    { echo "# tools/pmc_run.sh $k  (tools/prof_one.py $k; averages per launch over 5 launches)"
+    { echo "# tools/pmc_run.sh $k  (tools/prof_one.py $k; averages per launch over 6 launches on three inputs in turn)"
       cat gpurun_out/pmc_$k/p1.summary.txt gpurun_out/pmc_$k/p2.summary.txt gpurun_out/pmc_$k/p3.summary.txt gpurun_out/pmc_$k/p4.summary.txt
       echo "# rocprofv3 --kernel-trace --stats of the same script:"
       grep -E "^\"_ZN12_GLOBAL__N_|^\"void \(anonymous namespace\)::" gpurun_out/pmc_$k/kernel_stats.csv | sed -E "$strip"; } > $out/pmc_$k.txt

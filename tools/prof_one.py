@@ -22,24 +22,32 @@ which = sys.argv[1] if len(sys.argv) > 1 else "sym"
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 C = 1920
+_k = [0]
+
+
+def nxt(ts):   # three inputs in turn: a single 252 MB tensor would be served partly from the 256 MiB Infinity Cache
+    _k[0] += 1
+    return ts[_k[0] % len(ts)]
+
+
 if which in ("adaln", "adaln32"):
     B, L = 100, 655
-    x = torch.randn(B, L, C, device=dev)
+    xs = [torch.randn(B, L, C, device=dev) for _ in range(3)]
     if which == "adaln":
-        x = x.half()
+        xs = [t.half() for t in xs]
     scale = (torch.randn(B, 1, C, device=dev) * 0.3).half()
     shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
     s = torch.rand(C, device=dev) + 0.5
-    fn = lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=s)
+    fn = lambda: rot.adaln_rotate_quant(nxt(xs), scale, shift, "e2m1", smooth=s)
 elif which == "adaln_codes":    # the producer writing packed E2M1 codes + one fp16 scale per group (2.53 B per element)
     B, L = 100, 655
-    x = torch.randn(B, L, C, device=dev).half()
+    xs = [torch.randn(B, L, C, device=dev).half() for _ in range(3)]
     scale = (torch.randn(B, 1, C, device=dev) * 0.3).half()
     shift = (torch.randn(B, 1, C, device=dev) * 0.3).half()
-    fn = lambda: rot.adaln_rotate_quant_mx(x, scale, shift)
+    fn = lambda: rot.adaln_rotate_quant_mx(nxt(xs), scale, shift)
 elif which == "rotate_codes":
-    x = torch.randn(65536, C, device=dev).half()
-    fn = lambda: rot.rotate_quant_mx(x)
+    xs = [torch.randn(65536, C, device=dev).half() for _ in range(3)]
+    fn = lambda: rot.rotate_quant_mx(nxt(xs))
 elif which == "gemm":
     from fpqvar_amd import gemm
     x = torch.randn(65536, C, device=dev).half()
@@ -61,18 +69,18 @@ elif which == "dual6":
     x = torch.nn.functional.gelu(torch.randn(65536, 4 * C, device=dev)).half()
     fn = lambda: ops.quant_rows_dual(x, "int_neg", "e2m3_pos", 128, None)
 elif which == "rotate":
-    x = torch.randn(65536, C, device=dev).half()
-    fn = lambda: rot.rotate_quant(x, "e2m1")
+    xs = [torch.randn(65536, C, device=dev).half() for _ in range(3)]
+    fn = lambda: rot.rotate_quant(nxt(xs), "e2m1")
 elif which == "rotate_smooth":   # with a GALT smoothing vector: the SMOOTH = 1 instantiation (one resident workgroup fewer per CU)
-    x = torch.randn(65536, C, device=dev).half()
+    xs = [torch.randn(65536, C, device=dev).half() for _ in range(3)]
     s = torch.rand(C, device=dev) + 0.5
-    fn = lambda: rot.rotate_quant(x, "e2m1", smooth=s)
+    fn = lambda: rot.rotate_quant(nxt(xs), "e2m1", smooth=s)
 elif which == "dual":
     x = torch.nn.functional.gelu(torch.randn(65536, C, device=dev)).half()
     fn = lambda: ops.quant_rows_dual(x, "e1m2_neg", "e2m1_pos", 128, None)
 else:
-    x = torch.randn(65536, C, device=dev).half()
-    fn = lambda: qu.fp_quant_e2_per_group_cuda(x, 4, 128)
-for _ in range(5):
+    xs = [torch.randn(65536, C, device=dev).half() for _ in range(3)]
+    fn = lambda: qu.fp_quant_e2_per_group_cuda(nxt(xs), 4, 128)
+for _ in range(6):
     fn()
 torch.cuda.synchronize()
