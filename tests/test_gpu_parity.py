@@ -784,6 +784,23 @@ def test_producers_at_full_size_equal_their_slices(dev, x_dtype):
         assert_bits_equal(tok[b0:b1], orc.per_token_kernel_sem(y_p.cpu(), "e2m3"), f"adaln per token {b0}:{b1}")
 
 
+def test_rotate_quant_several_passes_ragged_end(dev):
+    """The table-free rotate forms run one pass per workgroup up to 16384 (values) / 8192 (codes) workgroups and several
+    beyond: 70001 rows of 1920 = 16407 workgroup-tiles, the last one partial - two passes per workgroup in both forms,
+    a grid that does not divide the tiles.  Against launches on slices (one pass) and the oracle."""
+    from fpqvar_amd import gemm, rotation as rot
+    g = torch.Generator(device=dev).manual_seed(321)
+    R, C = 70001, 1920
+    x = (torch.randn(R, C, device=dev, generator=g) * 0.7).half()
+    out = rot.rotate_quant(x, "e2m1")
+    codes, scales = rot.rotate_quant_mx(x)
+    for lo, hi in ((0, 129), (34990, 35100), (65500, 65700), (R - 131, R)):
+        o_s, y_s = rot.rotate_quant(x[lo:hi].contiguous(), "e2m1", return_rotated=True)
+        assert_bits_equal(out[lo:hi], o_s, f"rows {lo}:{hi}")
+        assert_bits_equal(o_s, orc.per_group_kernel_sem(y_s.cpu(), "e2m1", 128), f"oracle rows {lo}:{hi}")
+        assert_bits_equal(gemm.dequantize_mx(codes[lo:hi].contiguous(), scales[lo:hi].contiguous()).half(), o_s, f"codes rows {lo}:{hi}")
+
+
 # ------------------------------------------------------------------ KV cache step and format search
 def test_kv_cache_step(dev):
     from fpqvar_amd import kv_cache as kv
