@@ -976,7 +976,9 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
     const int64_t per_wg = (int64_t)(kBlock / 64) * kRqTileVec;
     const int64_t wg_tiles = (n_vec + per_wg - 1) / per_wg;
     static const int64_t resident_env = [] { const char* e = FPQ_ENV("FPQ_ROT_WGS"); return e ? atoll(e) : 0ll; }();
-    const int64_t resident = resident_env > 0 ? resident_env : !hw4 ? 2 * 256ll * FPQ_ROT_WAVES : code_scales ? 8192 : 16384;
+    // (with a smoothing vector every workgroup stages it - 7.5 KiB at C = 1920 - so a few passes each: 7680 / 2560)
+    const int64_t resident = resident_env > 0 ? resident_env : !hw4 ? 2 * 256ll * FPQ_ROT_WAVES
+                             : smooth ? (code_scales ? 2560 : 7680) : code_scales ? 8192 : 16384;
     const int64_t passes = (wg_tiles + resident - 1) / resident;
     const dim3 mgrid((unsigned)((wg_tiles + passes - 1) / passes));
 #define FPQ_ROT_MFMA(EMIT, SMOOTH, ...)                                                                             \

@@ -50,6 +50,7 @@ constexpr int kRqTileVec = 256;   // 16 groups x 16 vectors of 8 halves per wave
 //       8-byte pieces in (piece c of lane (g, quarter) = outputs 16 c + 4 quarter ..): base + 32 c (two lanes per bank
 //       pair - the store's own transfer time covers it);  16-byte vectors out in row order: base + i * 1088.
 constexpr int kRqInStride = 288, kRqOutStride = 272;
+constexpr int kRqSmoothMax = 2560;   // channels of a smoothing vector kept in LDS by the rotate kernel (VAR: 1024 .. 2304)
 constexpr int kRqImageBytes = 16 * kRqInStride;           // 4608 per wavefront
 constexpr int kRqImageVec = kRqImageBytes / 16;
 
@@ -378,6 +379,18 @@ __global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES)
     lut = lut_s;
   }
   __shared__ u32x4 xpose[kBlock / 64][kRqImageVec];   // 4.5 KiB per wavefront, private to it
+  // SMOOTH: the vector (<= kRqSmoothMax channels: every VAR width) is staged in LDS once per workgroup; a tile's chunk of
+  // it is two ds_read_b128 at (column chunk) * 32 bytes.  Round 2 read it from global memory behind a 64-bit modulo per
+  // vector, inside the tile's dependency chain: 280 us per [65536 x 1920] against 80 without a vector
+  // (profiles/r03_pmc_rotate_smooth.txt, first measurement of this instantiation).  Wider rows keep global loads.
+  constexpr int kSmoothLds = SMOOTH ? kRqSmoothMax : 4;
+  __shared__ __attribute__((aligned(16))) float smooth_s[kSmoothLds];
+  const uint32_t vpr32 = (uint32_t)r.vec_per_row;
+  const bool smooth_in_lds = SMOOTH && vpr32 * 8u <= (uint32_t)kRqSmoothMax;
+  if constexpr (SMOOTH) {
+    if (smooth_in_lds)
+      for (uint32_t i = threadIdx.x; i < vpr32 * 2u; i += kBlock) ((u32x4*)smooth_s)[i] = ((const u32x4*)r.smooth)[i];
+  }
 #ifndef FPQ_ROT_PREFETCH16
 #define FPQ_ROT_PREFETCH16 1
 #endif
@@ -408,11 +421,24 @@ __global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES)
 
   RqRaw<Tin> raw;
   if (PREFETCH) rq_load_tile<Tin>(in_rsrc(tile), lane, raw);
-  if constexpr (!HW4) {
-    lut16_stage(lut, tab, a.shift);
-    __syncthreads();   // the table (workgroup-wide, once); everything below is private to the wavefront
-  }
+  if constexpr (!HW4) lut16_stage(lut, tab, a.shift);
+  if constexpr (!HW4 || SMOOTH) __syncthreads();   // the table / the smoothing vector (workgroup-wide, once); everything below is private to the wavefront
   const HadOperand ha = had_operand(lane);
+  // column chunk of vector (tile, i, lane) = (tile * 256 + i * 64 + lane) mod vpr: the tile's part once per pass in the
+  // scalar unit's width, the rest in 32 bits
+  auto smooth_chunk = [&](uint32_t base_mod, int off) {
+    const uint32_t c = (base_mod + (uint32_t)off) % vpr32;
+    u32x4 s0, s1;
+    if (smooth_in_lds) {
+      s0 = *(const u32x4*)(smooth_s + c * 8);
+      s1 = *(const u32x4*)(smooth_s + c * 8 + 4);
+    } else {
+      s0 = *(const u32x4*)(r.smooth + (size_t)c * 8);
+      s1 = *(const u32x4*)(r.smooth + (size_t)c * 8 + 4);
+    }
+    struct { u32x4 a, b; } out = {s0, s1};
+    return out;
+  };
 
   // The body as a lambda, run once in front of the loop: the compiler merges its s_waitcnt bookkeeping over the edges
   // into the loop header, and the entry edge (prologue loads, nothing after them) would make the wait for the
@@ -426,16 +452,17 @@ __global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES)
     // 1. + 2.: (smooth,) sign, into the operand image (lane-constant addresses are rebuilt per phase from an opaque
     // lane index: two or three instructions, instead of registers held across the whole tile at 6 wavefronts per SIMD)
     const RqLaneAddr la1 = rq_lane_addr(rq_opaque(lane));
+    const uint32_t base_mod = SMOOTH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)base_vec % (uint64_t)vpr32)) : 0u;
     if constexpr (sizeof(Tin) == 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         u32x4 w = raw.w[i];
-        if (SMOOTH) {   // h = half(float(x) * s)
-          const int64_t v = base_vec + i * 64 + lane;
-          const float* sp = r.smooth + ((v < n_vec ? v : 0) % r.vec_per_row) * 8;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            w[k] = f2h(h2f(w[k] & 0xFFFFu) * sp[2 * k]) | (f2h(h2f(w[k] >> 16) * sp[2 * k + 1]) << 16);
+        if (SMOOTH) {   // h = half(float(x) * s): the widening rides on the multiply (x * s - 0 == x * s, signed zeros included)
+          const auto sv = smooth_chunk(base_mod, i * 64 + lane);
+          w[0] = f2h2(fmaf_h_lo(w[0], u2f(sv.a[0]), -0.0f), fmaf_h_hi(w[0], u2f(sv.a[1]), -0.0f));
+          w[1] = f2h2(fmaf_h_lo(w[1], u2f(sv.a[2]), -0.0f), fmaf_h_hi(w[1], u2f(sv.a[3]), -0.0f));
+          w[2] = f2h2(fmaf_h_lo(w[2], u2f(sv.b[0]), -0.0f), fmaf_h_hi(w[2], u2f(sv.b[1]), -0.0f));
+          w[3] = f2h2(fmaf_h_lo(w[3], u2f(sv.b[2]), -0.0f), fmaf_h_hi(w[3], u2f(sv.b[3]), -0.0f));
         }
         *(u32x4*)(img + la1.in_w + i * (4 * kRqInStride)) = u32x4{w[0] ^ sx[0], w[1] ^ sx[1], w[2] ^ sx[2], w[3] ^ sx[3]};
       }
@@ -448,10 +475,10 @@ __global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES)
       for (int n = 0; n < 8; ++n) {
         float f[4] = {u2f(raw.w[n][0]), u2f(raw.w[n][1]), u2f(raw.w[n][2]), u2f(raw.w[n][3])};
         if (SMOOTH) {
-          const int64_t v = base_vec + 32 * n + k2;
-          const float* sp = r.smooth + ((v < n_vec ? v : 0) % r.vec_per_row) * 8 + 4 * hsel;
+          const auto sv = smooth_chunk(base_mod, 32 * n + k2);
+          const u32x4 sp = hsel ? sv.b : sv.a;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) f[k] *= sp[k];
+          for (int k = 0; k < 4; ++k) f[k] *= u2f(sp[k]);
         }
         // half h = lane & 1 of chunk 32 n + lane / 2 = chunk (lane / 2) % 16 of group 2 n + lane / 32
         *(u32x2*)(img + la1.in_w8 + n * (2 * kRqInStride)) =

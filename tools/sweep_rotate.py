@@ -9,13 +9,16 @@ from fpqvar_amd import rotation as rot
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 xs = [torch.randn(65536, 1920, device=dev, generator=g).half() for _ in range(4)]
+sm = (torch.rand(1920, device=dev, generator=g) + 0.5) if os.environ.get("SWEEP_SMOOTH") else None
+if os.environ.get("SWEEP_X32"):
+    xs = [x[:32768].float() for x in xs]
 k = 0
 def run():
     global k
     k += 1
     if os.environ.get("SWEEP_CODES"):   # the operand-emitting form: packed E2M1 codes + fp16 group scales (2.53 B per element)
-        return rot.rotate_quant_mx(xs[k % 4])
-    return rot.rotate_quant(xs[k % 4], "e2m1")
+        return rot.rotate_quant_mx(xs[k % 4], smooth=sm)
+    return rot.rotate_quant(xs[k % 4], "e2m1", smooth=sm)
 for _ in range(200):
     run()
 torch.cuda.synchronize()
