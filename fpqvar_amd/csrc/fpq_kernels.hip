@@ -1450,8 +1450,14 @@ int fpq_quant_rows(const void* x, void* out, int64_t rows, int64_t cols, int tab
     return FPQ_ERR_DTYPE;
   if (rows == 0 || cols == 0) return FPQ_OK;
   if (!x || !out) return FPQ_ERR_ARG;
-  if (fast16_eligible(x, out, cols, in_dtype, out_dtype))
-    return launch_fast16<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
+  if (fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
+    // tables of >= 1024 buckets (E2M3, int: 2 KiB to stage per workgroup, a quarter of an 8 KiB tile's own bytes): at most
+    // 16384 workgroups, so that at the large shapes every workgroup stages once for two tiles or more - E2M3 g = 128 and
+    // KV rows of 64 at [65536 x 1920]: 84.2 -> 80.8 us (caps 10240 .. 24576: 82.3 .. 80.6; U = 4 and U = 1 are slower,
+    // profiles/r03_e2m3_grid.txt)
+    const int cap = (1 << (16 - lut16_host(table_id, table_id).args.shift)) >= 1024 ? 16384 : 1 << 20;
+    return launch_fast16<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream, cap);
+  }
   if (fast16_block_eligible(x, out, cols, in_dtype, out_dtype))
     return launch_fast16_block<false>(x, out, rows, cols, table_id, table_id, (hipStream_t)stream);
   if (fast32_eligible(x, out, cols, in_dtype, table_id)) {
