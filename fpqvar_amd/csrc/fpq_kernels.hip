@@ -1215,7 +1215,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   const int64_t target_wgs = h.tab_valid ? (1 << 20) : 2048;
   int64_t rpb = (rows + target_wgs - 1) / target_wgs;
   if (rpb < 1) rpb = 1;
-  if (h.tab_valid && (1 << (16 - h.args.shift)) > 1024) {   // 2 x 1024 buckets to stage: a few rows per workgroup
+  if (h.tab_valid && (1 << (16 - h.args.shift)) >= 1024) {   // 2 x 512 (E2M3: [16384 x 7680] 86.3 -> 83.4 us) or 2 x 1024 buckets to stage: two rows per workgroup
     const char* e = FPQ_ENV("FPQ_BIGTAB_RPB");
     rpb = e ? atoll(e) : 2;
     if (rpb < 1) rpb = 1;

@@ -1,5 +1,6 @@
+"""Experiment driver for diagnostic builds: per-token E2M3 quantizers under grid variations read from the environment."""
 import ctypes, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fpqvar_amd import _lib, ops
 l = ctypes.CDLL(os.path.abspath(sys.argv[1]))
@@ -9,20 +10,25 @@ for name, (res, args) in _lib._SIGS.items():
 _lib._lib = l
 dev = torch.device("cuda:0")
 xs = [torch.randn(65536, 1920, device=dev).half() for _ in range(4)]
+hs = [torch.randn(16384, 7680, device=dev).half() for _ in range(4)]
 k = [0]
-def run(table, cols):
-    k[0] += 1
-    return ops.quant_rows(xs[k[0] % 4], table, cols, torch.float16)
-def t(table, cols):
+def t(fn):
     best = 1e9
     for _ in range(3):
-        for _ in range(10): run(table, cols)
+        for _ in range(10): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(100): run(table, cols)
+        for _ in range(100): fn()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 100 * 1e3)
     return best
-for cfg in (None, "2,10240", "2,12288", "2,15360", "2,16384", "2,20480", "2,24576"):
-    if cfg: os.environ["FPQ_SYM_BIGTAB"] = cfg
-    print(cfg, "e2m3 g128: %.1f us   e2m3 kv64: %.1f us   e2m1 g128 (unaffected): %.1f" % (t("e2m3", 128), t("e2m3", 64), t("e2m1", 128)), flush=True)
+def nxt(l):
+    k[0] += 1
+    return l[k[0] % 4]
+for cap in (None, "4096", "8192", "12288", "16384"):
+    if cap: os.environ["FPQ_WAVE_CAP"] = cap
+    print("wave cap", cap, "per token e2m3 [65536x1920]: %.1f us   dual int-/e2m3+ per token: n/a" % t(lambda: ops.quant_rows(nxt(xs), "e2m3", 1920, torch.float16)), flush=True)
+for rpb in (None, "1", "2", "3", "4"):
+    if rpb: os.environ["FPQ_BLOCK_RPB"] = rpb
+    print("block rows per workgroup", rpb, "per token e2m3 [16384x7680]: %.1f us   dual int-/e2m3+ per token: %.1f us" % (
+        t(lambda: ops.quant_rows(nxt(hs), "e2m3", 7680, torch.float16)), t(lambda: ops.quant_rows_dual(nxt(hs), "int_neg", "e2m3_pos", 7680, None))), flush=True)
