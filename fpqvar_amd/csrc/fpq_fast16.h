@@ -41,6 +41,8 @@ struct Lut16Args {
   float inv_gpos;
   int shift;           // bucket width = 2^shift fp16 patterns
   uint32_t* nan_flag;  // dual format only: nullptr, or device word OR-ed with 1 when an input is NaN
+  const void* clip_absmax;   // dual format per group only (CLIP kernels): device scalar max|x| in x's dtype, or nullptr
+  float clip_strength;       // the reference's global clamp to +-strength * max|x| (tr/quant_utils.py:421-422)
 };
 
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
@@ -291,6 +293,25 @@ __device__ __forceinline__ uint32_t vec_absmax16(const u32x4& w) {
   return lo > hi ? lo : hi;
 }
 
+__device__ __forceinline__ uint32_t pk_min_f16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_max_f16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// torch.clamp(x, -c, c) on a packed pair; c2 = the bound in both halves (c >= 0, not NaN).  v_pk_min / max return the
+// other operand for a NaN input, torch keeps the NaN: `keep_nan` restores it (only on the rare path that saw a NaN).
+__device__ __forceinline__ uint32_t pk_clamp_f16(uint32_t w, uint32_t c2, bool keep_nan) {
+  const uint32_t r = pk_min_f16(pk_max_f16(w, c2 ^ 0x80008000u), c2);
+  if (!keep_nan) return r;
+  const uint32_t nanm = pk_ashr_i16(pk_sub_u16(0x7C007C00u, w & 0x7FFF7FFFu), 15);   // 0xFFFF where the half is a NaN
+  return (r & ~nanm) | (w & nanm);
+}
+
 // dual format: max|x| over x <= 0 and over x > 0 separately; NaN belongs to neither
 __device__ __forceinline__ uint32_t vec_absmax16_dual(const u32x4& w, uint32_t& mneg, uint32_t& mpos) {
   uint32_t mn = 0, mp = 0, any_nan = 0;
@@ -450,7 +471,11 @@ inline void lut16_build_host(uint16_t* lut, const Lut16Args& a) {
 // to back.  All U loads are issued before the table is staged and the barrier.
 // ---------------------------------------------------------------------------------
 // HW4: E2M1 levels from the conversion hardware (above) - no table, no LDS, no barrier.
-template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true, bool HW4 = false>
+// CLIP (dual format per group): the reference's global clamp to +-strength * max|x| in front of the quantizer, the
+// maximum read from a device scalar (fpq_absmax) - two packed instructions per pair on the fast path instead of the
+// generic kernel (0.23 -> of 8 TB/s, profiles/r03_survey_shapes.txt).  Group maxima are taken on the raw words (a NaN
+// is still seen) and clamped afterwards (clamping is monotonic).
+template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true, bool HW4 = false, bool CLIP = false>
 __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4* __restrict__ x,
                                                                    u32x4* __restrict__ out, int64_t n_vec,
                                                                    Lut16Args a, Lut16Tab tab) {
@@ -459,7 +484,15 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
     __shared__ __attribute__((aligned(16))) uint16_t lut_s[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
     lut = lut_s;
   }
+  static_assert(!CLIP || DUAL, "the global clamp belongs to the dual format");
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  uint32_t clip2 = 0;
+  bool clip_nan = false;
+  if constexpr (CLIP) {   // c = half(strength * max|x|), as the reference's fp16 multiply
+    const uint32_t cb = f2h(a.clip_strength * h2f(*(const uint16_t*)a.clip_absmax));
+    clip_nan = (cb & 0x7FFFu) > 0x7C00u;   // a NaN in the tensor: clamp(x, NaN, NaN) is NaN everywhere -> every output +0
+    clip2 = cb | (cb << 16);
+  }
   bool first = true;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t v0 = tile * ((int64_t)kBlock * U) + threadIdx.x;
@@ -489,14 +522,24 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
         dual_max_finish(un, sg, mn, mp);
         mn = row_max_dpp<LPR>(mn);
         mp = row_max_dpp<LPR>(mp);
-        if (__builtin_expect(dual_max_has_nan(mn, mp), 0)) {   // a NaN somewhere in the wavefront's vectors: the exact rule
-          if (vec_absmax16_dual(raw[u], mn, mp) && a.nan_flag) atomicOr(a.nan_flag, 1u);
+        u32x4 xw = raw[u];
+        const bool has_nan = dual_max_has_nan(mn, mp);
+        if constexpr (CLIP) {
+          const uint32_t cb = clip2 & 0xFFFFu;
+          mn = mn < cb ? mn : cb;
+          mp = mp < cb ? mp : cb;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xw[k] = pk_clamp_f16(xw[k], clip2, has_nan);
+        }
+        if (__builtin_expect(has_nan, 0)) {   // a NaN somewhere in the wavefront's vectors: the exact rule
+          if (vec_absmax16_dual(xw, mn, mp) && a.nan_flag) atomicOr(a.nan_flag, 1u);
           mn = row_max_dpp<LPR>(mn);
           mp = row_max_dpp<LPR>(mp);
         }
         RowScale16 sn = row_scale16(mn, a.fneg.gmax, a.inv_gneg), sp = row_scale16(mp, a.fpos.gmax, a.inv_gpos);
         dual_poison(sn, sp);
-        o = quant_vec16<true>(raw[u], lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
+        o = quant_vec16<true>(xw, lut, a.shift, sn.inv, sn.inv_lo, sn.s16x2, sp.inv, sp.inv_lo, sp.s16x2);
+        if (CLIP && clip_nan) o = u32x4{0, 0, 0, 0};
       } else {
         uint32_t m = row_max_dpp<LPR>(vec_absmax16(raw[u]));
         RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);

@@ -880,6 +880,8 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
         h.args.inv_gpos = 1.0f / h.args.fpos.gmax;
         h.args.shift = table_shift16(n) < table_shift16(p) ? table_shift16(n) : table_shift16(p);
         h.args.nan_flag = nullptr;
+        h.args.clip_absmax = nullptr;
+        h.args.clip_strength = 1.0f;
         for (int i = 0; i < kLutLdsEntries; ++i) h.full[i] = 0;
         lut16_build_host(h.full, h.args);
         h.tab_valid = lut16_compress(h.full, h.args.shift, &h.tab);
@@ -900,10 +902,13 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
 #endif
 template <bool DUAL, int U = FPQ_FAST16_U, bool NTL = true, bool NTS = true>
 int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id, hipStream_t st,
-                  int grid_cap = 1 << 20, uint32_t* nan_flag = nullptr) {
+                  int grid_cap = 1 << 20, uint32_t* nan_flag = nullptr, const void* clip_absmax = nullptr,
+                  float clip_strength = 1.0f) {
   const Lut16Host& h = lut16_host(neg_id, pos_id);
   Lut16Args args = h.args;
   args.nan_flag = nan_flag;
+  args.clip_absmax = clip_absmax;
+  args.clip_strength = clip_strength;
   const int64_t n_vec = rows * (cols / 8);
   const int lpr = (int)(cols / 8);
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
@@ -919,6 +924,12 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   };
   // the headline shape - E2M1, groups of 128 - takes its levels from the FP4 conversion hardware (fpq_fast16.h); FPQ_NO_HW4
   // (read at every call: the exhaustive test sweeps both forms in one process) keeps the bucket table
+  if constexpr (DUAL) {
+    if (clip_absmax) {   // groups of 128 only (fpq_quant_rows_dual checks): the clamping form of the same kernel
+      if (lpr != 16) return FPQ_ERR_SHAPE;
+      return go(rows16_lut_subwave_kernel<16, true, U, true, NTL, NTS, false, true>, rows16_lut_subwave_kernel<16, true, U, false, NTL, NTS, false, true>);
+    }
+  }
   if constexpr (!DUAL) {
     if (lpr == 16 && neg_id == FPQ_E2M1 && pos_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4")) {
       // no table to stage, so nothing to amortise over a tile: ONE vector per lane on the full grid, the best plain-copy
@@ -1610,7 +1621,11 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   uint32_t* flag = (uint32_t*)nan_flag;
   if (flag && (((uintptr_t)flag) & 7) != 0) return FPQ_ERR_ARG;
   int rc;
-  if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
+  const bool bigtab = (1 << (16 - lut16_host(neg_table, pos_table).args.shift)) > 1024;
+  if (clip_absmax && clip_strength >= 0.0f && cols == 128 && !bigtab && fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
+    // the global clamp on the fast path (fp16 groups of 128, strength >= 0; anything else below, through the generic kernel)
+    rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag, clip_absmax, clip_strength);
+  } else if (!clip_absmax && fast16_eligible(x, out, cols, in_dtype, out_dtype)) {
     // int_neg/e2m3_pos needs a 2048-entry table (too big for the kernel arguments): every workgroup
     // evaluates it once, so give each workgroup many tiles (measured: 88 us vs 127 us with a full grid)
     // tables of 2 x 1024 buckets (int_neg / e2m3_pos) cost a workgroup 8 stores per lane to stage: give each

@@ -187,6 +187,53 @@ def test_dual_nan_clip_quirk(dev, qu, golden):
     assert bool(out.any()) and not torch.isnan(out).any()
 
 
+@pytest.mark.parametrize("tables", (("e1m2_neg", "e2m1_pos"), ("e2m1_neg", "e2m1_pos")))
+def test_dual_clip_fast_path(dev, tables):
+    """The reference's global clamp to +-strength * max|x| (tr/quant_utils.py:421-422) on the fp16 group-of-128 fast
+    path (two packed instructions per pair in front of the dual quantizer): strengths below and above 1, zero, tensors
+    with an Inf (bound = inf: no clamp, the row poisons), with a NaN (bound = NaN: every output +0), with -0, ragged
+    tile ends - against the oracle; and, through the C ABI with a supplied maximum, NaN ELEMENTS beside a finite bound
+    (torch.clamp keeps them, the hardware min / max would not)."""
+    from fpqvar_amd import _lib, ops
+    from fpqvar_amd.ops import TABLE_IDS, dtype_id, stream_ptr
+    neg, pos = tables
+    g = torch.Generator().manual_seed(77)
+    for rows, kind in ((1000, "gelu"), (4099, "gauss"), (3, "gauss")):
+        x = torch.randn(rows, 128 * 5, generator=g) * 1.7
+        if kind == "gelu":
+            x = torch.nn.functional.gelu(x, approximate="tanh")
+        x = x.half()
+        x[0, 5] = -0.0
+        x[1, :128] = x[1, :128].abs() + 0.1
+        x[2, :128] = 0
+        for strength in (0.5, 0.9, 1.5, 0.0, 0.999):
+            got = ops.quant_rows_dual(x.to(dev), neg, pos, 128, clipping_strength=strength)
+            assert_bits_equal(got, orc.dual_per_group_kernel_sem(x, neg, pos, 128, strength), f"{kind} rows={rows} strength={strength}")
+        xi = x.clone()
+        xi[rows // 2, 130] = float("inf")
+        assert_bits_equal(ops.quant_rows_dual(xi.to(dev), neg, pos, 128, clipping_strength=0.7),
+                          orc.dual_per_group_kernel_sem(xi, neg, pos, 128, 0.7), f"{kind} with inf")
+        xn = x.clone()
+        xn[rows - 1, 7] = float("nan")
+        out = ops.quant_rows_dual(xn.to(dev), neg, pos, 128, clipping_strength=0.7)
+        assert_bits_equal(out, orc.dual_per_group_kernel_sem(xn, neg, pos, 128, 0.7), f"{kind} with nan")
+        assert not out.any()
+    # a supplied maximum: bound 0.9 * 2.0 beside NaN elements and values beyond the bound
+    x = (torch.randn(300, 256, generator=g) * 2.5).half()
+    x[5, 9] = float("nan")
+    x[5, 200] = float("nan")
+    x[299, 255] = float("nan")
+    am = torch.tensor([2.0, 0.0], dtype=torch.float16, device=dev)
+    xd = x.to(dev)
+    out = torch.empty_like(xd)
+    rc = _lib.lib().fpq_quant_rows_dual(xd.data_ptr(), out.data_ptr(), x.numel() // 128, 128, TABLE_IDS[neg], TABLE_IDS[pos],
+                                        dtype_id(x.dtype), dtype_id(x.dtype), am.data_ptr(), 0.9, None, stream_ptr(dev))
+    assert rc == 0
+    c = torch.tensor(0.9, dtype=torch.float32) * torch.tensor(2.0)
+    want = orc._dual_rows_kernel_sem(torch.clamp(x, -c.half(), c.half()).reshape(-1, 128), neg, pos).view(x.shape).to(x.dtype)
+    assert_bits_equal(out, want, "supplied maximum with NaN elements")
+
+
 # ------------------------------------------------------------------ oracle on seeded inputs
 def _inputs(kind, shape, dtype, seed):
     g = torch.Generator().manual_seed(seed)
