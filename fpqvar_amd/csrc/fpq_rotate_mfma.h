@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES)
   // SMOOTH: the vector (<= kRqSmoothMax channels: every VAR width) is staged in LDS once per workgroup; a tile's chunk of
   // it is two ds_read_b128 at (column chunk) * 32 bytes.  Round 2 read it from global memory behind a 64-bit modulo per
   // vector, inside the tile's dependency chain: 280 us per [65536 x 1920] against 80 without a vector
-  // (profiles/r03_pmc_rotate_smooth.txt, first measurement of this instantiation).  Wider rows keep global loads.
+  // (profiles/r03_pmc_rotate_smooth_before.txt, the first measurement of this instantiation).  Wider rows keep global loads.
   constexpr int kSmoothLds = SMOOTH ? kRqSmoothMax : 4;
   __shared__ __attribute__((aligned(16))) float smooth_s[kSmoothLds];
   const uint32_t vpr32 = (uint32_t)r.vec_per_row;
