@@ -110,6 +110,10 @@ _SIGS = {
                                          _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_dequant_rows_codes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                            _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    "fpq_quant_rows_codes_segments": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                                  _c.c_void_p]),
+    "fpq_dequant_rows_codes_segments": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                                    _c.c_int, _c.c_void_p]),
 }
 
 

@@ -290,44 +290,74 @@ def calibrate_sharded(weights: Mapping[str, torch.Tensor],
 
 
 def _calibrate_codes(weights, rank, world, group, gather):
-    from . import ops
+    """The packed exchange: nibble codes + one fp32 scale per group of 128 (0.53 B per element on the wire).  ONE launch
+    quantizes this rank's layers straight into its slot of the slab (fpq_quant_rows_codes_segments: no per-layer
+    launches, no copies), one all-gather, ONE launch decodes every layer of every rank into an fp16 slab
+    (fpq_dequant_rows_codes_segments) whose views are the result - bit-equal to the fp16 exchange."""
+    from . import _lib
     names = list(weights.keys())
     numel = {n: int(weights[n].numel()) for n in names}
     plan = partition([(n, numel[n]) for n in names], world)
     mine = plan[rank]
     ref = next(iter(weights.values()))
-    table = "e2m1"
+    dev = ref.device
+    table_id = _lib.TABLE_IDS["e2m1"]
     for n in names:
         if numel[n] % _GROUP != 0:
             raise RuntimeError(f"calibrate_sharded(exchange='codes'): {n} is not a multiple of {_GROUP} elements")
-    code_bytes = {n: numel[n] // 2 for n in names}
+    code_bytes = {n: numel[n] // 2 for n in names}                     # multiples of 64: every layer's codes stay 16-byte aligned
     n_scales = {n: numel[n] // _GROUP for n in names}
-    local_codes, local_scales = OrderedDict(), OrderedDict()
-    for n in mine:
-        c, s = ops.quant_rows_codes(weights[n].float(), table, _GROUP, pack_nibbles=True)
-        local_codes[n], local_scales[n] = c.reshape(-1), s.reshape(-1)
-    if not gather or world == 1:
-        return {n: ops.dequant_rows_codes(local_codes[n].view(-1, 64), local_scales[n], table, _GROUP,
-                                          torch.float16, True).view(weights[n].shape) for n in mine}
+    ranks = range(world) if gather and world > 1 else (rank,)
     wc = max(sum(code_bytes[n] for n in plan[r]) for r in range(world))
     wc = (wc + 15) // 16 * 16
     ws = max(sum(n_scales[n] for n in plan[r]) for r in range(world))
-    slab = torch.empty((world, wc + 4 * ws), dtype=torch.uint8, device=ref.device)
-    off, soff = 0, wc
-    for n in mine:
-        slab[rank, off:off + code_bytes[n]] = local_codes[n]
-        off += code_bytes[n]
-        b = local_scales[n].contiguous().view(torch.uint8)
-        slab[rank, soff:soff + b.numel()] = b
-        soff += b.numel()
-    gather_slab(slab, rank, group)
-    out = {}
-    for r in range(world):
-        off, soff = 0, wc
+    slab = torch.empty((world, wc + 4 * ws), dtype=torch.uint8, device=dev)
+    if slab.data_ptr() % 16 != 0 or (wc + 4 * ws) % 16 != 0:
+        raise RuntimeError("calibrate_sharded(exchange='codes'): slab rows are not 16-byte aligned")
+
+    def layout(r):                                                     # (layer, codes offset, scales offset) inside slab[r]
+        off, soff, rows = 0, wc, []
         for n in plan[r]:
-            codes = slab[r, off:off + code_bytes[n]].view(-1, 64)
-            scales = slab[r, soff:soff + 4 * n_scales[n]].view(torch.float32)
-            out[n] = ops.dequant_rows_codes(codes, scales, table, _GROUP, torch.float16, True).view(weights[n].shape)
+            rows.append((n, off, soff))
             off += code_bytes[n]
             soff += 4 * n_scales[n]
-    return {n: out[n] for n in names}
+        return rows
+    lib = _lib.lib()
+    keep = []                                                          # contiguous fp32 inputs stay alive until the launch is enqueued
+    q_desc = []
+    base = slab.data_ptr() + rank * slab.stride(0)
+    for n, off, soff in layout(rank):
+        w = weights[n]
+        _lib.require_gpu(w, f"calibrate_sharded({n})")
+        w = w.float() if w.dtype != torch.float32 else w
+        w = w if w.is_contiguous() else w.contiguous()
+        if w.data_ptr() % 16 != 0:
+            w = w.clone()
+        keep.append(w)
+        q_desc.append([w.data_ptr(), base + off, base + soff, n_scales[n]])
+    with _lib.device_guard(dev):
+        if q_desc:
+            q_tab = torch.tensor(q_desc, dtype=torch.int64).to(dev)
+            _lib.check(lib.fpq_quant_rows_codes_segments(q_tab.data_ptr(), len(q_desc), max(d[3] for d in q_desc), _GROUP,
+                                                         table_id, _lib.F32, 1, _lib.stream_ptr(dev)),
+                       "fpq_quant_rows_codes_segments")
+        if gather and world > 1:
+            gather_slab(slab, rank, group)
+        out_names = [n for r in ranks for n in plan[r]]
+        offsets, total = {}, 0
+        for n in out_names:
+            offsets[n] = total
+            total += numel[n]
+        out = torch.empty(total, dtype=torch.float16, device=dev)
+        d_desc = []
+        for r in ranks:
+            rb = slab.data_ptr() + r * slab.stride(0)
+            for n, off, soff in layout(r):
+                d_desc.append([rb + off, rb + soff, out.data_ptr() + 2 * offsets[n], n_scales[n]])
+        if d_desc:
+            d_tab = torch.tensor(d_desc, dtype=torch.int64).to(dev)
+            _lib.check(lib.fpq_dequant_rows_codes_segments(d_tab.data_ptr(), len(d_desc), max(d[3] for d in d_desc), _GROUP,
+                                                           table_id, _lib.F32, _lib.F16, 1, _lib.stream_ptr(dev)),
+                       "fpq_dequant_rows_codes_segments")
+    res = {n: out[offsets[n]:offsets[n] + numel[n]].view(weights[n].shape) for n in out_names}
+    return {n: res[n] for n in names if n in res} if gather and world > 1 else {n: res[n] for n in mine}

@@ -677,8 +677,8 @@ __global__ __launch_bounds__(kBlock) void rows_codes_kernel(const Tin* __restric
 // Vectorised codes for rows of exactly 128 elements (per-group): LPR lanes own a row, 16-byte
 // loads, one packed store per lane (FP4: V nibbles, FP6: V bytes), lane 0 of the row writes the scale.
 template <typename Tin, bool PACK, bool HW = false>
-__global__ __launch_bounds__(kBlock) void codes128_kernel(const u32x4* __restrict__ x, uint8_t* __restrict__ codes,
-                                                         Tin* __restrict__ scales, int64_t n_vec, Fmt fs) {
+__device__ __forceinline__ void codes128_body(const u32x4* __restrict__ x, uint8_t* __restrict__ codes,
+                                              Tin* __restrict__ scales, int64_t n_vec, const Fmt& fs) {
   constexpr int V = DT<Tin>::kVec;
   constexpr int LPR = 128 / V;
   for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * kBlock) {
@@ -719,11 +719,29 @@ __global__ __launch_bounds__(kBlock) void codes128_kernel(const u32x4* __restric
     }
   }
 }
+template <typename Tin, bool PACK, bool HW = false>
+__global__ __launch_bounds__(kBlock) void codes128_kernel(const u32x4* __restrict__ x, uint8_t* __restrict__ codes,
+                                                         Tin* __restrict__ scales, int64_t n_vec, Fmt fs) {
+  codes128_body<Tin, PACK, HW>(x, codes, scales, n_vec, fs);
+}
+// Many tensors, one launch (fpq_quant_rows_codes_segments): blockIdx.y = segment of a device-resident table, the
+// workgroups of the x dimension stride over that segment's vectors (a short segment's surplus workgroups fall through)
+struct CodesSeg {
+  const void* x;
+  uint8_t* codes;
+  void* scales;
+  int64_t rows;
+};
+template <typename Tin, bool PACK>
+__global__ __launch_bounds__(kBlock) void codes128_segments_kernel(const CodesSeg* __restrict__ segs, Fmt fs) {
+  const CodesSeg sg = segs[blockIdx.y];
+  codes128_body<Tin, PACK, false>((const u32x4*)sg.x, sg.codes, (Tin*)sg.scales, sg.rows * (128 / DT<Tin>::kVec), fs);
+}
 
 // inverse for rows of 128: every lane decodes 8 consecutive elements
 template <typename Ts, typename Tout, bool PACK>
-__global__ __launch_bounds__(kBlock) void decode128_kernel(const uint8_t* __restrict__ codes, const Ts* __restrict__ scales,
-                                                          Tout* __restrict__ out, int64_t n_oct, Fmt fs) {
+__device__ __forceinline__ void decode128_body(const uint8_t* __restrict__ codes, const Ts* __restrict__ scales,
+                                               Tout* __restrict__ out, int64_t n_oct, const Fmt& fs) {
   const int nsub = (int)(fs.kmin * fs.inv_step0);
   for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_oct; v += (int64_t)gridDim.x * kBlock) {
     uint32_t c[8];
@@ -755,6 +773,22 @@ __global__ __launch_bounds__(kBlock) void decode128_kernel(const uint8_t* __rest
       __builtin_nontemporal_store(u32x4{fbits(p[4]), fbits(p[5]), fbits(p[6]), fbits(p[7])}, (u32x4*)out + 2 * v + 1);
     }
   }
+}
+template <typename Ts, typename Tout, bool PACK>
+__global__ __launch_bounds__(kBlock) void decode128_kernel(const uint8_t* __restrict__ codes, const Ts* __restrict__ scales,
+                                                          Tout* __restrict__ out, int64_t n_oct, Fmt fs) {
+  decode128_body<Ts, Tout, PACK>(codes, scales, out, n_oct, fs);
+}
+struct DecodeSeg {
+  const uint8_t* codes;
+  const void* scales;
+  void* out;
+  int64_t rows;
+};
+template <typename Ts, typename Tout, bool PACK>
+__global__ __launch_bounds__(kBlock) void decode128_segments_kernel(const DecodeSeg* __restrict__ segs, Fmt fs) {
+  const DecodeSeg sg = segs[blockIdx.y];
+  decode128_body<Ts, Tout, PACK>(sg.codes, (const Ts*)sg.scales, (Tout*)sg.out, sg.rows * 16, fs);
 }
 
 template <typename Ts, typename Tout>
@@ -2046,6 +2080,55 @@ int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, 
   else
     hipLaunchKernelGGL((rows_decode_kernel<float, float>), dim3(g), dim3(kBlock), 0, st, codes,
                        (const float*)scales, (float*)out, rows, cols, f, pk);
+  return check_launch();
+}
+
+int fpq_quant_rows_codes_segments(const fpq_codes_segment_t* segments_device, int n_segments, int64_t max_rows,
+                                  int64_t cols, int table_id, int in_dtype, int pack_nibbles, fpq_stream_t stream) {
+  static_assert(sizeof(fpq_codes_segment_t) == sizeof(CodesSeg), "fpq_codes_segment_t and the kernels' CodesSeg share one layout");
+  if (n_segments < 0 || max_rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (cols != 128 || n_segments > 65535) return FPQ_ERR_SHAPE;
+  if (pack_nibbles && kTables[table_id].n_pos > 8) return FPQ_ERR_SHAPE;
+  if (n_segments == 0 || max_rows == 0) return FPQ_OK;
+  if (!segments_device || (((uintptr_t)segments_device) & 7) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const Fmt f = make_fmt(table_id);
+  const int64_t n_vec = max_rows * (in_dtype == FPQ_F16 ? 16 : 32);
+  // a few vectors per thread in the largest segment: the grid's y dimension multiplies it by the segment count
+  const dim3 grid((unsigned)grid_for((n_vec + 4 * kBlock - 1) / (4 * kBlock), 1 << 16), (unsigned)n_segments);
+  const CodesSeg* sg = (const CodesSeg*)segments_device;
+  if (in_dtype == FPQ_F16 && pack_nibbles) hipLaunchKernelGGL((codes128_segments_kernel<_Float16, true>), grid, dim3(kBlock), 0, st, sg, f);
+  else if (in_dtype == FPQ_F16) hipLaunchKernelGGL((codes128_segments_kernel<_Float16, false>), grid, dim3(kBlock), 0, st, sg, f);
+  else if (pack_nibbles) hipLaunchKernelGGL((codes128_segments_kernel<float, true>), grid, dim3(kBlock), 0, st, sg, f);
+  else hipLaunchKernelGGL((codes128_segments_kernel<float, false>), grid, dim3(kBlock), 0, st, sg, f);
+  return check_launch();
+}
+
+int fpq_dequant_rows_codes_segments(const fpq_decode_segment_t* segments_device, int n_segments, int64_t max_rows,
+                                    int64_t cols, int table_id, int scale_dtype, int out_dtype, int pack_nibbles,
+                                    fpq_stream_t stream) {
+  static_assert(sizeof(fpq_decode_segment_t) == sizeof(DecodeSeg), "fpq_decode_segment_t and the kernels' DecodeSeg share one layout");
+  if (n_segments < 0 || max_rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
+  if ((scale_dtype != FPQ_F16 && scale_dtype != FPQ_F32) || (out_dtype != FPQ_F16 && out_dtype != FPQ_F32))
+    return FPQ_ERR_DTYPE;
+  if (cols != 128 || n_segments > 65535) return FPQ_ERR_SHAPE;
+  if (pack_nibbles && kTables[table_id].n_pos > 8) return FPQ_ERR_SHAPE;
+  if (n_segments == 0 || max_rows == 0) return FPQ_OK;
+  if (!segments_device || (((uintptr_t)segments_device) & 7) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const Fmt f = make_fmt(table_id);
+  const int64_t n_oct = max_rows * 16;
+  const dim3 grid((unsigned)grid_for((n_oct + 4 * kBlock - 1) / (4 * kBlock), 1 << 16), (unsigned)n_segments);
+  const DecodeSeg* sg = (const DecodeSeg*)segments_device;
+#define FPQ_DECS(TS, TO, PK) hipLaunchKernelGGL((decode128_segments_kernel<TS, TO, PK>), grid, dim3(kBlock), 0, st, sg, f)
+  if (scale_dtype == FPQ_F16 && out_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DECS(_Float16, _Float16, true); else FPQ_DECS(_Float16, _Float16, false); }
+  else if (scale_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DECS(_Float16, float, true); else FPQ_DECS(_Float16, float, false); }
+  else if (out_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DECS(float, _Float16, true); else FPQ_DECS(float, _Float16, false); }
+  else { if (pack_nibbles) FPQ_DECS(float, float, true); else FPQ_DECS(float, float, false); }
+#undef FPQ_DECS
   return check_launch();
 }
 

@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 121 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2) */
+#define FPQ_VERSION 122 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
+                           0.1.3: + fpq_quant_rows_codes_segments, fpq_dequant_rows_codes_segments (round 3) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -390,6 +391,33 @@ int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_sca
 int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, int64_t rows,
                            int64_t cols, int table_id, int scale_dtype, int out_dtype,
                            int pack_nibbles, fpq_stream_t stream);
+
+/* The two above over many tensors in ONE launch each: the packed exchange format of the sharded weight calibration
+ * (every Linear a rank owns -> nibble codes + one scale per group straight into its slot of the all-gather slab; after
+ * the gather every rank decodes all layers of all ranks; reference: quantize_VAR, tr/quant_utils.py:1095-1167 over
+ * QuantizedLinear.from_float :828-837, whose result this reproduces bit for bit at 0.53 B per element on the wire).
+ * segments_device: DEVICE-resident array of n_segments descriptors, as for fpq_quant_rows_segments; every segment is
+ * `rows` groups of `cols` elements; x / codes / out 16-byte aligned, scales aligned to their dtype; max_rows = the
+ * largest segment (sizes grid.x; grid.y = segment).  This version: cols == 128, n_segments <= 65535; scales have
+ * in_dtype (quantize) / scale_dtype (decode).  Same results as the single-tensor calls per segment.  The descriptors'
+ * pointers are NOT validated (they live on the device): the caller guarantees them. */
+typedef struct {
+  const void* x;
+  uint8_t* codes;
+  void* scales;
+  int64_t rows;
+} fpq_codes_segment_t;
+int fpq_quant_rows_codes_segments(const fpq_codes_segment_t* segments_device, int n_segments, int64_t max_rows,
+                                  int64_t cols, int table_id, int in_dtype, int pack_nibbles, fpq_stream_t stream);
+typedef struct {
+  const uint8_t* codes;
+  const void* scales;
+  void* out;
+  int64_t rows;
+} fpq_decode_segment_t;
+int fpq_dequant_rows_codes_segments(const fpq_decode_segment_t* segments_device, int n_segments, int64_t max_rows,
+                                    int64_t cols, int table_id, int scale_dtype, int out_dtype, int pack_nibbles,
+                                    fpq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -286,6 +286,47 @@ def test_config4_d30_codes_exchange_full_size(dev):
     _oracle_slices("codes " + list(shapes)[-1], w[list(shapes)[-1]], got[list(shapes)[-1]])
 
 
+@pytest.mark.parametrize("in_dtype", (torch.float32, torch.float16))
+@pytest.mark.parametrize("pack", (True, False))
+def test_codes_segments_equal_single_tensor_calls(dev, in_dtype, pack):
+    """fpq_quant_rows_codes_segments / fpq_dequant_rows_codes_segments (the packed calibration exchange: many layers, one
+    launch each way) against fpq_quant_rows_codes / fpq_dequant_rows_codes per layer, on layers of very different sizes
+    (1 group ... 40000 groups, so that most workgroups of the small segments fall through), both dtypes, nibble-packed
+    and byte codes; and the decoded values against the oracle's fake quantization."""
+    from fpqvar_amd import _lib, ops
+    g = torch.Generator().manual_seed(5)
+    groups = (1, 3, 40000, 257, 16, 1024)
+    xs = [(torch.randn(r, 128, generator=g) * (0.02 + 0.3 * i)).to(in_dtype).to(dev) for i, r in enumerate(groups)]
+    xs[1][0, :] = 0
+    cb = 64 if pack else 128
+    codes = [torch.full((r, cb), 0xAB, dtype=torch.uint8, device=dev) for r in groups]
+    scales = [torch.full((r,), float("nan"), dtype=in_dtype, device=dev) for r in groups]
+    tab = torch.tensor([[x.data_ptr(), c.data_ptr(), s.data_ptr(), r] for x, c, s, r in zip(xs, codes, scales, groups)],
+                       dtype=torch.int64).to(dev)
+    lib = _lib.lib()
+    rc = lib.fpq_quant_rows_codes_segments(tab.data_ptr(), len(groups), max(groups), 128, _lib.TABLE_IDS["e2m1"],
+                                           _lib.dtype_id(in_dtype), int(pack), _lib.stream_ptr(dev))
+    assert rc == 0
+    outs = [torch.full((r, 128), float("nan"), dtype=torch.float16, device=dev) for r in groups]
+    dtab = torch.tensor([[c.data_ptr(), s.data_ptr(), o.data_ptr(), r] for c, s, o, r in zip(codes, scales, outs, groups)],
+                        dtype=torch.int64).to(dev)
+    rc = lib.fpq_dequant_rows_codes_segments(dtab.data_ptr(), len(groups), max(groups), 128, _lib.TABLE_IDS["e2m1"],
+                                             _lib.dtype_id(in_dtype), _lib.F16, int(pack), _lib.stream_ptr(dev))
+    assert rc == 0
+    for i, (x, c, s, o) in enumerate(zip(xs, codes, scales, outs)):
+        c1, s1 = ops.quant_rows_codes(x, "e2m1", 128, pack_nibbles=pack)
+        assert torch.equal(c.view(-1), c1.view(-1)), f"segment {i}: codes"
+        assert_bits_equal(s, s1.view(-1), f"segment {i}: scales")
+        o1 = ops.dequant_rows_codes(c1, s1, "e2m1", 128, torch.float16, pack)
+        assert_bits_equal(o, o1.view_as(o), f"segment {i}: decoded")
+        assert_bits_equal(o, orc.per_group_kernel_sem(x.cpu(), "e2m1", 128).half(), f"segment {i}: decoded vs oracle")
+    # argument checks: nothing is enqueued for a bad call
+    assert lib.fpq_quant_rows_codes_segments(tab.data_ptr(), len(groups), max(groups), 64, _lib.TABLE_IDS["e2m1"],
+                                             _lib.dtype_id(in_dtype), int(pack), _lib.stream_ptr(dev)) != 0
+    assert lib.fpq_dequant_rows_codes_segments(None, 1, 1, 128, _lib.TABLE_IDS["e2m1"], _lib.F32, _lib.F16, 1, _lib.stream_ptr(dev)) != 0
+    assert lib.fpq_quant_rows_codes_segments(None, 0, 0, 128, _lib.TABLE_IDS["e2m1"], _lib.F32, 1, _lib.stream_ptr(dev)) == 0
+
+
 @pytest.mark.parametrize("out_dtype", (torch.float16, torch.float32))
 @pytest.mark.parametrize("cols", (1920, 2304, 7680, 9216, 512, 1000, 2048, 2056, 5000 * 2))
 def test_fast32_long_rows_vs_oracle(dev, cols, out_dtype):

@@ -94,10 +94,47 @@ def cases():
         yield f"d{depth} weight [{3 * C} x {C}] fp32: per channel e2m3 -> fp16", lambda x: ops.quant_rows(x, "e2m3", C, torch.float16), ws, n * 6
 
 
+def other_cases():
+    """The entry points that are not producers or row quantizers of an activation, at the d30 shape."""
+    from fpqvar_amd import gemm
+    C = 1920
+    n = ROWS * C
+    x16 = inputs(ROWS, C, torch.float16)
+    x32 = inputs(ROWS, C, torch.float32)
+    tab = torch.tensor([-6.0, -4.0, -3.0, -2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], device=dev)
+    odd = torch.tensor([-5.0, -2.5, -1.0, -0.3, 0.0, 0.2, 0.7, 1.9, 4.4], device=dev)
+    yield "quant_cuda.quant fp32, the E2M1 table (recognised)", lambda x: ops.quant_nearest(x.view(-1), tab), x32, n * 8
+    yield "quant_cuda.quant fp32, a 9-entry table of its own (literal scan)", lambda x: ops.quant_nearest(x.view(-1), odd), x32, n * 8
+    yield "per tensor argmin e2m1 fp32 (BASELINE config 1 form)", lambda x: ops.quant_tensor_argmin(x, "e2m1"), x32, n * 12
+    yield "per group argmin e2m1 fp32 (pure-torch semantics)", lambda x: ops.quant_rows_argmin(x, "e2m1", 128, False), x32, n * 8
+    yield "per token argmin e2m1 fp32, clamp3", lambda x: ops.quant_rows_argmin(x, "e2m1", C, True), x32, n * 8
+    yield "per group argmin e2m1 fp16 -> fp32", lambda x: ops.quant_rows_argmin(x, "e2m1", 128, False), x16, n * 6
+    yield "dual argmin e1m2-/e2m1+ fp16 -> fp32", lambda x: ops.quant_rows_dual_argmin(x, "e1m2_neg", "e2m1_pos", 128, 1.0), x16, n * 6
+    yield "neg_reverse per group e2m1 fp16", lambda x: ops.quant_rows_neg_reverse(x, "e2m1", 128), x16, n * 4
+    yield "nearest argmin, 15-entry grid, fp32", lambda x: ops.quant_nearest_argmin(x.view(-1), tab), x32, n * 8
+    yield "per group e2m1 fp32 -> fp32", lambda x: ops.quant_rows(x, "e2m1", 128), x32, n * 8
+    yield "per group e2m1 fp16 -> fp32 (mixed)", lambda x: ops.quant_rows(x, "e2m1", 128, torch.float32), x16, n * 6
+    yield "per token e2m3 fp32 -> fp16", lambda x: ops.quant_rows(x, "e2m3", C, torch.float16), x32, n * 6
+    yield "per token e2m3 fp32 -> fp32", lambda x: ops.quant_rows(x, "e2m3", C, torch.float32), x32, n * 8
+    yield "rows of 1000 (ragged) e2m1 fp16", lambda x: ops.quant_rows(x.view(-1)[:32000 * 1000].view(-1, 1000), "e2m1", 1000), x16, 32000 * 1000 * 4
+    yield "codes: generic byte codes + scales, e2m1 g128", lambda x: ops.quant_rows_codes(x, "e2m1", 128), x16, n * (2 + 1 + 2 / 128)
+    yield "codes: nibble-packed + scales, e2m1 g128", lambda x: ops.quant_rows_codes(x, "e2m1", 128, True), x16, n * (2 + W4)
+    yield "codes: FP4 GEMM operands (quantize_mx)", lambda x: gemm.quantize_mx(x), x16, n * (2 + W4)
+    yield "codes: E4M3 bytes per token (quantize_fp8)", lambda x: gemm.quantize_fp8(x), x16, n * 3
+    yield "codes: dense 6-bit per token (quantize_fp6)", lambda x: gemm.quantize_fp6(x), x16, n * 2.75
+    cm = [gemm.quantize_mx(x) for x in x16]
+    yield "decode FP4 operands (dequantize_mx)", lambda cs: gemm.dequantize_mx(*cs), cm, n * (W4 + 4)
+    k16 = [x.view(-1, 64) for x in x16]
+    yield "K and V in one launch (quant_rows_multi, rows of 64, e2m3)", lambda x: ops.quant_rows_multi([x, x], "e2m3", 64, torch.float16), k16, 2 * n * 4
+    yield "absmax fp16", lambda x: ops.absmax(x), x16, n * 2
+    yield "rotate_quant returning the rotated rows too", lambda x: rot.rotate_quant(x, "e2m1", return_rotated=True), x16, n * 6
+
+
 def main():
     want = sys.argv[1:]
     res = {}
-    for name, fn, xs, nbytes in cases():
+    import itertools
+    for name, fn, xs, nbytes in itertools.chain(other_cases(), cases()):
         if want and not any(w in name for w in want):
             continue
         try:
