@@ -286,6 +286,41 @@ def test_config4_d30_codes_exchange_full_size(dev):
     _oracle_slices("codes " + list(shapes)[-1], w[list(shapes)[-1]], got[list(shapes)[-1]])
 
 
+def test_codes_exchange_three_ranks_on_one_gpu(dev, monkeypatch):
+    """The packed exchange as THREE ranks would run it, replayed on one GPU: every rank quantizes its share into its slot
+    (the collective replaced by a recorder), then each rank's decode runs on a slab filled with all recorded slots -
+    offsets, slot widths and the decode table must agree between ranks that never talk about them.  Bit-equal to the
+    one-launch fp16 form on every layer, on every rank."""
+    from fpqvar_amd import calibrate as cal
+    shapes = {f"l{i}": s for i, s in enumerate(((384, 128), (128, 512), (640, 256), (256, 128), (1024, 384), (128, 128), (896, 640)))}
+    g = torch.Generator().manual_seed(9)
+    w = {n: (torch.randn(*s, generator=g) * 0.02).to(dev) for n, s in shapes.items()}
+    ref = cal.ShardedCalibration(shapes, w).run()
+    world = 3
+    slots = {}
+
+    def record(slab, rank, group=None):
+        slots[rank] = slab[rank].clone()
+    monkeypatch.setattr(cal, "gather_slab", record)
+    plan = cal.partition([(n, w[n].numel()) for n in w], world)
+    for r in range(world):
+        own = {n: (w[n] if n in plan[r] else torch.zeros((), device=dev).expand(shapes[n])) for n in shapes}
+        cal._calibrate_codes(own, r, world, None, True)
+    assert sorted(slots) == [0, 1, 2] and len({v.numel() for v in slots.values()}) == 1
+
+    def replay(slab, rank, group=None):
+        for r in range(world):
+            slab[r].copy_(slots[r])
+    monkeypatch.setattr(cal, "gather_slab", replay)
+    for r in range(world):
+        own = {n: (w[n] if n in plan[r] else torch.zeros((), device=dev).expand(shapes[n])) for n in shapes}
+        got = cal._calibrate_codes(own, r, world, None, True)
+        assert list(got) == list(shapes)
+        for n in shapes:
+            assert got[n].shape == w[n].shape and got[n].dtype == torch.float16
+            assert bool((got[n].view(torch.int16) == ref[n].view(torch.int16)).all()), f"rank {r}: {n}"
+
+
 @pytest.mark.parametrize("in_dtype", (torch.float32, torch.float16))
 @pytest.mark.parametrize("pack", (True, False))
 def test_codes_segments_equal_single_tensor_calls(dev, in_dtype, pack):
