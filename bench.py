@@ -458,8 +458,10 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
                 # the same with the packed exchange format (nibble codes + one fp32 scale per group: 0.53 B per element
                 # on the wire instead of 2, decoded locally, bit-identical): a second curve for the same run
                 stage[0] = "sharded calibration, codes exchange + all_gather_into_tensor"
-                codes_run = getattr(plat, "codes_calibration", None) or \
-                    (lambda: cal.calibrate_sharded(own_all(shapes, own, dev), exchange="codes"))
+                codes_run = getattr(plat, "codes_calibration", None)
+                if codes_run is None:   # slabs + the two segment tables built once (not timed), as for the fp16 form
+                    codes_plan = cal.ShardedCodesCalibration(own_all(shapes, own, dev), group=None)
+                    codes_run = codes_plan.run
                 codes_run()
                 plat.synchronize()
                 dist.barrier()
@@ -501,8 +503,8 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
         res["codes_exchange"] = {"exchange": "nibble codes + fp32 group scales (0.53 B per element), decoded locally",
                                  "ms_with_all_gather": round(dt_c * 1e3, 3), "Gelem_s_with_all_gather": round(total / dt_c / 1e9, 1),
                                  "gathered_bytes_per_rank": int(total * (0.5 + 4.0 / GROUP)),
-                                 "note": "per-layer quantizer launches + slab assembly are inside this time (the fp16 form "
-                                         "is one launch into a prebuilt slab)"}
+                                 "note": "one launch quantizes the rank's layers into its slot of a prebuilt codes slab, one "
+                                         "launch decodes every layer of every rank after the gather (both inside this time)"}
     return res
 
 

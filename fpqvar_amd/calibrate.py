@@ -289,75 +289,98 @@ def calibrate_sharded(weights: Mapping[str, torch.Tensor],
             for n in plan.names}
 
 
-def _calibrate_codes(weights, rank, world, group, gather):
-    """The packed exchange: nibble codes + one fp32 scale per group of 128 (0.53 B per element on the wire).  ONE launch
-    quantizes this rank's layers straight into its slot of the slab (fpq_quant_rows_codes_segments: no per-layer
-    launches, no copies), one all-gather, ONE launch decodes every layer of every rank into an fp16 slab
-    (fpq_dequant_rows_codes_segments) whose views are the result - bit-equal to the fp16 exchange."""
-    from . import _lib
-    names = list(weights.keys())
-    numel = {n: int(weights[n].numel()) for n in names}
-    plan = partition([(n, numel[n]) for n in names], world)
-    mine = plan[rank]
-    ref = next(iter(weights.values()))
-    dev = ref.device
-    table_id = _lib.TABLE_IDS["e2m1"]
-    for n in names:
-        if numel[n] % _GROUP != 0:
-            raise RuntimeError(f"calibrate_sharded(exchange='codes'): {n} is not a multiple of {_GROUP} elements")
-    code_bytes = {n: numel[n] // 2 for n in names}                     # multiples of 64: every layer's codes stay 16-byte aligned
-    n_scales = {n: numel[n] // _GROUP for n in names}
-    ranks = range(world) if gather and world > 1 else (rank,)
-    wc = max(sum(code_bytes[n] for n in plan[r]) for r in range(world))
-    wc = (wc + 15) // 16 * 16
-    ws = max(sum(n_scales[n] for n in plan[r]) for r in range(world))
-    slab = torch.empty((world, wc + 4 * ws), dtype=torch.uint8, device=dev)
-    if slab.data_ptr() % 16 != 0 or (wc + 4 * ws) % 16 != 0:
-        raise RuntimeError("calibrate_sharded(exchange='codes'): slab rows are not 16-byte aligned")
+class ShardedCodesCalibration:
+    """The packed exchange: nibble codes + one fp32 scale per group of 128 (0.53 B per element on the wire).
 
-    def layout(r):                                                     # (layer, codes offset, scales offset) inside slab[r]
-        off, soff, rows = 0, wc, []
-        for n in plan[r]:
-            rows.append((n, off, soff))
-            off += code_bytes[n]
-            soff += 4 * n_scales[n]
-        return rows
-    lib = _lib.lib()
-    keep = []                                                          # contiguous fp32 inputs stay alive until the launch is enqueued
-    q_desc = []
-    base = slab.data_ptr() + rank * slab.stride(0)
-    for n, off, soff in layout(rank):
-        w = weights[n]
-        _lib.require_gpu(w, f"calibrate_sharded({n})")
-        w = w.float() if w.dtype != torch.float32 else w
-        w = w if w.is_contiguous() else w.contiguous()
-        if w.data_ptr() % 16 != 0:
-            w = w.clone()
-        keep.append(w)
-        q_desc.append([w.data_ptr(), base + off, base + soff, n_scales[n]])
-    with _lib.device_guard(dev):
-        if q_desc:
-            q_tab = torch.tensor(q_desc, dtype=torch.int64).to(dev)
-            _lib.check(lib.fpq_quant_rows_codes_segments(q_tab.data_ptr(), len(q_desc), max(d[3] for d in q_desc), _GROUP,
-                                                         table_id, _lib.F32, 1, _lib.stream_ptr(dev)),
-                       "fpq_quant_rows_codes_segments")
-        if gather and world > 1:
-            gather_slab(slab, rank, group)
-        out_names = [n for r in ranks for n in plan[r]]
-        offsets, total = {}, 0
-        for n in out_names:
-            offsets[n] = total
+    Built once (slabs, the two device-resident segment tables); `run()` is then ONE launch that quantizes this rank's
+    layers straight into its slot of the codes slab (fpq_quant_rows_codes_segments: no per-layer launches, no copies),
+    one all-gather, and ONE launch that decodes every layer of every rank into an fp16 slab
+    (fpq_dequant_rows_codes_segments) whose views are the result - bit-equal to the fp16 exchange.  `weights`: every
+    name; only this rank's layers are read (others may be zero-stride placeholders of the right shape)."""
+
+    def __init__(self, weights, group=None, gather: bool = True, rank: Optional[int] = None, world: Optional[int] = None):
+        from . import _lib
+        self._lib = _lib
+        r0, w0 = _world(group)
+        self.rank = r0 if rank is None else rank
+        self.world = w0 if world is None else world
+        self.group, self.gather = group, bool(gather) and self.world > 1
+        rank, world = self.rank, self.world
+        self.names = list(weights.keys())
+        self.shapes = {n: tuple(weights[n].shape) for n in self.names}
+        numel = {n: int(weights[n].numel()) for n in self.names}
+        for n in self.names:
+            if numel[n] % _GROUP != 0:
+                raise RuntimeError(f"calibrate_sharded(exchange='codes'): {n} is not a multiple of {_GROUP} elements")
+        self.plan = partition([(n, numel[n]) for n in self.names], world)
+        self.mine = self.plan[rank]
+        dev = next(iter(weights.values())).device
+        self.device = dev
+        self.table_id = _lib.TABLE_IDS["e2m1"]
+        code_bytes = {n: numel[n] // 2 for n in self.names}               # multiples of 64: every layer's codes stay 16-byte aligned
+        n_scales = {n: numel[n] // _GROUP for n in self.names}
+        wc = max(sum(code_bytes[n] for n in self.plan[r]) for r in range(world))
+        wc = (wc + 15) // 16 * 16
+        ws = max(sum(n_scales[n] for n in self.plan[r]) for r in range(world))
+        width = (wc + 4 * ws + 15) // 16 * 16
+        self.slab = torch.empty((world, width), dtype=torch.uint8, device=dev)
+        if self.slab.data_ptr() % 16 != 0:
+            raise RuntimeError("calibrate_sharded(exchange='codes'): the slab is not 16-byte aligned")
+
+        def layout(r):                                                    # (layer, codes offset, scales offset) inside slab[r]
+            off, soff, rows = 0, wc, []
+            for n in self.plan[r]:
+                rows.append((n, off, soff))
+                off += code_bytes[n]
+                soff += 4 * n_scales[n]
+            return rows
+        self._inputs = []                                                 # contiguous fp32 inputs, kept alive with the table
+        q_desc = []
+        base = self.slab.data_ptr() + rank * width
+        for n, off, soff in layout(rank):
+            w = weights[n]
+            _lib.require_gpu(w, f"calibrate_sharded({n})")
+            w = w.float() if w.dtype != torch.float32 else w
+            w = w if w.is_contiguous() else w.contiguous()
+            if w.data_ptr() % 16 != 0:
+                w = w.clone()
+            self._inputs.append(w)
+            q_desc.append([w.data_ptr(), base + off, base + soff, n_scales[n]])
+        self._q_rows = max((d[3] for d in q_desc), default=0)
+        self._q_tab = torch.tensor(q_desc, dtype=torch.int64).to(dev) if q_desc else None
+        ranks = range(world) if self.gather else (rank,)
+        self.out_names = [n for r in ranks for n in self.plan[r]]
+        self.offsets, total = {}, 0
+        for n in self.out_names:
+            self.offsets[n] = total
             total += numel[n]
-        out = torch.empty(total, dtype=torch.float16, device=dev)
+        self.numel = numel
+        self.out = torch.empty(total, dtype=torch.float16, device=dev)
         d_desc = []
         for r in ranks:
-            rb = slab.data_ptr() + r * slab.stride(0)
+            rb = self.slab.data_ptr() + r * width
             for n, off, soff in layout(r):
-                d_desc.append([rb + off, rb + soff, out.data_ptr() + 2 * offsets[n], n_scales[n]])
-        if d_desc:
-            d_tab = torch.tensor(d_desc, dtype=torch.int64).to(dev)
-            _lib.check(lib.fpq_dequant_rows_codes_segments(d_tab.data_ptr(), len(d_desc), max(d[3] for d in d_desc), _GROUP,
-                                                           table_id, _lib.F32, _lib.F16, 1, _lib.stream_ptr(dev)),
-                       "fpq_dequant_rows_codes_segments")
-    res = {n: out[offsets[n]:offsets[n] + numel[n]].view(weights[n].shape) for n in out_names}
-    return {n: res[n] for n in names if n in res} if gather and world > 1 else {n: res[n] for n in mine}
+                d_desc.append([rb + off, rb + soff, self.out.data_ptr() + 2 * self.offsets[n], n_scales[n]])
+        self._d_rows = max((d[3] for d in d_desc), default=0)
+        self._d_tab = torch.tensor(d_desc, dtype=torch.int64).to(dev) if d_desc else None
+        self.gathered_bytes_per_rank = (world - 1) * width if self.gather else 0
+
+    def run(self) -> Dict[str, torch.Tensor]:
+        _lib, lib = self._lib, self._lib.lib()
+        with _lib.device_guard(self.device):
+            if self._q_tab is not None:
+                _lib.check(lib.fpq_quant_rows_codes_segments(self._q_tab.data_ptr(), self._q_tab.shape[0], self._q_rows, _GROUP,
+                                                             self.table_id, _lib.F32, 1, _lib.stream_ptr(self.device)),
+                           "fpq_quant_rows_codes_segments")
+            if self.gather:
+                gather_slab(self.slab, self.rank, self.group)
+            if self._d_tab is not None:
+                _lib.check(lib.fpq_dequant_rows_codes_segments(self._d_tab.data_ptr(), self._d_tab.shape[0], self._d_rows, _GROUP,
+                                                               self.table_id, _lib.F32, _lib.F16, 1, _lib.stream_ptr(self.device)),
+                           "fpq_dequant_rows_codes_segments")
+        res = {n: self.out[self.offsets[n]:self.offsets[n] + self.numel[n]].view(self.shapes[n]) for n in self.out_names}
+        return {n: res[n] for n in self.names if n in res}
+
+
+def _calibrate_codes(weights, rank, world, group, gather):
+    return ShardedCodesCalibration(weights, group=group, gather=gather, rank=rank, world=world).run()

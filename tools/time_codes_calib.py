@@ -1,5 +1,6 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Time the weight-calibration forms of VAR-d30 at world size 1 (profiles/r03_calib_codes_n1.txt)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fpqvar_amd import calibrate as cal, ops
 dev = torch.device("cuda:0")
@@ -15,6 +16,8 @@ def t(fn, it=5):
 sc = cal.ShardedCalibration(shapes, w)
 print("fp16 slab, one launch: %.2f ms" % t(sc.run))
 print("codes exchange path (world 1: quantize to codes + decode): %.2f ms" % t(lambda: cal.calibrate_sharded(w, exchange="codes")))
+cc = cal.ShardedCodesCalibration(w)
+print("  prebuilt ShardedCodesCalibration.run() (two launches): %.2f ms" % t(cc.run))
 names = list(w)
 def q_only():
     return [ops.quant_rows_codes(w[n], "e2m1", 128, pack_nibbles=True) for n in names]
