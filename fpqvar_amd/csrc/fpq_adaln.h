@@ -524,11 +524,13 @@ struct AdalnTiers {
 // 4 wavefronts per SIMD (128 registers) wherever the row fits: d30 on fp16 rows takes 96, on fp32 rows 118.  fp32 rows of
 // 17 .. 20 groups hold 40 registers of raw row and get 168 (3 wavefronts); the emitting forms are for tests and
 // calibration dumps.
-// TIGHT (fp16 rows of exactly 15 groups = VAR-d30, hardware levels: no table): planes of 240 vectors + four 272-byte-stride
-// images = 32 KiB of LDS to the byte, so FIVE workgroups fit a CU; the row loop is bound by latency (loads, LDS round
-// trips, cross-lane hazards: a wavefront issues an instruction every ~20 cycles), not by the vector pipe, and every
-// further wavefront per SIMD shows (profiles/r03_pmc_adaln.txt).  The padding lanes then read past the planes (finite
-// garbage, or the images behind them): their group 15 is dead weight in every phase and its stores are dropped.
+// TIGHT (fp16 rows of exactly 15 groups = VAR-d30, hardware levels: no table): planes of 240 vectors + four 4096-byte
+// images of 15 groups x 272 bytes = 31744 bytes of LDS - the most with which FIVE workgroups are placed on a CU (LDS is
+// handed out in 1280-byte granules, profiles/r03_occupancy_census.txt).  From ~14 resident wavefronts per CU on the
+// launch is throughput-bound (the stream itself: profiles/r03_adaln_ab.txt), so the fifth workgroup alone changes
+// nothing; what it buys is that workgroups of 8 rows no longer cost throughput and drain faster at the end of the grid
+// (profiles/r03_adaln_partition.txt, state C).  The padding lanes read past the planes (finite garbage, or the images
+// behind them): their group 15 is dead weight in every phase, writes nothing into the image, and its stores are dropped.
 #ifndef FPQ_ADALN_TIGHT
 #define FPQ_ADALN_TIGHT 1
 #endif
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
                                                               Lut16Tab tab, AdalnTiers tiers) {
   static_assert(MAXC >= 1 && MAXC <= 5, "rows of at most 20 groups");
   static_assert(!HW4 || !TOKEN, "hardware E2M1 levels / codes: per group only");
-  static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 32 KiB form: fp16 rows of 15 groups, no table");
+  static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 31 KiB form: fp16 rows of 15 groups, no table");
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   static_assert(NW == 4, "four wavefronts per workgroup");
   constexpr int W = NW;
