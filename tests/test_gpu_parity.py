@@ -831,6 +831,34 @@ def test_producers_at_full_size_equal_their_slices(dev, x_dtype):
         assert_bits_equal(tok[b0:b1], orc.per_token_kernel_sem(y_p.cpu(), "e2m3"), f"adaln per token {b0}:{b1}")
 
 
+@pytest.mark.parametrize("in_dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("cols", (128, 1024, 1920, 2560, 2688, 7680))
+def test_rotate_quant_smoothing_vector_every_width(dev, cols, in_dtype):
+    """rotate_quant(x, smooth=s) == rotate_quant(half(float(x) * s)) bit for bit, values and operands: the vector staged in
+    LDS (<= 2560 channels) and read from global memory (wider rows), tiles that straddle rows (column chunk = vector
+    index mod vectors per row, in 32 bits), several passes per workgroup (a smoothing vector selects a smaller grid),
+    ragged last tile, signed zeros."""
+    from fpqvar_amd import gemm, rotation as rot
+    g = torch.Generator().manual_seed(cols)
+    rows = 8192 * 1920 // cols + 3
+    x = (torch.randn(rows, cols, generator=g) * 1.1).to(in_dtype)
+    x[0, :7] = -0.0
+    x[rows - 1, -5:] = 0.0
+    s = torch.rand(cols, generator=g) * 1.5 + 0.25
+    s[3] = 1.0
+    xd, sd = x.to(dev), s.to(dev)
+    h = (xd.float() * sd).half()
+    want, want_y = rot.rotate_quant(h, "e2m1", return_rotated=True)
+    got, got_y = rot.rotate_quant(xd, "e2m1", smooth=sd, return_rotated=True)
+    assert_bits_equal(got_y, want_y, f"rotated rows, C={cols}")
+    assert_bits_equal(got, want, f"values, C={cols}")
+    assert_bits_equal(rot.rotate_quant(xd, "e2m1", smooth=sd), want, f"values (not emitting), C={cols}")
+    assert_bits_equal(rot.rotate_quant(xd, "e2m3", smooth=sd), rot.rotate_quant(h, "e2m3"), f"table form, C={cols}")
+    c1, s1 = rot.rotate_quant_mx(xd, smooth=sd)
+    c0, s0 = rot.rotate_quant_mx(h)
+    assert torch.equal(c1, c0) and torch.equal(s1.view(torch.int16), s0.view(torch.int16)), f"operands, C={cols}"
+
+
 def test_rotate_quant_several_passes_ragged_end(dev):
     """The table-free rotate forms run one pass per workgroup up to 16384 (values) / 8192 (codes) workgroups and several
     beyond: 70001 rows of 1920 = 16407 workgroup-tiles, the last one partial - two passes per workgroup in both forms,
