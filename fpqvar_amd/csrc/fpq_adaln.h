@@ -622,7 +622,16 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   if (hi > (b + 1) * L) hi = (b + 1) * L;
   if (hi > rows) hi = rows;
 
-  auto load_row = [&](u32x4 (&dst)[RV], int64_t row) {
+  // Rows of 17 / 18 groups (d36: C = 2304): the one or two groups beyond the tile fill at most half of the 64-lane slot
+  // that transforms them as butterflies.  A wavefront therefore pairs its rows: the first row of a pair parks its
+  // modulated slot chunk (lanes 0 .. 31), the second row is loaded and modulated with its slot chunk on lanes 32 .. 63
+  // (`hi_half`), and ONE slot pass - butterfly, maximum, scale, quantize, store - serves both (about 200 of a row's
+  // ~700 vector instructions belong to that pass).  Not for the emitting form (tests), the per-token forms (the slot
+  // enters the row's scale), fp32 rows (their slot chunk meets in the image).
+  constexpr bool PAIRABLE = MAXC == 5 && !X32 && !EMIT && !TOKEN && !DB;
+  const bool pair_ok = PAIRABLE && vpr - 256 <= 32;
+  const int lane16_hi = ((lane + 32) & 63) * 16;     // the slot chunk's vector index of this lane in a `hi_half` row
+  auto load_row = [&](u32x4 (&dst)[RV], int64_t row, bool hi_half = false) {
 #ifdef FPQ_ADALN_NOMEM   // timing experiment: zero-record descriptors - every row load returns zeros, every row store is dropped,
                          // the instruction stream is unchanged: what the kernel costs without its HBM traffic
     const __amdgpu_buffer_rsrc_t src = rq_rsrc((const char*)x + row * row_bytes, 0);
@@ -630,7 +639,11 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
     const __amdgpu_buffer_rsrc_t src = rq_rsrc((const char*)x + row * row_bytes, row_bytes);
 #endif
 #pragma unroll
-    for (int n = 0; n < RV; ++n) dst[n] = __builtin_amdgcn_raw_buffer_load_b128(src, la.lane16 + n * 1024, 0, kRqNt);
+    for (int n = 0; n < RV; ++n) {
+      int at = la.lane16 + n * 1024;
+      if (PAIRABLE && n == 4 && hi_half) at = lane16_hi + 4096;   // lanes 0 .. 31 then point beyond the row: zeros
+      dst[n] = __builtin_amdgcn_raw_buffer_load_b128(src, at, 0, kRqNt);
+    }
   };
 
   // the rotation's signs of this lane's chunk (16-byte vector: chunk lane % 16; fp32 rows: half lane & 1 of chunk
@@ -737,7 +750,12 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   unsigned long long st_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_rows = 0;
   const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole chip
 #endif
+  u32x4 pend = {0, 0, 0, 0};      // PAIRABLE: the parked slot chunk of the pair's first row, and that row
+  int64_t pend_row = 0;
+  bool cur_hi = false;           // the row in `cur` was loaded with its slot chunk on lanes 32 .. 63
   auto do_row = [&](u32x4 (&cur)[RV], u32x4 (&nxt)[RV], int64_t row, int64_t next_row) {
+    const bool hi_half = PAIRABLE && cur_hi;                           // second row of a pair
+    const bool park = PAIRABLE && pair_ok && !hi_half && next_row >= 0;   // first row of a pair: its slot waits for the next row
     FPQ_STAMP(0);                                   // between rows (loop control; the first row: the prologue)
 #ifdef FPQ_ADALN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -809,8 +827,10 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
           }
         }
 #pragma unroll
-      for (int c = 0; c < RV; ++c)                        // the zero padding is not part of the row
-        if ((c * 64 + lane) * (X32 ? 4 : 8) >= (int)ad.cols) a2[c] = 0.0f;
+      for (int c = 0; c < RV; ++c) {                      // the zero padding is not part of the row
+        const int vl = (PAIRABLE && c == 4 && hi_half) ? ((lane + 32) & 63) : lane;
+        if ((c * 64 + vl) * (X32 ? 4 : 8) >= (int)ad.cols) a2[c] = 0.0f;
+      }
       s2 = a2[0];
 #pragma unroll
       for (int c = 1; c < RV; ++c) s2 += a2[c];
@@ -852,8 +872,9 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       }
     } else {
       auto chunk = [&](int c) {
-        const u32x4 A0 = *(const u32x4*)(pl + la.lane16 + (0 * PV + c * 64) * 16), A1 = *(const u32x4*)(pl + la.lane16 + (1 * PV + c * 64) * 16);
-        const u32x4 B0 = *(const u32x4*)(pl + la.lane16 + (2 * PV + c * 64) * 16), B1 = *(const u32x4*)(pl + la.lane16 + (3 * PV + c * 64) * 16);
+        const int l16 = (PAIRABLE && c == 4 && hi_half) ? lane16_hi : la.lane16;
+        const u32x4 A0 = *(const u32x4*)(pl + l16 + (0 * PV + c * 64) * 16), A1 = *(const u32x4*)(pl + l16 + (1 * PV + c * 64) * 16);
+        const u32x4 B0 = *(const u32x4*)(pl + l16 + (2 * PV + c * 64) * 16), B1 = *(const u32x4*)(pl + l16 + (3 * PV + c * 64) * 16);
         const u32x4 w = cur[c];
         u32x4 hw;
         hw[0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])), __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
@@ -873,10 +894,24 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       }
       if constexpr (MAXC == 5) hw_slot = chunk(4);
     }
+    // the slot pass of this row: skipped when the chunk is parked; both halves of the lanes when it closes a pair
+    bool do_slot = MAXC == 5, paired = false;
+    if constexpr (PAIRABLE) {
+      if (park) {
+        pend = hw_slot;
+        pend_row = row;
+        do_slot = false;
+      } else if (hi_half) {
+        paired = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hw_slot[k] = lane < 32 ? pend[k] : hw_slot[k];
+      }
+    }
     if constexpr (!DB) {
       FPQ_PHASE("prefetch_next_row");
-      if (next_row >= 0) load_row(cur, next_row);   // wave-uniform; lands under the rest of this row
+      if (next_row >= 0) load_row(cur, next_row, park);   // wave-uniform; lands under the rest of this row
     }
+    if constexpr (PAIRABLE) cur_hi = park;
     __builtin_amdgcn_wave_barrier();
     FPQ_STAMP(3);                                   // modulate (plane reads), image writes, next row requested
 
@@ -901,7 +936,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
     // would run its epilogue for 64 lanes to serve 8 - 16 of them); quantized after the tile ----
     u32x4 y1 = {0, 0, 0, 0};
     uint32_t m1 = 0;
-    if constexpr (MAXC == 5) {
+    if (MAXC == 5 && do_slot) {   // wave-uniform (always true unless this row's chunk is parked for its pair)
       const u32x4 hwa[1] = {hw_slot};
       float t1[1][8];
       fwht128_h_n<1>(hwa, t1, 1, lane & 15);
@@ -920,7 +955,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
       m = sw[0] > sw[1] ? sw[0] : sw[1];
       s = s1 = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      if constexpr (MAXC == 5) {
+      if (MAXC == 5 && do_slot) {
         uint32_t ms[1] = {m1};
         row_max_dpp16_n<1>(ms, 1);
         s1 = row_scale16(ms[0], a.fpos.gmax, a.inv_gpos);
@@ -931,8 +966,12 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       }
     }
     FPQ_STAMP(5);                                   // group maximum across the quarters, scale and its reciprocal
-    const int64_t slot_at = row * vpr + 256 + lane;            // MAXC == 5: this lane's chunk of groups 16 .. 19
-    const bool slot_live = 256 + lane < vpr;
+    // MAXC == 5: this lane's chunk of groups 16 .. 19 - of this row, or (closing a pair) lanes 0 .. 31 the parked row's
+    // and lanes 32 .. 63 this row's
+    const int slot_idx = paired ? (lane & 31) : lane;
+    const int64_t slot_row = (paired && lane < 32) ? pend_row : row;
+    const int64_t slot_at = slot_row * vpr + 256 + slot_idx;
+    const bool slot_live = do_slot && 256 + slot_idx < vpr;
     if constexpr (CODES && TOKEN) {   // per-token operands: E4M3 bytes or dense 6-bit codes, the row scale is out already
       if (r.code_bits == 6) rq_store_codes6((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 6), vpr * 6), lane);
       else rq_store_codes8((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 8), vpr * 8), lane);
@@ -975,7 +1014,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       else
         rq_store_codes((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
                        rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
-      if constexpr (MAXC == 5) {
+      if (MAXC == 5 && do_slot) {
         const uint32_t cd = HW4 ? codes_vec16_hw(y1, s1.inv) : codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
         if (slot_live) {
           ((uint32_t*)out)[slot_at] = cd;
@@ -1010,7 +1049,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
 #endif
       FPQ_STAMP(7);                                 // output image round trip, stores issued
       FPQ_PHASE("row_end");
-      if constexpr (MAXC == 5) {
+      if (MAXC == 5 && do_slot) {
         u32x4 o1;
         if constexpr (HW4) {
 #pragma unroll
