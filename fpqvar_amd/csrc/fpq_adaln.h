@@ -556,7 +556,12 @@ struct AdalnTiers {
 #endif
 // NW: wavefronts per workgroup.  (8 sharing one set of planes - the staging paid once per 8 wavefronts - was measured
 // no faster than 4 and is not built any more, profiles/r03_adaln_partition.txt.)
-template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN, bool X32, bool HW4, bool TIGHT = false, int NW = 4>
+// PAIR2 (rows of exactly 8 groups = C 1024, VAR-d16; instantiated with MAXC = 4): TWO consecutive rows of a batch entry
+// fill the 16 group slots of one tile - chunks 0, 1 of the lane registers hold the first row, chunks 2, 3 the second
+// (they are contiguous in memory: the loads, the image, the transform and the stores do not know) - with LayerNorm
+// statistics and the modulation per half.  One row per tile leaves half of every epilogue instruction's lanes idle:
+// 0.53 of 8 TB/s at [32768 x 1024] (profiles/r03_survey_shapes.txt).
+template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN, bool X32, bool HW4, bool TIGHT = false, int NW = 4, bool PAIR2 = false>
 __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ? 5 : 4) void adaln_mfma_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                               u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                               int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a,
@@ -566,12 +571,14 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 31 KiB form: fp16 rows of 15 groups, no table");
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   static_assert(NW == 4, "four wavefronts per workgroup");
+  static_assert(!PAIR2 || (MAXC == 4 && !X32 && !EMIT && !TOKEN && !TIGHT), "two rows per tile: fp16 rows of 8 groups, per group");
   constexpr int W = NW;
+  constexpr int RPU = PAIR2 ? 2 : 1;             // rows per unit of work of a wavefront
   constexpr int RV = X32 ? 2 * MAXC : MAXC;      // 16-byte registers of one row per lane
 #ifdef FPQ_ADALN_PV_TEST   // timing experiment only (wrong results): a smaller LDS footprint
   constexpr int PV = FPQ_ADALN_PV_TEST;
 #else
-  constexpr int PV = TIGHT ? 240 : MAXC * 64;    // vectors per modulation plane (not TIGHT: the padding carries zeros)
+  constexpr int PV = TIGHT ? 240 : PAIR2 ? 128 : MAXC * 64;   // vectors per modulation plane (not TIGHT: the padding carries zeros)
 #endif
   constexpr int INS = TIGHT ? kRqOutStride : kRqInStride;
   constexpr bool DB = FPQ_ADALN_DB && !X32 && !EMIT;
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
                          // the instruction stream is unchanged: what the kernel costs without its HBM traffic
     const __amdgpu_buffer_rsrc_t src = rq_rsrc((const char*)x + row * row_bytes, 0);
 #else
-    const __amdgpu_buffer_rsrc_t src = rq_rsrc((const char*)x + row * row_bytes, row_bytes);
+    const __amdgpu_buffer_rsrc_t src = rq_rsrc((const char*)x + row * row_bytes, (PAIR2 && row + 1 < hi ? 2 : 1) * row_bytes);
 #endif
 #pragma unroll
     for (int n = 0; n < RV; ++n) {
@@ -754,6 +761,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   int64_t pend_row = 0;
   bool cur_hi = false;           // the row in `cur` was loaded with its slot chunk on lanes 32 .. 63
   auto do_row = [&](u32x4 (&cur)[RV], u32x4 (&nxt)[RV], int64_t row, int64_t next_row) {
+    const int nrows = (PAIR2 && row + 1 < hi) ? 2 : 1;                 // PAIR2: rows in this unit (a batch entry of odd length ends with one)
     const bool hi_half = PAIRABLE && cur_hi;                           // second row of a pair
     const bool park = PAIRABLE && pair_ok && !hi_half && next_row >= 0;   // first row of a pair: its slot waits for the next row
     FPQ_STAMP(0);                                   // between rows (loop control; the first row: the prologue)
@@ -801,16 +809,44 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
         }
       }
     float sum1 = a1[0], s2 = a2[0];
+    float sum1b = 0.0f, s2b = 0.0f;                  // PAIR2: the second row's sums (chunks 2, 3)
+    if constexpr (PAIR2) {
+      sum1 += a1[1];
+      s2 += a2[1];
+      sum1b = a1[2] + a1[3];
+      s2b = a2[2] + a2[3];
+    } else {
 #pragma unroll
-    for (int c = 1; c < RV; ++c) {
-      sum1 += a1[c];
-      s2 += a2[c];
+      for (int c = 1; c < RV; ++c) {
+        sum1 += a1[c];
+        s2 += a2[c];
+      }
     }
     FPQ_PHASE("ln_reduce_rstd");
     wave_sum2_dpp(sum1, s2);
     const float mean = sum1 * inv_c;
     float var = __builtin_fmaf(-mean, mean, s2 * inv_c);
-    if (!(mean * mean < (X32 ? 8.0f : 64.0f) * var)) {   // cancellation (or NaN / Inf): the centred second pass - rare
+    float mean_b = 0.0f, var_b = 1.0f;
+    if constexpr (PAIR2) {
+      wave_sum2_dpp(sum1b, s2b);
+      mean_b = sum1b * inv_c;
+      var_b = __builtin_fmaf(-mean_b, mean_b, s2b * inv_c);
+      if (!(mean * mean < 64.0f * var) || !(mean_b * mean_b < 64.0f * var_b)) {   // either row: both centred (rare)
+        float ca = 0.0f, cb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float mu = c < 2 ? mean : mean_b;
+            const float d0 = fma_h_lo(cur[c][k], 1.0f, -mu), d1 = fma_h_hi(cur[c][k], 1.0f, -mu);
+            if (c < 2) ca = __builtin_fmaf(d1, d1, __builtin_fmaf(d0, d0, ca));
+            else cb = __builtin_fmaf(d1, d1, __builtin_fmaf(d0, d0, cb));
+          }
+        var = wave_sum_dpp(ca) * inv_c;
+        var_b = wave_sum_dpp(cb) * inv_c;
+      }
+    }
+    if (!PAIR2 && !(mean * mean < (X32 ? 8.0f : 64.0f) * var)) {   // cancellation (or NaN / Inf): the centred second pass - rare
 #pragma unroll
       for (int c = 0; c < RV; ++c) a2[c] = 0.0f;
 #pragma unroll
@@ -840,11 +876,19 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
     float rstd = __builtin_amdgcn_rsqf(ve);
     rstd = __builtin_fmaf(rstd * __builtin_fmaf(-ve * rstd, rstd, 1.0f), 0.5f, rstd);
     const float nm = -mean * rstd;
+    float rstd_b = 0.0f, nm_b = 0.0f;
+    if constexpr (PAIR2) {
+      const float vb = var_b + ad.eps;
+      rstd_b = __builtin_amdgcn_rsqf(vb);
+      rstd_b = __builtin_fmaf(rstd_b * __builtin_fmaf(-vb * rstd_b, rstd_b, 1.0f), 0.5f, rstd_b);
+      nm_b = -mean_b * rstd_b;
+    }
     FPQ_STAMP(2);                                   // statistics, reduction, rstd
 
     // ---- modulate into the operand image: h * D = half(fma(fma(x, rstd, nm), A, B)) ----
     FPQ_PHASE("modulate_to_image");
     const __amdgpu_buffer_rsrc_t h_dst = rq_rsrc(EMIT && h_out ? (const char*)(h_out + row * vpr) : nullptr, EMIT && h_out ? vpr * 16 : 0);
+    const float rstd_a = rstd, nm_a = nm;
     u32x4 hw_slot = {0, 0, 0, 0};   // MAXC == 5: chunk 256 + lane of the row (groups 16 .. 19), transformed as butterflies
     if constexpr (X32) {
       auto half_chunk = [&](int n) {
@@ -873,8 +917,10 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
     } else {
       auto chunk = [&](int c) {
         const int l16 = (PAIRABLE && c == 4 && hi_half) ? lane16_hi : la.lane16;
-        const u32x4 A0 = *(const u32x4*)(pl + l16 + (0 * PV + c * 64) * 16), A1 = *(const u32x4*)(pl + l16 + (1 * PV + c * 64) * 16);
-        const u32x4 B0 = *(const u32x4*)(pl + l16 + (2 * PV + c * 64) * 16), B1 = *(const u32x4*)(pl + l16 + (3 * PV + c * 64) * 16);
+        const int pc = PAIR2 ? (c & 1) : c;                       // plane chunk: PAIR2 - both rows share the batch entry's modulation
+        const float rstd = (PAIR2 && c >= 2) ? rstd_b : rstd_a, nm = (PAIR2 && c >= 2) ? nm_b : nm_a;
+        const u32x4 A0 = *(const u32x4*)(pl + l16 + (0 * PV + pc * 64) * 16), A1 = *(const u32x4*)(pl + l16 + (1 * PV + pc * 64) * 16);
+        const u32x4 B0 = *(const u32x4*)(pl + l16 + (2 * PV + pc * 64) * 16), B1 = *(const u32x4*)(pl + l16 + (3 * PV + pc * 64) * 16);
         const u32x4 w = cur[c];
         u32x4 hw;
         hw[0] = f2h2(__builtin_fmaf(fma_h_lo(w[0], rstd, nm), u2f(A0[0]), u2f(B0[0])), __builtin_fmaf(fma_h_hi(w[0], rstd, nm), u2f(A0[1]), u2f(B0[1])));
@@ -1009,11 +1055,11 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       }
     } else if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
       if constexpr (HW4)
-        rq_store_codes_hw(img, yw, s, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
-                          rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
+        rq_store_codes_hw(img, yw, s, rq_rsrc((const uint32_t*)out + row * vpr, nrows * vpr * 4),
+                          rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane);
       else
-        rq_store_codes((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, vpr * 4),
-                       rq_rsrc(r.code_scales + row * (vpr >> 4), (vpr >> 4) * 2), lane);
+        rq_store_codes((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, nrows * vpr * 4),
+                       rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane);
       if (MAXC == 5 && do_slot) {
         const uint32_t cd = HW4 ? codes_vec16_hw(y1, s1.inv) : codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
         if (slot_live) {
@@ -1045,7 +1091,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
 #ifdef FPQ_ADALN_NOMEM
       rq_store_tile<TIGHT>(img, yw, rq_rsrc(out + row * vpr, 0), la);
 #else
-      rq_store_tile<TIGHT>(img, yw, rq_rsrc(out + row * vpr, vpr * 16), la);
+      rq_store_tile<TIGHT>(img, yw, rq_rsrc(out + row * vpr, nrows * vpr * 16), la);
 #endif
       FPQ_STAMP(7);                                 // output image round trip, stores issued
       FPQ_PHASE("row_end");
@@ -1071,7 +1117,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
 
   // ---- the workgroup's rows: wavefront w takes rows lo + w, lo + w + 4, ... ----
   u32x4 cur[RV], alt[DB ? RV : 1];
-  int64_t i = lo + wave;
+  int64_t i = lo + RPU * wave;
   if (i < hi) load_row(cur, i);                  // requested before the staging below
   if constexpr (!HW4) lut16_stage(lut, tab, a.shift);
 #if !defined(FPQ_ADALN_COPYONLY) || FPQ_ADALN_COPYONLY < 2
@@ -1086,8 +1132,8 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   } else if (i < hi) {
     // first pass peeled: both edges into the loop then carry "loads, then this row's stores", and the wait for the
     // prefetched row leaves the stores in flight (fpq_rotate_mfma.h, rotate_quant_mfma_kernel)
-    do_row(cur, cur, i, i + W < hi ? i + W : -1);
-    for (i += W; i < hi; i += W) do_row(cur, cur, i, i + W < hi ? i + W : -1);
+    do_row(cur, cur, i, i + RPU * W < hi ? i + RPU * W : -1);
+    for (i += RPU * W; i < hi; i += RPU * W) do_row(cur, cur, i, i + RPU * W < hi ? i + RPU * W : -1);
   }
 #ifdef FPQ_ADALN_STAMPS
   if constexpr (!EMIT) {

@@ -1088,6 +1088,10 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       const bool issue_bound = !X32 && (code_scales != nullptr || token_mode != 0 || table_id != FPQ_E2M1);
       int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 8192 ? (adaln_butterfly && rows >= 32768 ? 16 : issue_bound && rows >= 32768 ? 12 : 8) : 4);
       if (rows_per_wg < 1) rows_per_wg = 1;
+      // rows of exactly 8 groups (C = 1024): two rows per tile (fpq_adaln.h, PAIR2) - workgroups of an even number of rows
+      const bool pair2 = !adaln_butterfly && !X32 && r.vec_per_row == 128 && token_mode == 0 && !h_out && !y_out &&
+                         !getenv("FPQ_ADALN_NO_PAIR2");
+      if (pair2) rows_per_wg = rows_env ? ((rows_per_wg + 1) & ~1) : (rows >= 8192 ? 16 : 8);
       const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
       AdalnTiers tiers = {};
@@ -1119,6 +1123,19 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
     if (!adaln_butterfly) {                                                                                            \
+      if constexpr (M == 2 && !X32 && !(EMIT) && !(TOKEN)) {                                                           \
+        if (pair2) {                                                                                                   \
+          if (hw4)                                                                                                     \
+            hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, 4, CODES, false, false, false, true, false, 4, true>), g3,     \
+                               dim3(kBlock), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,     \
+                               rows, ad, r, h.args, tab, tiers);                                                       \
+          else                                                                                                         \
+            hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, 4, CODES, false, false, false, false, false, 4, true>), g3,    \
+                               dim3(kBlock), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,     \
+                               rows, ad, r, h.args, tab, tiers);                                                       \
+          break;                                                                                                       \
+        }                                                                                                              \
+      }                                                                                                                \
       if constexpr (!(TOKEN)) {                                                                                        \
         if constexpr (M == 4 && !X32 && !(EMIT) && !(CODES)) {                                                                     \
           if (hw4 && tight_ok && r.vec_per_row == 240) {   /* VAR-d30: 31 KiB of LDS, five workgroups per CU */        \

@@ -831,6 +831,38 @@ def test_producers_at_full_size_equal_their_slices(dev, x_dtype):
         assert_bits_equal(tok[b0:b1], orc.per_token_kernel_sem(y_p.cpu(), "e2m3"), f"adaln per token {b0}:{b1}")
 
 
+@pytest.mark.parametrize("mod_dtype", (torch.float16, torch.float32))
+def test_adaln_two_rows_per_tile_at_c1024(dev, mod_dtype, monkeypatch):
+    """C = 1024 (VAR-d16): two consecutive rows of a batch entry share one matrix-core tile (PAIR2).  Bit for bit against
+    the one-row-per-tile kernel - the emitting form always is one, FPQ_ADALN_NO_PAIR2 forces it - for batch entries of
+    odd and even length (a lone last row), one-row entries, the BASELINE-like shape, values and FP4 operands, with and
+    without a smoothing vector; plus the oracle's quantizer on the emitted rotated rows."""
+    from fpqvar_amd import gemm, rotation as rot
+    g = torch.Generator().manual_seed(1024)
+    C = 1024
+    for B, L in ((3, 5), (7, 1), (2, 2), (4, 7), (5, 16), (33, 131), (64, 512)):
+        x = (torch.randn(B, L, C, generator=g) * 1.3 + 0.2).half().to(dev)
+        x[0, 0] = x[0, 0] * 0 + 3.0                       # a constant row: zero variance
+        if L > 2:
+            x[B - 1, L - 1, :] = 1000.0 + torch.randn(C, generator=g).half().to(dev) * 0.01   # mean^2 >> var: the centred pass
+        sc = (torch.randn(B, 1, C, generator=g) * 0.3).to(mod_dtype).to(dev)
+        sh = (torch.randn(B, 1, C, generator=g) * 0.3).to(mod_dtype).to(dev)
+        for sm in (None, (torch.rand(C, generator=g) + 0.5).to(dev)):
+            got = rot.adaln_rotate_quant(x, sc, sh, "e2m1", smooth=sm)
+            codes, scales = rot.adaln_rotate_quant_mx(x, sc, sh, smooth=sm)
+            tab = rot.adaln_rotate_quant(x, sc, sh, "e2m3", smooth=sm)
+            out_e, h_e, y_e = rot.adaln_rotate_quant(x, sc, sh, "e2m1", smooth=sm, return_intermediates=True)
+            assert_bits_equal(got, out_e, f"B={B} L={L}: paired vs emitting (one row per tile)")
+            assert_bits_equal(got, orc.per_group_kernel_sem(y_e.cpu().reshape(-1, C), "e2m1", 128).view_as(got), f"B={B} L={L}: oracle on rotated rows")
+            assert_bits_equal(gemm.dequantize_mx(codes.view(B * L, -1), scales.view(B * L, -1)).half().view_as(got), got, f"B={B} L={L}: operands")
+            monkeypatch.setenv("FPQ_ADALN_NO_PAIR2", "1")
+            assert_bits_equal(rot.adaln_rotate_quant(x, sc, sh, "e2m1", smooth=sm), got, f"B={B} L={L}: unpaired values")
+            assert_bits_equal(rot.adaln_rotate_quant(x, sc, sh, "e2m3", smooth=sm), tab, f"B={B} L={L}: unpaired, table form")
+            c0, s0 = rot.adaln_rotate_quant_mx(x, sc, sh, smooth=sm)
+            assert torch.equal(c0, codes) and torch.equal(s0.view(torch.int16), scales.view(torch.int16)), f"B={B} L={L}: unpaired operands"
+            monkeypatch.delenv("FPQ_ADALN_NO_PAIR2")
+
+
 @pytest.mark.parametrize("in_dtype", (torch.float16, torch.float32))
 @pytest.mark.parametrize("cols", (128, 1024, 1920, 2560, 2688, 7680))
 def test_rotate_quant_smoothing_vector_every_width(dev, cols, in_dtype):
