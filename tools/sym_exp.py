@@ -1,4 +1,7 @@
-"""Experiment driver for diagnostic builds: per-token E2M3 quantizers under grid variations read from the environment."""
+"""Experiment driver behind profiles/r03_e2m3_grid.txt: E2M3 quantizers under grid variations.  The environment hooks it
+sets (FPQ_SYM_BIGTAB="U,cap", FPQ_WAVE_CAP, FPQ_BLOCK_RPB) existed only in a temporary diagnostic build of fpq_kernels.hip
+(three getenv lines in fpq_quant_rows / launch_fast16_block); the measured choices are the defaults now, so against the
+regular library every line of this script prints the same figure.      python tools/sym_exp.py <libfpq_hip.so>"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
