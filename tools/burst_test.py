@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Time per call against the number of launches per burst (profiles/r03_burst_lead.txt): the tensors, calls and burst
+protocol of bench.py's other_kernels; JUNK=n / CHURN=GiB reproduce bench.py's allocation history first."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fpqvar_amd import rotation as rot, ops
 dev = torch.device("cuda:0")
