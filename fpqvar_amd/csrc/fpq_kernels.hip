@@ -1109,6 +1109,13 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       for (int t = 0; t < 3; ++t) tiers.per_batch[t] = (int)((L + tiers.rows[t] - 1) / tiers.rows[t]);
       tiers.batches[0] = (int)(n_batches - nb1 - nb2);
       tiers.batches[1] = (int)nb1;
+      {
+        const int64_t nb_of[3] = {n_batches - nb1 - nb2, nb1, nb2};
+        for (int t = 0; t < 3; ++t) {   // id / d == (id * ceil(2^32 / d)) >> 32 whenever id * d < 2^32
+          const uint64_t d = (uint64_t)tiers.per_batch[t], ids = (uint64_t)nb_of[t] * d;
+          tiers.magic[t] = (d >= 2 && ids * d < (1ull << 32)) ? (uint32_t)(((1ull << 32) + d - 1) / d) : 0u;
+        }
+      }
       const int64_t n_wg3 = (int64_t)tiers.batches[0] * tiers.per_batch[0] + nb1 * tiers.per_batch[1] + nb2 * tiers.per_batch[2];
       if (n_wg3 > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
       const dim3 g2((unsigned)(n_batches * per_batch));         // second generation (butterfly form): flat grid of equal chunks
