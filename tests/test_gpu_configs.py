@@ -286,6 +286,35 @@ def test_config4_d30_codes_exchange_full_size(dev):
     _oracle_slices("codes " + list(shapes)[-1], w[list(shapes)[-1]], got[list(shapes)[-1]])
 
 
+def test_fp16_exchange_three_ranks_on_one_gpu(dev, monkeypatch):
+    """The fp16 slab exchange (ShardedCalibration: one launch into the rank's slot, one in-place all-gather, views of the
+    slab) as three ranks would run it, replayed on one GPU with the collective replaced by a recorder / a replayer:
+    every rank's slot offsets and the views every rank takes agree; bit-equal to per-layer fpq_quant_rows."""
+    from fpqvar_amd import calibrate as cal, ops
+    shapes = {f"l{i}": s for i, s in enumerate(((384, 128), (128, 512), (640, 256), (256, 128), (1024, 384), (128, 128), (896, 640)))}
+    g = torch.Generator().manual_seed(10)
+    w = {n: (torch.randn(*s, generator=g) * 0.02).to(dev) for n, s in shapes.items()}
+    want = {n: ops.quant_rows(w[n], "e2m1", 128, torch.float16) for n in shapes}
+    world, slots = 3, {}
+    owners = cal.plan_owners(shapes, world)
+    assert sorted(n for o in owners for n in o) == sorted(shapes)
+    for r in range(world):
+        monkeypatch.setattr(cal, "_world", lambda group, r=r: (r, world))
+        monkeypatch.setattr(cal, "gather_slab", lambda slab, rank, group=None: slots.__setitem__(rank, slab[rank].clone()))
+        cal.ShardedCalibration(shapes, {n: w[n] for n in owners[r]}).run()
+    assert sorted(slots) == [0, 1, 2]
+
+    def replay(slab, rank, group=None):
+        for r in range(world):
+            slab[r].copy_(slots[r])
+    monkeypatch.setattr(cal, "gather_slab", replay)
+    for r in range(world):
+        monkeypatch.setattr(cal, "_world", lambda group, r=r: (r, world))
+        got = cal.ShardedCalibration(shapes, {n: w[n] for n in owners[r]}).run()
+        for n in shapes:
+            assert_bits_equal(got[n], want[n], f"rank {r}: {n}")
+
+
 def test_codes_exchange_three_ranks_on_one_gpu(dev, monkeypatch):
     """The packed exchange as THREE ranks would run it, replayed on one GPU: every rank quantizes its share into its slot
     (the collective replaced by a recorder), then each rank's decode runs on a slab filled with all recorded slots -
