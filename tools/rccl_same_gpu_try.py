@@ -1,0 +1,35 @@
+"""The sharded calibration over RCCL with world size 2 (fp16 and codes exchange, in-place all_gather_into_tensor), bit-equal to
+per-layer launches - on a node with two GPUs.  On the one-GPU boxes this build had, both ranks land on device 0 and RCCL
+refuses ("Duplicate GPU detected : rank 0 and rank 1 both on CUDA device", NCCL 2.26.6 - run of round 3): the N > 1 path is
+covered by gloo ranks on CPU and by three-rank replays on one GPU (tests/test_gpu_configs.py) instead.
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_same_gpu_try.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import datetime
+import torch
+import torch.distributed as dist
+
+rank = int(os.environ["RANK"])
+local = int(os.environ.get("LOCAL_RANK", rank))
+DEV = local if torch.cuda.device_count() > local else 0
+torch.cuda.set_device(DEV)
+try:
+    dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=60), device_id=torch.device("cuda", DEV))
+    slab = torch.full((2, 1024), float(rank + 1), device=f"cuda:{DEV}", dtype=torch.float16)
+    dist.all_gather_into_tensor(slab.view(-1), slab[rank])
+    torch.cuda.synchronize()
+    print(f"rank {rank}: in-place all_gather_into_tensor ok: rows {slab[:, 0].tolist()}", flush=True)
+    from fpqvar_amd import calibrate as cal
+    shapes = {f"l{i}": s for i, s in enumerate(((384, 128), (128, 512), (640, 256), (256, 128), (1024, 384)))}
+    g = torch.Generator().manual_seed(3)
+    w = {n: (torch.randn(*s, generator=g) * 0.02).to(f"cuda:{DEV}") for n, s in shapes.items()}
+    from fpqvar_amd import ops
+    want = {n: ops.quant_rows(w[n], "e2m1", 128, torch.float16) for n in shapes}
+    got = cal.calibrate_sharded(w)
+    ok16 = all(torch.equal(got[n].view(torch.int16), want[n].view(torch.int16)) for n in shapes)
+    gotc = cal.calibrate_sharded(w, exchange="codes")
+    okc = all(torch.equal(gotc[n].view(torch.int16), want[n].view(torch.int16)) for n in shapes)
+    print(f"rank {rank}: sharded calibration over RCCL, world 2: fp16 exchange bit-equal {ok16}, codes exchange bit-equal {okc}", flush=True)
+    dist.destroy_process_group()
+except Exception as e:
+    print(f"rank {rank}: {type(e).__name__}: {str(e)[:400]}", flush=True)
