@@ -2,7 +2,7 @@
 per-layer launches - on a node with two GPUs.  On the one-GPU boxes this build had, both ranks land on device 0 and RCCL
 refuses ("Duplicate GPU detected : rank 0 and rank 1 both on CUDA device", NCCL 2.26.6 - run of round 3): the N > 1 path is
 covered by gloo ranks on CPU and by three-rank replays on one GPU (tests/test_gpu_configs.py) instead.
-    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_same_gpu_try.py"""
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_world2_check.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import datetime
