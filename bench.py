@@ -104,12 +104,23 @@ class GpuPlatform:
         import torch
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-        torch.cuda.set_device(local_rank)
+        index = local_rank
+        if os.environ.get("FPQ_BENCH_SHARE_GPU"):
+            # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks: the ranks share the devices there are,
+            # the collectives run over gloo (RCCL refuses two ranks on one device).  Exercises every GPU-side step of the
+            # multi-rank line - slabs, in-place gather on device memory, codes exchange; its numbers are no scaling curve.
+            index = local_rank % torch.cuda.device_count()
+            self.backend = "gloo"
+            self.data = "synthetic; REHEARSAL: the ranks share one GPU, collectives over gloo - not a scaling measurement"
+        torch.cuda.set_device(index)
         self.torch = torch
-        self.dev = torch.device("cuda", local_rank)
+        self.dev = torch.device("cuda", index)
 
     def init_dist(self, dist):
-        dist.init_process_group(self.backend, device_id=self.dev)
+        if self.backend == "nccl":
+            dist.init_process_group(self.backend, device_id=self.dev)
+        else:
+            dist.init_process_group(self.backend)
 
     def synchronize(self):
         self.torch.cuda.synchronize()

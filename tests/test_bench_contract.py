@@ -47,6 +47,29 @@ def test_bench_prints_one_contract_line():
     assert res["value"] > 400
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """`bench.py --gpus 2` with FPQ_BENCH_SHARE_GPU=1: two ranks on the one GPU of a test box, collectives over gloo (RCCL
+    refuses two ranks on a device).  Every GPU-side step of the multi-rank line runs for real - the shards, the barrier
+    and the MAX over ranks, the sharded calibration's slab with its in-place all-gather on device memory, the codes
+    exchange with its two segment launches; the line says that it is a rehearsal, its numbers are no scaling curve."""
+    env = dict(os.environ, FPQ_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and "REHEARSAL" in res["data"] and res["scaling"] == "weak"
+    cal = res["weight_calibration"]
+    assert "error" not in cal, cal
+    assert cal["n_gpus"] == 2 and cal["ms"] > 0 and cal["ms_with_all_gather"] > cal["ms"]
+    assert cal["all_gather_ms"] > 0 and cal["gathered_bytes_per_rank"] == 2 * cal["elements"]
+    cx = cal["codes_exchange"]
+    assert cx["ms_with_all_gather"] > 0 and cx["gathered_bytes_per_rank"] < cal["gathered_bytes_per_rank"] // 3
+    assert res["omitted_at_n_gt_1"] == ["cpu_baseline", "other_kernels", "unfused_gpu"]
+
+
 # ---- the N > 1 control flow, rehearsed on CPU: `bench.py --gpus 2` starts two ranks as a child process, the ranks
 # meet over gloo, every rank reaches every collective, rank 0 prints ONE line with n_gpus == 2.  The platform
 # (device, backend, the hot-path step) and the two HIP calibration classes are replaced by stand-ins in a launcher
