@@ -170,3 +170,23 @@ dist.destroy_process_group()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29731", str(script)], capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", (2, 3))
+def test_sharded_calibration_real_ranks_share_the_gpu(world):
+    """tools/rccl_world2_check.py with FPQ_CHECK_BACKEND=gloo: `world` processes on the one GPU of a test box (gloo takes
+    device tensors; RCCL refuses two ranks on a device), the in-place all_gather_into_tensor on device memory, and
+    calibrate_sharded with the fp16 and the codes exchange - every rank's gathered model bit-equal to per-layer launches."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPQ_CHECK_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", str(29540 + world), os.path.join(root, "tools", "rccl_world2_check.py")],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-2000:]
+    assert text.count("in-place all_gather_into_tensor ok") == world, text[-2000:]
+    assert text.count("fp16 exchange bit-equal True, codes exchange bit-equal True") == world, text[-2000:]

@@ -14,8 +14,11 @@ local = int(os.environ.get("LOCAL_RANK", rank))
 DEV = local if torch.cuda.device_count() > local else 0
 torch.cuda.set_device(DEV)
 try:
-    dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=60), device_id=torch.device("cuda", DEV))
-    slab = torch.full((2, 1024), float(rank + 1), device=f"cuda:{DEV}", dtype=torch.float16)
+    if os.environ.get("FPQ_CHECK_BACKEND", "nccl") == "gloo":   # two ranks on one GPU: gloo takes device tensors, RCCL refuses the duplicate device
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+    else:
+        dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=60), device_id=torch.device("cuda", DEV))
+    slab = torch.full((dist.get_world_size(), 1024), float(rank + 1), device=f"cuda:{DEV}", dtype=torch.float16)
     dist.all_gather_into_tensor(slab.view(-1), slab[rank])
     torch.cuda.synchronize()
     print(f"rank {rank}: in-place all_gather_into_tensor ok: rows {slab[:, 0].tolist()}", flush=True)
@@ -29,7 +32,7 @@ try:
     ok16 = all(torch.equal(got[n].view(torch.int16), want[n].view(torch.int16)) for n in shapes)
     gotc = cal.calibrate_sharded(w, exchange="codes")
     okc = all(torch.equal(gotc[n].view(torch.int16), want[n].view(torch.int16)) for n in shapes)
-    print(f"rank {rank}: sharded calibration over RCCL, world 2: fp16 exchange bit-equal {ok16}, codes exchange bit-equal {okc}", flush=True)
+    print(f"rank {rank}: sharded calibration over {dist.get_backend()}, world {dist.get_world_size()}: fp16 exchange bit-equal {ok16}, codes exchange bit-equal {okc}", flush=True)
     dist.destroy_process_group()
 except Exception as e:
     print(f"rank {rank}: {type(e).__name__}: {str(e)[:400]}", flush=True)
