@@ -177,7 +177,8 @@ dist.destroy_process_group()
 def test_sharded_calibration_real_ranks_share_the_gpu(world):
     """tools/rccl_world2_check.py with FPQ_CHECK_BACKEND=gloo: `world` processes on the one GPU of a test box (gloo takes
     device tensors; RCCL refuses two ranks on a device), the in-place all_gather_into_tensor on device memory, and
-    calibrate_sharded with the fp16 and the codes exchange - every rank's gathered model bit-equal to per-layer launches."""
+    calibrate_sharded with the fp16 and the codes exchange - every rank's gathered model bit-equal to per-layer launches -
+    and the block-sharded format search against the single-process loop."""
     import os
     import subprocess
     import sys
@@ -190,3 +191,4 @@ def test_sharded_calibration_real_ranks_share_the_gpu(world):
     assert out.returncode == 0, text[-2000:]
     assert text.count("in-place all_gather_into_tensor ok") == world, text[-2000:]
     assert text.count("fp16 exchange bit-equal True, codes exchange bit-equal True") == world, text[-2000:]
+    assert text.count("equals the single-process result: True") == world, text[-2000:]

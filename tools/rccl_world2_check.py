@@ -33,6 +33,25 @@ try:
     gotc = cal.calibrate_sharded(w, exchange="codes")
     okc = all(torch.equal(gotc[n].view(torch.int16), want[n].view(torch.int16)) for n in shapes)
     print(f"rank {rank}: sharded calibration over {dist.get_backend()}, world {dist.get_world_size()}: fp16 exchange bit-equal {ok16}, codes exchange bit-equal {okc}", flush=True)
+    # the format search sharded by block (search/search_fp6_format.py's per-block loop): block b on rank b mod world, every
+    # rank evaluates with the fused quantizers on ITS device tensors, one all-gather of (loss, formats) triples
+    from fpqvar_amd import format_search as fs
+
+    def layer(b):
+        gg = torch.Generator().manual_seed(100 + b)
+        xs = [torch.randn(2, 16 * (j + 1), 256, generator=gg).half().to(f"cuda:{DEV}") for j in range(3)]
+        wt = (torch.randn(384, 256, generator=gg) * 0.05).half().to(f"cuda:{DEV}")
+        return xs, wt
+
+    def evaluate(b):
+        xs, wt = layer(b)
+        wf, af, losses = fs.search_layer(xs, wt, fs.FP6_FORMATS)
+        return wf, af, losses[(wf, af)]
+    n_blocks = 5
+    got_s = fs.search_blocks_sharded(n_blocks, evaluate, fs.FP6_FORMATS)
+    want_s = [evaluate(b) for b in range(n_blocks)]
+    ok_s = all(g[0] == w_[0] and g[1] == w_[1] and abs(g[2] - w_[2]) <= 1e-6 * abs(w_[2]) for g, w_ in zip(got_s, want_s))
+    print(f"rank {rank}: format search sharded over {dist.get_world_size()} ranks equals the single-process result: {ok_s}", flush=True)
     dist.destroy_process_group()
 except Exception as e:
     print(f"rank {rank}: {type(e).__name__}: {str(e)[:400]}", flush=True)
