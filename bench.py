@@ -403,6 +403,157 @@ def other_kernels(dev):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ configs 3 and 5
+STEP_MODELS = {
+    # tr/var.py:175 - ten scale steps over patch_nums, B images with CFG = 2 B conditioned rows per token
+    "d30": dict(C=1920, B=100, pn=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16),
+                what="VAR-d30 256x256, 50 images with CFG (evaluate_fp_quant_transform_rotate.py:187-199)"),
+    "d36-512": dict(C=2304, B=20, pn=(1, 2, 3, 4, 6, 9, 13, 18, 24, 32),
+                    what="VAR-d36 512x512, 10 images with CFG (evaluate_fp_quant_transform_rotate_512x512.py:54,62,192-200)"),
+}
+STEP_POOL_BYTES = 3 << 29        # 1.5 GiB per side: six times the 256 MiB Infinity Cache
+STEP_FLUSH_BYTES = 1 << 29
+
+
+def generation_steps(dev, model="d30", rows_dtype="fp32", mode="rotating", replays=7, only_ops=None):
+    """BASELINE configs 3 / 5 at the row counts they actually run (tr/var.py:175: rows = 2 B pn^2): the four quantizer
+    calls of one W4A4 AdaLN block (tr/basic_var.py:263,266 -> two adaLN producers on the residual stream; tr/quant_utils.py:765
+    -> the proj input; :991 -> the dual-format fc2 input) at every one of the ten scale steps, through the C ABI on
+    preallocated buffers, N calls of one kind captured in ONE hipGraph and replayed.
+    mode "rotating": call i of a graph works on slice i of a 1.5 GiB input pool and a 1.5 GiB output pool, and a 512 MiB
+    write between replays empties the caches - every call streams cold HBM, also at 100 rows.  mode "resident": every call
+    on the same tensor (what r03's tool did; at small steps the Infinity Cache serves it, as it may in a model whose
+    previous kernel has just written the tensor).  rows_dtype: dtype of the residual stream entering the adaLN producer
+    (fp32 under the reference's autocast, tr/var.py:209); the other two inputs are fp16 Linear / GELU outputs.
+    Per step and kernel: median and minimum us per call over `replays` replays, algorithmic bytes, fraction of 8 TB/s; per
+    model: sum of bytes / sum of (2 adaLN + act + dual) medians = the time-weighted fraction."""
+    import ctypes
+    import statistics
+    import torch
+    from fpqvar_amd import _lib, rotation as rot
+    lib = _lib.lib()
+    m = STEP_MODELS[model]
+    C, B, HID = m["C"], m["B"], 4 * m["C"]
+    x32 = rows_dtype == "fp32"
+    g = torch.Generator(device=dev).manual_seed(3)
+    scale = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
+    shift = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
+    smooth = torch.rand(C, device=dev, generator=g) + 0.5
+    mask = rot._mask_arg(None)
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    flush = torch.empty(STEP_FLUSH_BYTES, dtype=torch.uint8, device=dev)
+    E2M1, NEG, POS = _lib.TABLE_IDS["e2m1"], _lib.TABLE_IDS["e1m2_neg"], _lib.TABLE_IDS["e2m1_pos"]
+
+    def pool(kind):
+        n = STEP_POOL_BYTES // (4 if kind == "f32" else 2)
+        chunk = 1 << 26
+        t = torch.empty(n, dtype=torch.float32 if kind == "f32" else torch.float16, device=dev)
+        for o in range(0, n, chunk):
+            r = torch.randn(min(chunk, n - o), device=dev, generator=g)
+            t[o:o + r.numel()] = torch.nn.functional.gelu(r, approximate="tanh") if kind == "gelu" else r
+        return t
+
+    def graph_us(call, in_bytes, out_bytes, xin, xout):
+        n_calls = 50 if in_bytes + out_bytes < (64 << 20) else 20
+        ib, ob = (in_bytes + 255) & ~255, (out_bytes + 255) & ~255
+        k = 1 if mode == "resident" else max(1, min(n_calls, STEP_POOL_BYTES // max(ib, ob)))
+        xi, xo = xin.data_ptr(), xout.data_ptr()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            sp = _lib.stream_ptr(dev)
+            call(xi, xo, sp)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                sp = _lib.stream_ptr(dev)
+                for i in range(n_calls):
+                    call(xi + (i % k) * ib, xo + (i % k) * ob, sp)
+        torch.cuda.current_stream().wait_stream(s)
+        for _ in range(3):
+            gr.replay()
+        ts = []
+        for _ in range(replays):
+            if mode != "resident":
+                flush.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / n_calls)
+        del gr
+        return statistics.median(ts), min(ts), n_calls, k
+
+    def ck(st, what):
+        if st != 0:
+            _lib.check(st, what)
+
+    steps = [dict(pn=pn, rows=B * pn * pn) for pn in m["pn"]]
+    xout = torch.empty(STEP_POOL_BYTES, dtype=torch.uint8, device=dev)
+    plan = [("adaln", "f32" if x32 else "f16", C), ("act", "f16", C), ("dual", "gelu", HID)]
+    for name, kind, cols in plan:
+        if only_ops and name not in only_ops:
+            continue
+        xin = pool(kind)
+        for stp in steps:
+            rows, L = stp["rows"], stp["pn"] ** 2
+            in_b = rows * cols * (4 if kind == "f32" else 2)
+            out_b = rows * cols * 2
+            if name == "adaln":
+                def call(xi, xo, sp, rows=rows, L=L):
+                    ck(lib.fpq_adaln_rotate_quant_rows(xi, xo, None, None, rows, C, _lib.F32 if x32 else _lib.F16,
+                                                       scale.data_ptr(), shift.data_ptr(), _lib.F16, L, 1e-6,
+                                                       smooth.data_ptr(), mask, E2M1, sp), "fpq_adaln_rotate_quant_rows")
+            elif name == "act":
+                def call(xi, xo, sp, rows=rows):
+                    ck(lib.fpq_quant_rows(xi, xo, rows * (C // GROUP), GROUP, E2M1, _lib.F16, _lib.F16, sp), "fpq_quant_rows")
+            else:
+                def call(xi, xo, sp, rows=rows):
+                    ck(lib.fpq_quant_rows_dual(xi, xo, rows * (HID // GROUP), GROUP, NEG, POS, _lib.F16, _lib.F16, None, 1.0,
+                                               flag.data_ptr(), sp), "fpq_quant_rows_dual")
+            med, best, n_calls, k = graph_us(call, in_b, out_b, xin, xout)
+            stp[name] = {"us": round(med, 2), "min_us": round(best, 2), "bytes": in_b + out_b,
+                         "frac_of_8TBps": round((in_b + out_b) / med / 1e6 / HBM_PEAK_GBS, 3), "calls_per_graph": n_calls,
+                         "slices": k}
+        del xin
+        torch.cuda.empty_cache()
+    assert not bool(flag.any()), "the dual quantizer's NaN scratch must be zero again"
+    weights = {"adaln": 2, "act": 1, "dual": 1}     # calls per block and step
+    have = [n for n, _, _ in plan if all(n in s for s in steps)]
+    by_kernel, tot_t, tot_b = {}, 0.0, 0
+    for n in have:
+        t = sum(s[n]["us"] for s in steps)
+        b = sum(s[n]["bytes"] for s in steps)
+        by_kernel[n] = {"sum_us": round(t, 1), "bytes": b, "frac_of_8TBps": round(b / t / 1e6 / HBM_PEAK_GBS, 3)}
+        tot_t += weights[n] * t
+        tot_b += weights[n] * b
+    for s in steps:
+        if len(have) == 3:
+            t = sum(weights[n] * s[n]["us"] for n in have)
+            b = sum(weights[n] * s[n]["bytes"] for n in have)
+            s["block_us"] = round(t, 2)
+            s["frac_of_8TBps"] = round(b / t / 1e6 / HBM_PEAK_GBS, 3)
+    return {"model": model, "what": m["what"], "rows_dtype_of_the_residual_stream": rows_dtype, "mode": mode,
+            "clock": "hipGraph replay, HIP events around each replay, median over %d replays per (step, kernel)" % replays,
+            "per_block_and_step": "2 x adaLN producer (values out) + 1 x E2M1 g=128 (proj input) + 1 x dual E1M2-/E2M1+ g=128 "
+                                  "(fc2 input, default clipping strength: two launches)",
+            "steps": steps, "by_kernel": by_kernel,
+            "block_us_over_the_ten_steps": round(tot_t, 1), "bytes_per_block": tot_b,
+            "time_weighted_frac_of_8TBps": round(tot_b / tot_t / 1e6 / HBM_PEAK_GBS, 4) if tot_t else None}
+
+
+def steps_summary(full):
+    """The compact form for the bench line (the full record goes to profiles/ through tools/bench_small_steps.py)."""
+    out = {k: full[k] for k in ("model", "rows_dtype_of_the_residual_stream", "mode", "clock", "per_block_and_step",
+                                "block_us_over_the_ten_steps", "bytes_per_block", "time_weighted_frac_of_8TBps")}
+    out["by_kernel"] = {n: v["frac_of_8TBps"] for n, v in full["by_kernel"].items()}
+    out["rows"] = [s["rows"] for s in full["steps"]]
+    for n in full["by_kernel"]:
+        out[n + "_us"] = [s[n]["us"] for s in full["steps"]]
+    out["step_frac_of_8TBps"] = [s.get("frac_of_8TBps") for s in full["steps"]]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ config 4
 def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, warm=6):
     """BASELINE.json config 4: every Linear weight of VAR-d30 (1.327 G fp32 elements, synthetic randn*0.02) quantized
@@ -682,6 +833,12 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
                 res["other_kernels"] = other_kernels(plat.dev)
             except Exception as e:
                 res["other_kernels"] = {"error": repr(e)[:200]}
+            # BASELINE configs 3 and 5 at their real row counts (ten scale steps), fp32 residual stream, cold inputs
+            for key, model in (("config3_steps", "d30"), ("config5_steps", "d36-512")):
+                try:
+                    res[key] = steps_summary(generation_steps(plat.dev, model, "fp32", "rotating"))
+                except Exception as e:
+                    res[key] = {"error": repr(e)[:200]}
             res["cpu_baseline"] = cpu_baseline()
         if world > 1:
             res["omitted_at_n_gt_1"] = ["cpu_baseline", "other_kernels", "unfused_gpu"]   # N = 1 lines carry them

@@ -1,90 +1,91 @@
 #!/usr/bin/env python3
-"""The small-step regime of a VAR-d30 generation batch (tr/var.py:175: rows = 100 * pn^2, pn = 1, 2, 3, ...): what one
-quantizer / producer call costs when the tensor is tiny.  Three clocks per (op, rows):
-  eager_us   host loop over the Python wrapper (launch-bound: Python + ctypes + hipLaunchKernel), wall clock / call
-  graph_us   the same calls captured in ONE hipGraph and replayed: GPU time per call incl. the inter-kernel gaps
-  kernels    launches per call
-and the floor: an empty-range launch of the same library (rows = 1) replayed the same way.
-"eager_ctypes_us" is the same call through the Python + ctypes path of fpqvar_amd.ops (round 2's only binding); "eager_us" goes
-through quant_utils, i.e. the compiled binding fpqvar_amd._native where it covers the function.
-usage: bench_small_steps.py > profiles/r03_small_steps.json"""
+"""BASELINE configs 3 and 5 at the row counts they actually run (tr/var.py:175: ten scale steps, rows = 2 B pn^2): what the
+four quantizer calls of a W4A4 AdaLN block cost per step, and the time-weighted fraction of 8 TB/s over the ten steps.
+The measurement itself is bench.generation_steps (the bench line carries its summary as config3_steps / config5_steps);
+this tool writes the full record.
+
+  bench_small_steps.py --model d30|d36-512 --rows fp16|fp32 --mode rotating|resident [--eager] > profiles/r04_steps_<model>.json
+
+--eager adds the host-side cost of one call through the Python wrappers (compiled binding where it covers the function)
+and through ctypes: wall clock per call of a 200-call loop, launch-bound at small steps."""
+import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from fpqvar_amd import ops, quant_utils as qu, rotation as rot  # noqa: E402
-
-dev = torch.device("cuda:0")
-C, HID, B = 1920, 7680, 100
-PN = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
-g = torch.Generator(device=dev).manual_seed(0)
-N = 50
+import bench  # noqa: E402
 
 
-def graph_time(fn):
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        fn()
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, stream=s):
-            for _ in range(N):
-                fn()
-    torch.cuda.current_stream().wait_stream(s)
-    for _ in range(3):
-        gr.replay()
-    torch.cuda.synchronize()
-    best = 1e9
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        gr.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 1e3 / N)
-    return best
+def stamp():
+    """What was measured: the commit and the hash of the library that ran."""
+    import hashlib
+    from fpqvar_amd import _lib
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        head = ""
+    with open(_lib.LIB_PATH, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    return {"git_head": head or os.environ.get("FPQ_GIT_HEAD", "unknown (no .git on the GPU box: see FPQ_GIT_HEAD)"),
+            "libfpq_hip_sha256": sha}
 
 
-def eager_time(fn):
+def eager_us(fn, n=200):
     for _ in range(20):
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(200):
+    for _ in range(n):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 200 * 1e6
+    return (time.perf_counter() - t0) / n * 1e6
 
 
-res = {"note": "VAR-d30 256x256, B = 50 with CFG (100 conditioned rows per token); us per call", "steps": []}
-tiny = torch.randn(1, 128, device=dev, generator=g).half()
-res["launch_floor_graph_us"] = round(graph_time(lambda: qu.fp_quant_e2_per_group_cuda(tiny, 4, 128)), 2)
-res["launch_floor_eager_us"] = round(eager_time(lambda: qu.fp_quant_e2_per_group_cuda(tiny, 4, 128)), 2)
-res["launch_floor_eager_ctypes_us"] = round(eager_time(lambda: ops.quant_rows(tiny, "e2m1", 128)), 2)
-res["compiled_binding"] = getattr(qu, "_native", None) is not None
-scale = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
-shift = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
-smooth = torch.rand(C, device=dev, generator=g) + 0.5
-for pn in PN:
-    L = pn * pn
-    rows = B * L
-    x = torch.randn(B, L, C, device=dev, generator=g).half()
-    hid = torch.nn.functional.gelu(torch.randn(rows, HID, device=dev, generator=g), approximate="tanh").half()
-    ops_ = {
-        "act_quant_e2m1_g128 (proj input)": (lambda: qu.fp_quant_e2_per_group_cuda(x, 4, 128), 1,
-                                              lambda: ops.quant_rows(x, "e2m1", 128)),
-        "adaln_rotate_quant (mat_qkv / fc1 input)": (lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=smooth), 1, None),
-        "dual_fp4_g128 (fc2 input, default clip)": (lambda: qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(hid, 4, 128), 2,
-                                                     lambda: ops.quant_rows_dual(hid, "e1m2_neg", "e2m1_pos", 128, 1.0)),
-    }
-    step = {"pn": pn, "rows": rows}
-    for name, (fn, launches, slow) in ops_.items():
-        step[name] = {"eager_us": round(eager_time(fn), 2), "graph_us": round(graph_time(fn), 2), "kernels": launches}
-        if slow is not None:
-            step[name]["eager_ctypes_us"] = round(eager_time(slow), 2)
-    res["steps"].append(step)
-print(json.dumps(res, indent=1))
+def eager(dev, model, rows_dtype):
+    from fpqvar_amd import ops, quant_utils as qu, rotation as rot
+    m = bench.STEP_MODELS[model]
+    C, B = m["C"], m["B"]
+    g = torch.Generator(device=dev).manual_seed(0)
+    scale = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
+    shift = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
+    smooth = torch.rand(C, device=dev, generator=g) + 0.5
+    out = []
+    for pn in m["pn"]:
+        L = pn * pn
+        x = torch.randn(B, L, C, device=dev, generator=g)
+        x = x if rows_dtype == "fp32" else x.half()
+        a = torch.randn(B * L, C, device=dev, generator=g).half()
+        hid = torch.nn.functional.gelu(torch.randn(B * L, 4 * C, device=dev, generator=g), approximate="tanh").half()
+        out.append({"pn": pn, "rows": B * L,
+                    "adaln_eager_us": round(eager_us(lambda: rot.adaln_rotate_quant(x, scale, shift, "e2m1", smooth=smooth)), 2),
+                    "act_eager_us": round(eager_us(lambda: qu.fp_quant_e2_per_group_cuda(a, 4, 128)), 2),
+                    "act_eager_ctypes_us": round(eager_us(lambda: ops.quant_rows(a, "e2m1", 128)), 2),
+                    "dual_eager_us": round(eager_us(lambda: qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(hid, 4, 128)), 2),
+                    "dual_eager_ctypes_us": round(eager_us(lambda: ops.quant_rows_dual(hid, "e1m2_neg", "e2m1_pos", 128, 1.0)), 2)})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="d30", choices=sorted(bench.STEP_MODELS))
+    ap.add_argument("--rows", default="fp32", choices=("fp16", "fp32"))
+    ap.add_argument("--mode", default="rotating", choices=("rotating", "resident"))
+    ap.add_argument("--ops", default=None, help="comma-separated subset of adaln,act,dual")
+    ap.add_argument("--eager", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    res = dict(stamp())
+    res.update(bench.generation_steps(dev, a.model, a.rows, a.mode, only_ops=a.ops.split(",") if a.ops else None))
+    if a.eager:
+        res["eager"] = eager(dev, a.model, a.rows)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
