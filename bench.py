@@ -513,7 +513,7 @@ def generation_steps(dev, model="d30", rows_dtype="fp32", mode="rotating", repla
                                                flag.data_ptr(), sp), "fpq_quant_rows_dual")
             med, best, n_calls, k = graph_us(call, in_b, out_b, xin, xout)
             stp[name] = {"us": round(med, 2), "min_us": round(best, 2), "bytes": in_b + out_b,
-                         "frac_of_8TBps": round((in_b + out_b) / med / 1e6 / HBM_PEAK_GBS, 3), "calls_per_graph": n_calls,
+                         "frac_of_8TBps": round((in_b + out_b) / med / 1e3 / HBM_PEAK_GBS, 3), "calls_per_graph": n_calls,
                          "slices": k}
         del xin
         torch.cuda.empty_cache()
@@ -524,7 +524,7 @@ def generation_steps(dev, model="d30", rows_dtype="fp32", mode="rotating", repla
     for n in have:
         t = sum(s[n]["us"] for s in steps)
         b = sum(s[n]["bytes"] for s in steps)
-        by_kernel[n] = {"sum_us": round(t, 1), "bytes": b, "frac_of_8TBps": round(b / t / 1e6 / HBM_PEAK_GBS, 3)}
+        by_kernel[n] = {"sum_us": round(t, 1), "bytes": b, "frac_of_8TBps": round(b / t / 1e3 / HBM_PEAK_GBS, 3)}
         tot_t += weights[n] * t
         tot_b += weights[n] * b
     for s in steps:
@@ -532,14 +532,14 @@ def generation_steps(dev, model="d30", rows_dtype="fp32", mode="rotating", repla
             t = sum(weights[n] * s[n]["us"] for n in have)
             b = sum(weights[n] * s[n]["bytes"] for n in have)
             s["block_us"] = round(t, 2)
-            s["frac_of_8TBps"] = round(b / t / 1e6 / HBM_PEAK_GBS, 3)
+            s["frac_of_8TBps"] = round(b / t / 1e3 / HBM_PEAK_GBS, 3)
     return {"model": model, "what": m["what"], "rows_dtype_of_the_residual_stream": rows_dtype, "mode": mode,
             "clock": "hipGraph replay, HIP events around each replay, median over %d replays per (step, kernel)" % replays,
             "per_block_and_step": "2 x adaLN producer (values out) + 1 x E2M1 g=128 (proj input) + 1 x dual E1M2-/E2M1+ g=128 "
                                   "(fc2 input, default clipping strength: two launches)",
             "steps": steps, "by_kernel": by_kernel,
             "block_us_over_the_ten_steps": round(tot_t, 1), "bytes_per_block": tot_b,
-            "time_weighted_frac_of_8TBps": round(tot_b / tot_t / 1e6 / HBM_PEAK_GBS, 4) if tot_t else None}
+            "time_weighted_frac_of_8TBps": round(tot_b / tot_t / 1e3 / HBM_PEAK_GBS, 4) if tot_t else None}
 
 
 def steps_summary(full):

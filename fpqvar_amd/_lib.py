@@ -37,6 +37,7 @@ class GemmEpilogue(_c.Structure):
 _SIGS = {
     "fpq_version": (_c.c_int, []),
     "fpq_strerror": (_c.c_char_p, [_c.c_int]),
+    "fpq_build_tag": (_c.c_char_p, []),
     "fpq_table_values": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_float)]),
     "fpq_quant_nearest": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
                                       _c.c_void_p]),
@@ -132,6 +133,32 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def use_variant(path: str, expect_tag: Optional[str] = None) -> ctypes.CDLL:
+    """Point the ctypes layer at another build of the library (tools/build_variant.sh) - for the A/B and profiling tools
+    only.  The compiled binding fpqvar_amd/_native is hard-linked to the stock libfpq_hip.so, so a tool that wants a
+    variant measured must also keep the wrappers off that binding: set FPQ_NO_NATIVE=1 BEFORE importing fpqvar_amd
+    (quant_utils, rotation and quant_cuda read it at import).  This function refuses to go on otherwise, and returns the
+    library's build tag so that the tool can print which build it timed."""
+    global _lib
+    if os.environ.get("FPQ_NO_NATIVE") != "1":
+        raise RuntimeError("use_variant: FPQ_NO_NATIVE=1 must be set before fpqvar_amd is imported - the compiled binding "
+                           "would otherwise keep calling the stock library")
+    l = ctypes.CDLL(os.path.abspath(path))
+    for name, (res, args) in _SIGS.items():
+        if hasattr(l, name):
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+    tag = l.fpq_build_tag().decode() if hasattr(l, "fpq_build_tag") else "untagged"
+    if expect_tag is not None and tag != expect_tag:
+        raise RuntimeError(f"use_variant: {path} carries build tag {tag!r}, expected {expect_tag!r}")
+    _lib = l
+    return l
+
+
+def build_tag() -> str:
+    return lib().fpq_build_tag().decode()
 
 
 def check(status: int, what: str) -> None:

@@ -517,22 +517,25 @@ __global__ __launch_bounds__(kBlock) void nearest_builtin_kernel(const float* __
 
 // ---------------------------------------------------------------------------------
 // "any NaN in the tensor => the whole result is zero" (the reference's global clamp with a
-// NaN bound, tr/quant_utils.py:421-422): second launch, a handful of workgroups that exit at once when the flag is
-// clear.  scratch[0] = the flag the quantizer raised, scratch[1] = a ticket counter: every workgroup takes a ticket
-// AFTER it has read the flag, the one that draws the last ticket clears both words - the scratch is zero again when
-// the launch ends (no memset per call, and a captured graph can be replayed).
+// NaN bound, tr/quant_utils.py:421-422): second launch, a handful of workgroups that read ONE word and exit when the
+// flag is clear - no atomic, no barrier on that path (round 3 drew a ticket per workgroup on every call: 64 device-scope
+// atomics on one address, ~11 ns each and serialised, tools/probe/ticket_cost.hip - 3 us of the 7 us a 100-row call took).
+// Only when the flag is up: scratch[0] = the flag the quantizer raised, scratch[1] = a ticket counter; every workgroup
+// zero-fills its share and takes a ticket AFTER it has read the flag, the one that draws the last ticket clears both
+// words - the scratch is zero again when the launch ends (no memset per call, and a captured graph can be replayed).
+// (One launch instead of two would need every workgroup of the quantizer to release its stores and count itself:
+// profiles/r04_ticket_cost.txt - the chip's eight L2s are not coherent with each other, the release is an L2 write-back
+// per workgroup, 4 - 40 times the kernel's own time.)
 // ---------------------------------------------------------------------------------
 constexpr int kFixupBlocks = 64;
 __global__ __launch_bounds__(kBlock) void zero_if_flag_kernel(uint8_t* __restrict__ out, int64_t n_bytes, uint32_t* scratch) {
-  __shared__ uint32_t f;
-  if (threadIdx.x == 0) f = __hip_atomic_load(scratch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (f != 0u) {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t n16 = ((uintptr_t)out & 15) == 0 ? n_bytes / 16 : 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) ((u32x4*)out)[i] = u32x4{0, 0, 0, 0};
-    for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_bytes; i += stride) out[i] = 0;
-  }
+  // the quantizer's atomicOr is visible to a plain (scalar) load here: kernel boundary; uniform branch
+  if (__hip_atomic_load(scratch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t n16 = ((uintptr_t)out & 15) == 0 ? n_bytes / 16 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) ((u32x4*)out)[i] = u32x4{0, 0, 0, 0};
+  for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_bytes; i += stride) out[i] = 0;
+  __syncthreads();   // every wavefront of this workgroup has read the flag
   if (threadIdx.x == 0 && atomicAdd(scratch + 1, 1u) == gridDim.x - 1) {   // every workgroup has read the flag by now
     __hip_atomic_store(scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(scratch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1414,6 +1417,11 @@ int launch_negrev(const void* x, void* out, int64_t rows, int64_t cols, const Fm
 extern "C" {
 
 int fpq_version(void) { return FPQ_VERSION; }
+
+#ifndef FPQ_BUILD_TAG
+#define FPQ_BUILD_TAG "stock"
+#endif
+const char* fpq_build_tag(void) { return FPQ_BUILD_TAG; }
 
 const char* fpq_strerror(int status) {
   switch (status) {

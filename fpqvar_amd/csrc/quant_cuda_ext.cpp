@@ -244,11 +244,172 @@ at::Tensor adaln_rotate_quant(const at::Tensor& x, const at::Tensor& scale, cons
   return out;
 }
 
+// ---- the "Q" path: the same producers emitting what the matrix-core GEMMs consume, the KV-cache step and the FP4 GEMM
+// (rotation.py / gemm.py / ops.py hold the general forms and dispatch here for the usual arguments) ----
+struct ProducerArgs {
+  int64_t b, l, c;
+  const float* smooth;
+};
+
+ProducerArgs producer_checks(const char* what, const at::Tensor& x, const at::Tensor* scale, const at::Tensor* shift,
+                             const c10::optional<at::Tensor>& smooth, int64_t max_c) {
+  require_gpu(x, what);
+  TORCH_CHECK(x.scalar_type() == at::kHalf || x.scalar_type() == at::kFloat, what, ": x must be float16 or float32, got ", x.scalar_type());
+  TORCH_CHECK(x.is_contiguous(), what, " (native): contiguous x");
+  ProducerArgs a{1, 1, 0, nullptr};
+  if (scale) {
+    TORCH_CHECK(x.dim() == 3, what, ": x must be [B, L, C]");
+    a.b = x.size(0), a.l = x.size(1), a.c = x.size(2);
+    TORCH_CHECK(scale->scalar_type() == shift->scalar_type() && (scale->scalar_type() == at::kHalf || scale->scalar_type() == at::kFloat),
+                what, ": scale and shift must both be float16 or both float32");
+    TORCH_CHECK(scale->is_contiguous() && shift->is_contiguous() && scale->numel() == a.b * a.c && shift->numel() == a.b * a.c &&
+                scale->device() == x.device() && shift->device() == x.device(), what, " (native): [B, C] modulation rows on x's device");
+  } else {
+    TORCH_CHECK(x.dim() >= 1, what, ": x must have a last dimension");
+    a.c = x.size(-1);
+    a.l = a.c ? x.numel() / a.c : 0;
+  }
+  TORCH_CHECK(a.c % 128 == 0 && a.c <= max_c, what, ": C must be a multiple of 128 and at most ", max_c);
+  if (smooth.has_value()) {
+    TORCH_CHECK(smooth->scalar_type() == at::kFloat && smooth->is_contiguous() && smooth->numel() == a.c && smooth->device() == x.device(),
+                what, " (native): smooth must be a contiguous float32 [C] tensor on x's device");
+    a.smooth = (const float*)smooth->data_ptr();
+  }
+  return a;
+}
+
+std::tuple<at::Tensor, at::Tensor> rotate_quant_mx(const at::Tensor& x, const std::array<uint32_t, 4>& sign_mask,
+                                                   const c10::optional<at::Tensor>& smooth) {
+  const ProducerArgs a = producer_checks("rotate_quant_mx", x, nullptr, nullptr, smooth, 1 << 30);
+  const int64_t rows = a.l;
+  at::Tensor codes = at::empty({rows, a.c / 2}, x.options().dtype(at::kByte));
+  at::Tensor scales = at::empty({rows, a.c / 128}, x.options().dtype(at::kHalf));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  check(fpq_rotate_quant_rows_codes_mx(x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c,
+                                       dtype_id(x.scalar_type(), "rotate_quant_mx"), a.smooth, sign_mask.data(), current_stream(x)),
+        "fpq_rotate_quant_rows_codes_mx");
+  return {codes, scales};
+}
+
+std::tuple<at::Tensor, at::Tensor> adaln_rotate_quant_mx(const at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift,
+                                                         const std::array<uint32_t, 4>& sign_mask,
+                                                         const c10::optional<at::Tensor>& smooth, double eps) {
+  const ProducerArgs a = producer_checks("adaln_rotate_quant_mx", x, &scale, &shift, smooth, 4096);
+  const int64_t rows = a.b * a.l;
+  at::Tensor codes = at::empty({rows, a.c / 2}, x.options().dtype(at::kByte));
+  at::Tensor scales = at::empty({rows, a.c / 128}, x.options().dtype(at::kHalf));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  check(fpq_adaln_rotate_quant_rows_codes_mx(x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c,
+                                             dtype_id(x.scalar_type(), "adaln_rotate_quant_mx"), scale.data_ptr(), shift.data_ptr(),
+                                             dtype_id(scale.scalar_type(), "adaln_rotate_quant_mx"), a.l, (float)eps, a.smooth,
+                                             sign_mask.data(), current_stream(x)), "fpq_adaln_rotate_quant_rows_codes_mx");
+  return {codes, scales};
+}
+
+// per-token configurations (W6A6): values, or the operands of the row-scaled GEMMs - code_bits 8: E4M3 bytes, 6: dense E2M3
+at::Tensor adaln_rotate_quant_token(const at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, int64_t table_id,
+                                    const std::array<uint32_t, 4>& sign_mask, const c10::optional<at::Tensor>& smooth, double eps) {
+  const ProducerArgs a = producer_checks("adaln_rotate_quant_token", x, &scale, &shift, smooth, 2560);
+  at::Tensor out = at::empty(x.sizes(), x.options().dtype(at::kHalf));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  check(fpq_adaln_rotate_quant_token_rows(x.data_ptr(), out.data_ptr(), nullptr, nullptr, nullptr, a.b * a.l, a.c,
+                                          dtype_id(x.scalar_type(), "adaln_rotate_quant_token"), scale.data_ptr(), shift.data_ptr(),
+                                          dtype_id(scale.scalar_type(), "adaln_rotate_quant_token"), a.l, (float)eps, a.smooth,
+                                          sign_mask.data(), (int)table_id, current_stream(x)), "fpq_adaln_rotate_quant_token_rows");
+  return out;
+}
+
+std::tuple<at::Tensor, at::Tensor> adaln_rotate_quant_token_codes(const at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift,
+                                                                  int64_t table_id, int64_t code_bits,
+                                                                  const std::array<uint32_t, 4>& sign_mask,
+                                                                  const c10::optional<at::Tensor>& smooth, double eps) {
+  const ProducerArgs a = producer_checks("adaln_rotate_quant_token_codes", x, &scale, &shift, smooth, 2560);
+  TORCH_CHECK(code_bits == 8 || (code_bits == 6 && table_id == FPQ_E2M3), "adaln_rotate_quant_token_codes: E4M3 bytes (8) or dense E2M3 codes (6)");
+  const int64_t rows = a.b * a.l;
+  at::Tensor codes = at::empty({rows, code_bits == 8 ? a.c : a.c * 3 / 4}, x.options().dtype(at::kByte));
+  at::Tensor scales = at::empty({rows}, x.options().dtype(at::kHalf));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+  const auto fn = code_bits == 8 ? fpq_adaln_rotate_quant_token_rows_codes_fp8 : fpq_adaln_rotate_quant_token_rows_codes_fp6;
+  check(fn(x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c, dtype_id(x.scalar_type(), "adaln_rotate_quant_token_codes"),
+           scale.data_ptr(), shift.data_ptr(), dtype_id(scale.scalar_type(), "adaln_rotate_quant_token_codes"), a.l, (float)eps, a.smooth,
+           sign_mask.data(), (int)table_id, current_stream(x)), "fpq_adaln_rotate_quant_token_rows_codes");
+  return {codes, scales};
+}
+
+// one step of the incrementally kept KV cache (ops.kv_cache_step holds the argument checks' prose)
+void kv_cache_step(const at::Tensor& cache, int64_t quant_start, int64_t quant_stop, const at::Tensor& k, const at::Tensor& v,
+                   int64_t new_start, int64_t group, int64_t table_id) {
+  require_gpu(cache, "kv_cache_step");
+  TORCH_CHECK(cache.scalar_type() == at::kHalf && k.scalar_type() == at::kHalf && v.scalar_type() == at::kHalf,
+              "kv_cache_step: cache, k and v must be float16");
+  TORCH_CHECK(cache.dim() == 5 && cache.size(0) == 2 && cache.is_contiguous(), "kv_cache_step: cache must be a contiguous [2, B, max_len, H, c] tensor");
+  const int64_t B = cache.size(1), max_len = cache.size(2), H = cache.size(3), c = cache.size(4);
+  TORCH_CHECK(k.sizes() == v.sizes() && k.dim() == 4 && k.size(0) == B && k.size(2) == H && k.size(3) == c && k.device() == cache.device() &&
+              v.device() == cache.device(), "kv_cache_step: k / v must be [B, n, H, c] on the cache's device");
+  const int64_t n = k.size(1);
+  if (n) {
+    TORCH_CHECK(k.stride(3) == 1 && k.stride(2) == c && v.stride(3) == 1 && v.stride(2) == c, "kv_cache_step: the (H, c) rows of k / v must be contiguous");
+    TORCH_CHECK(k.strides() == v.strides(), "kv_cache_step: k and v must share their strides");
+  }
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(cache.device());
+  check(fpq_kv_cache_step(cache.data_ptr(), B, max_len, H * c, quant_start, quant_stop, k.data_ptr(), v.data_ptr(), n ? k.stride(0) : 0,
+                          n ? k.stride(1) : 0, new_start, n, (int)group, (int)table_id, current_stream(cache)), "fpq_kv_cache_step");
+}
+
+void check_operand(const char* what, const at::Tensor& codes, const at::Tensor& scales, int64_t rows, int64_t row_bytes, int64_t n_scales,
+                   const at::Device& dev) {
+  TORCH_CHECK(codes.scalar_type() == at::kByte && codes.is_contiguous() && codes.device() == dev, what, ": codes must be a contiguous uint8 tensor on ", dev);
+  TORCH_CHECK(codes.numel() == rows * row_bytes, what, ": codes hold ", codes.numel(), " bytes, expected ", rows, " x ", row_bytes);
+  TORCH_CHECK((scales.scalar_type() == at::kHalf || scales.scalar_type() == at::kFloat) && scales.is_contiguous() && scales.device() == dev,
+              what, ": scales must be a contiguous float16 / float32 tensor on ", dev);
+  TORCH_CHECK(scales.numel() == n_scales, what, ": ", scales.numel(), " scales, expected ", n_scales);
+}
+
+// fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores, with the AdaLN block's gated residual in
+// the epilogue when given (tr/quant_utils.py:767, tr/basic_var.py:264): gemm.linear_fp4
+at::Tensor linear_fp4(const at::Tensor& a_codes, const at::Tensor& a_scales, const at::Tensor& w_codes, const at::Tensor& w_scales,
+                      const c10::optional<at::Tensor>& bias, const c10::optional<at::Tensor>& gate, const c10::optional<at::Tensor>& residual) {
+  require_gpu(a_codes, "linear_fp4");
+  TORCH_CHECK(a_codes.dim() == 2 && w_codes.dim() == 2, "linear_fp4: codes must be [rows, K / 2]");
+  const int64_t tokens = a_codes.size(0), outs = w_codes.size(0), k = a_codes.size(1) * 2;
+  TORCH_CHECK(w_codes.size(1) * 2 == k && a_scales.scalar_type() == at::kHalf && k % 128 == 0, "linear_fp4: operand shapes / activation scale dtype mismatch");
+  const at::Device dev = a_codes.device();
+  check_operand("linear_fp4(activation)", a_codes, a_scales, tokens, k / 2, tokens * (k / 128), dev);
+  check_operand("linear_fp4(weight)", w_codes, w_scales, outs, k / 2, outs * (k / 128), dev);
+  fpq_gemm_epilogue_t ep{nullptr, nullptr, 1};
+  at::Tensor g, r, b;
+  if (gate.has_value()) {
+    g = gate->reshape({-1, outs});
+    TORCH_CHECK(g.scalar_type() == at::kHalf && g.size(0) > 0 && tokens % g.size(0) == 0 && g.device() == dev,
+                "linear_fp4: gate must be float16 [B, outs] with tokens % B == 0");
+    g = g.contiguous();
+    ep.gate = g.data_ptr();
+    ep.rows_per_gate = std::max<int64_t>(tokens / g.size(0), 1);
+  }
+  if (residual.has_value()) {
+    r = residual->reshape({-1, outs});
+    TORCH_CHECK(r.scalar_type() == at::kHalf && r.size(0) == tokens && r.device() == dev, "linear_fp4: residual must be float16 with ", tokens, " rows of ", outs);
+    r = r.contiguous();
+    ep.residual = r.data_ptr();
+  }
+  if (bias.has_value()) {
+    TORCH_CHECK(bias->numel() == outs && bias->device() == dev, "linear_fp4: bias must hold one value per output on the operands' device");
+    b = bias->detach().to(at::kHalf).reshape({-1}).contiguous();
+  }
+  at::Tensor out = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
+  check(fpq_gemm_fp4_mx_ex((const uint8_t*)a_codes.data_ptr(), a_scales.data_ptr(), (const uint8_t*)w_codes.data_ptr(), w_scales.data_ptr(),
+                           dtype_id(w_scales.scalar_type(), "linear_fp4"), b.defined() ? b.data_ptr() : nullptr, out.data_ptr(), tokens, outs, k,
+                           (gate.has_value() || residual.has_value()) ? &ep : nullptr, current_stream(a_codes)), "fpq_gemm_fp4_mx_ex");
+  return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled binding of libfpq_hip.so for the reference's quant_cuda / quant_utils boundary";
   m.def("fpq_version", [] { return fpq_version(); });
+  m.def("fpq_build_tag", [] { return std::string(fpq_build_tag()); });
   m.def("quant", &quant, py::arg("x"), py::arg("y"));
   m.def("quant_rows", &quant_rows, py::arg("x"), py::arg("table_id"), py::arg("cols"), py::arg("out_dtype") = py::none());
   m.def("quant_rows_dual", &quant_rows_dual, py::arg("x"), py::arg("neg_table_id"), py::arg("pos_table_id"), py::arg("cols"),
@@ -267,6 +428,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rotate_quant", &rotate_quant, py::arg("x"), py::arg("table_id"), py::arg("sign_mask"), py::arg("smooth") = py::none());
   m.def("adaln_rotate_quant", &adaln_rotate_quant, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("table_id"),
         py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
+  m.def("rotate_quant_mx", &rotate_quant_mx, py::arg("x"), py::arg("sign_mask"), py::arg("smooth") = py::none());
+  m.def("adaln_rotate_quant_mx", &adaln_rotate_quant_mx, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("sign_mask"),
+        py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
+  m.def("adaln_rotate_quant_token", &adaln_rotate_quant_token, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("table_id"),
+        py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
+  m.def("adaln_rotate_quant_token_codes", &adaln_rotate_quant_token_codes, py::arg("x"), py::arg("scale"), py::arg("shift"),
+        py::arg("table_id"), py::arg("code_bits"), py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
+  m.def("kv_cache_step", &kv_cache_step, py::arg("cache"), py::arg("quant_start"), py::arg("quant_stop"), py::arg("k"), py::arg("v"),
+        py::arg("new_start"), py::arg("group"), py::arg("table_id"));
+  m.def("linear_fp4", &linear_fp4, py::arg("a_codes"), py::arg("a_scales"), py::arg("w_codes"), py::arg("w_scales"),
+        py::arg("bias") = py::none(), py::arg("gate") = py::none(), py::arg("residual") = py::none());
   m.def("fp6_quant_per_token_contig", &fp6_quant_per_token_contig, py::arg("x"), py::arg("n_bits"), py::arg("table_id"));
   m.def("fp6_quant_int_neg_e2m3_pos_per_token_contig", &fp6_quant_int_neg_e2m3_pos_per_token_contig, py::arg("x"), py::arg("n_bits"));
 }

@@ -33,7 +33,7 @@ def quantizer(fmt: str) -> Callable[[torch.Tensor], torch.Tensor]:
 
 @torch.no_grad()
 def search_layer(xs: Sequence[torch.Tensor], w: torch.Tensor, formats: Sequence[str] = FP6_FORMATS,
-                 quant: Callable[[str], Callable] = quantizer, batched: bool = True
+                 quant: Callable[[str], Callable] = quantizer, batched: Optional[bool] = None
                  ) -> Tuple[str, str, Dict[Tuple[str, str], float]]:
     """(best weight format, best activation format, {(w_fmt, a_fmt): summed MSE}).
 
@@ -43,8 +43,17 @@ def search_layer(xs: Sequence[torch.Tensor], w: torch.Tensor, formats: Sequence[
     by row (per token) or group by group, so the samples are concatenated along their rows - ONE quantizer launch per
     activation format for the whole calibration set (and one per weight format), ONE GEMM per pair, the per-sample
     means as a weighted row reduction, all `len(formats)^2` losses kept on the device and read back with ONE copy.
-    batched=False is the sample-by-sample loop (same quantizers), kept for comparison and for tests."""
+    batched=False is the sample-by-sample loop (same quantizers), kept for comparison and for tests.
+
+    Precondition of the batched form: the quantizer must be ROW-LOCAL (per token, or per group inside a row) - a
+    per-tensor quantizer sees a different tensor once the samples are concatenated.  The built-in `quantizer` table is;
+    an injected `quant` is not assumed to be: batched=None (default) means "batched for the built-in quantizers, the
+    loop for anything injected", and a caller who knows his quantizer to be row-local passes batched=True.
+    Both forms quantize x in ITS dtype (the reference calls the quantizer on the dumped activation as it is), cast to
+    the weight's dtype for the GEMM, and subtract in float32."""
     nf = len(formats)
+    if batched is None:
+        batched = quant is quantizer
     if not batched:
         losses: Dict[Tuple[str, str], float] = {}
         refs = [x.to(w.dtype) @ w.t() for x in xs]
@@ -60,17 +69,17 @@ def search_layer(xs: Sequence[torch.Tensor], w: torch.Tensor, formats: Sequence[
     else:
         c = w.shape[-1]
         rows = [x.numel() // c for x in xs]
-        x_all = torch.cat([x.reshape(-1, c) for x in xs]).to(w.dtype)                 # [sum rows, C]
+        x_all = torch.cat([x.reshape(-1, c) for x in xs])                             # [sum rows, C], the samples' dtype
         # sum_j mean_j((y - y_q)^2) = sum over rows of (row's squared error) / (rows_j * out): one weight per row
         w_row = torch.repeat_interleave(torch.tensor([1.0 / (r * w.shape[0]) for r in rows], dtype=torch.float32, device=w.device),
                                         torch.tensor(rows, device=w.device))
-        ref = x_all @ w.t()
+        ref = (x_all.to(w.dtype) @ w.t()).float()
         xq = {af: quant(af)(x_all).to(w.dtype) for af in formats}                     # one launch per activation format
         out = torch.empty(nf, nf, dtype=torch.float32, device=w.device)
         for i, wf in enumerate(formats):
             wq = quant(wf)(w).to(w.dtype)
             for j, af in enumerate(formats):
-                d = (ref - xq[af] @ wq.t()).float()
+                d = ref - (xq[af] @ wq.t()).float()
                 out[i, j] = torch.dot((d * d).sum(dim=1), w_row)
         host = out.cpu()                                                               # the layer's one synchronisation
         losses = {(wf, af): float(host[i, j]) for i, wf in enumerate(formats) for j, af in enumerate(formats)}

@@ -14,6 +14,13 @@ import ctypes
 
 from ._lib import GemmEpilogue, check, dtype_id, lib, require_gpu, stream_ptr, device_guard
 
+try:   # the compiled binding (csrc/quant_cuda_ext.cpp)
+    from . import _native
+except ImportError:   # pragma: no cover - build() always produces it
+    _native = None
+if __import__("os").environ.get("FPQ_NO_NATIVE") == "1":   # the A/B tools time variant builds of the library through ctypes (_lib.use_variant)
+    _native = None
+
 E2M1_LEVELS = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
 
 
@@ -105,6 +112,8 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores; with gate / residual the
     AdaLN block's `residual + y.mul(gate)` (tr/basic_var.py:264) is applied in the epilogue, bit-identical to the two
     torch ops on the plain result."""
+    if _native is not None:   # same checks, same C call (fpq_gemm_fp4_mx_ex)
+        return _native.linear_fp4(a_codes, a_scales, w_codes, w_scales, bias, gate, residual)
     require_gpu(a_codes, "linear_fp4")
     if a_codes.dim() != 2 or w_codes.dim() != 2:
         raise RuntimeError("linear_fp4: codes must be [rows, K / 2]")

@@ -19,6 +19,8 @@ try:   # the compiled binding (csrc/quant_cuda_ext.cpp, built by __graft_entry__
     from . import _native   # third of the host time per call; absent -> the ctypes path of ops.py (tests run both)
 except ImportError:         # pragma: no cover - build() always produces it
     _native = None
+if __import__("os").environ.get("FPQ_NO_NATIVE") == "1":   # the A/B tools time variant builds of the library through ctypes (_lib.use_variant)
+    _native = None
 
 # value tables, exactly as tr/quant_utils.py:233-235,458-500 spells them (host tensors)
 fp4_e3m0_grid = torch.tensor([-16.0, -8.0, -4.0, -2.0, -1.0, -0.5, -0.25, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0])

@@ -215,6 +215,8 @@ try:   # the compiled binding (csrc/quant_cuda_ext.cpp) for the hot, plain calls
     from . import _native
 except ImportError:   # pragma: no cover - build() always produces it
     _native = None
+if __import__("os").environ.get("FPQ_NO_NATIVE") == "1":   # the A/B tools time variant builds of the library through ctypes (_lib.use_variant)
+    _native = None
 
 
 def _native_ok(x, d, smooth, c) -> bool:
@@ -298,6 +300,8 @@ def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: O
         raise RuntimeError("rotate_quant_mx: x must be float16/float32 with a last dimension that is a multiple of 128")
     c = x.shape[-1]
     rows = x.numel() // c
+    if _native_ok(x, d, smooth, c):
+        return _native.rotate_quant_mx(x, _default_mask_tuple(), smooth)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
@@ -323,6 +327,8 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
         raise RuntimeError("adaln_rotate_quant_mx: scale and shift must both be float16 or both float32")
     sc = _mod_rows(scale, bsz, c)
     sh = _mod_rows(shift, bsz, c)
+    if sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c):
+        return _native.adaln_rotate_quant_mx(x, sc, sh, _default_mask_tuple(), smooth, float(eps))
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
@@ -353,6 +359,15 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
         raise RuntimeError("adaln_rotate_quant_token: scale and shift must both be float16 or both float32")
     sc = _mod_rows(scale, bsz, c)
     sh = _mod_rows(shift, bsz, c)
+    if emit not in ("values", "fp8", "fp6"):
+        raise RuntimeError(f"adaln_rotate_quant_token: unknown emit {emit!r}")
+    if emit == "fp6" and table != "e2m3":
+        raise RuntimeError("adaln_rotate_quant_token: emit='fp6' is the E2M3 operand format")
+    if sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c):
+        if emit == "values":
+            return _native.adaln_rotate_quant_token(x, sc, sh, TABLE_IDS[table], _default_mask_tuple(), smooth, float(eps))
+        return _native.adaln_rotate_quant_token_codes(x, sc, sh, TABLE_IDS[table], 8 if emit == "fp8" else 6, _default_mask_tuple(),
+                                                      smooth, float(eps))
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)

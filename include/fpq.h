@@ -22,8 +22,9 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 122 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
-                           0.1.3: + fpq_quant_rows_codes_segments, fpq_dequant_rows_codes_segments (round 3) */
+#define FPQ_VERSION 123 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
+                           0.1.3: + fpq_quant_rows_codes_segments, fpq_dequant_rows_codes_segments (round 3);
+                           123: + fpq_build_tag (round 4) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -58,6 +59,9 @@ enum fpq_table {
 
 int fpq_version(void);
 const char* fpq_strerror(int status);
+/* Which build this is: "stock" for the shipped library, the name given to tools/build_variant.sh for a diagnostic
+ * build (-DFPQ_BUILD_TAG).  The A/B tools assert on it so that a timing is never attributed to the wrong library. */
+const char* fpq_build_tag(void);
 
 /* Host-side copy of a built-in table exactly as the reference spells it
  * (ascending, duplicate zeros kept).  Returns the entry count, or FPQ_ERR_TABLE.

@@ -8,6 +8,13 @@ exports exactly one function (quant/quant.cpp:27-29):
 This module keeps that import name and signature and forwards to the gfx950
 kernel behind the C ABI (``fpq_quant_nearest`` in include/fpq.h).  With the repo
 root on ``sys.path`` the reference's own ``import quant_cuda`` resolves here.
+
+Additive (BASELINE.json's "the same quant_cuda.fp_quant_* entry points"): the module also
+carries the fused replacements of the quant_utils.py bodies under the reference's function names -
+``quant_cuda.fp_quant_e2_per_group_cuda(x, 4, 128)`` is ONE launch where tr/quant_utils.py:313-330 is ~11 torch ops
+around ``quant`` - so a caller that only has this module (tr/basic_var.py:33,50-87 holds private copies of two of the
+functions) can bind them from here.  They are the very objects fpqvar_amd.quant_utils exports (the compiled binding's
+functions where it covers them).
 """
 import torch
 
@@ -16,6 +23,8 @@ from fpqvar_amd import ops as _ops
 try:   # the compiled binding (fpqvar_amd/csrc/quant_cuda_ext.cpp): what the reference's pybind module is to its kernel
     from fpqvar_amd import _native
 except ImportError:   # pragma: no cover - __graft_entry__.build() always produces it
+    _native = None
+if __import__("os").environ.get("FPQ_NO_NATIVE") == "1":   # the A/B tools time variant builds of the library through ctypes (_lib.use_variant)
     _native = None
 
 
@@ -30,3 +39,22 @@ def _quant_ctypes(x: torch.Tensor, y: torch.Tensor):
 
 
 quant = _quant_ctypes if _native is None else _native.quant   # same C entry point (fpq_quant_nearest) either way
+
+
+# ---- the reference's function names on this module (one launch each; the same objects as fpqvar_amd.quant_utils') ----
+from fpqvar_amd import quant_utils as _qu   # noqa: E402
+
+FP_QUANT_NAMES = (
+    "fp_quant_e3_per_group_cuda", "fp_quant_e2_per_group_cuda", "fp_quant_e1_per_group_cuda",         # tr/quant_utils.py:265-282,313-330,361-378
+    "fp_quant_e1m2_neg_e2m1_pos_per_group_cuda",                                                       # :415-452
+    "fp6_quant_e2m3_per_token_cuda", "fp6_quant_e3m2_per_token_cuda",                                  # :503-534
+    "fp6_quant_e2m3_per_group_cuda", "fp6_quant_e3m2_per_group_cuda",                                  # :537-574
+    "fp6_quant_int_neg_e2m3_pos_per_group_cuda", "fp6_quant_int_neg_e2m3_pos_per_token_cuda",          # :577-646
+    "fp4_afpq_per_group_cuda", "fp_neg_reverse_quant_per_group_cuda",                                  # models_fp_quant/quant_utils.py:454-535
+    "fp_quant_e3_per_token", "fp_quant_e2_per_token", "fp_quant_e1_per_token",                         # the pure-torch semantics, :237-358
+    "fp_quant_e3_per_group", "fp_quant_e2_per_group", "fp_quant_e1_per_group",
+    "fp_quant_e1m2_neg_e2m1_pos_per_group", "fp_quant_e2_per_tensor", "quantize_to_nearest_grid",
+)
+for _n in FP_QUANT_NAMES:
+    globals()[_n] = getattr(_qu, _n)
+del _n

@@ -422,3 +422,88 @@ def test_fast32_long_rows_vs_oracle(dev, cols, out_dtype):
         got = ops.quant_rows(x.to(dev), table, cols, out_dtype)
         assert_bits_equal(got, want, f"rows32 {table} cols={cols} -> {out_dtype}")
     assert_bits_equal(ops.quant_rows(x[:1].to(dev), "e2m3", cols, out_dtype), orc.per_token_kernel_sem(x[:1], "e2m3", out_dtype), "one row")
+
+
+# ---- BASELINE config 4, the format search at its real size (search/search_fp6_format.py:576-608, search_fp4_format.py:782-821) ----
+def _config4_search_layer(dev, block=0, n=100):
+    """One d30 mat_qkv layer and its calibration dump: w [5760 x 1920], 100 samples x_j [2, pn^2, 1920] over the ten scale
+    steps (models/basic_var.py:55-61 writes one tensor per (label pair, step)), 13600 rows in all; heavy-tailed like
+    pre-quantization activations."""
+    g = torch.Generator(device=dev).manual_seed(400 + block)
+    pns = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
+    xs = []
+    for j in range(n):
+        shape = (2, pns[j % 10] ** 2, 1920)
+        xs.append((torch.randn(shape, device=dev, generator=g) * torch.exp(0.5 * torch.randn(shape, device=dev, generator=g))).half())
+    w = (torch.randn(5760, 1920, device=dev, generator=g) * 0.02).half()
+    return xs, w
+
+
+def test_config4_format_search_d30_layer(dev, qu):
+    from fpqvar_amd import format_search as fs
+    xs, w = _config4_search_layer(dev)
+    assert sum(x.numel() // 1920 for x in xs) == 13600
+    for formats in (fs.FP6_FORMATS, fs.FP4_FORMATS):
+        wf, af, lb = fs.search_layer(xs, w, formats)                      # batched: one quantizer launch per format
+        wl, al, ll = fs.search_layer(xs, w, formats, batched=False)       # the reference's sample-by-sample order
+        assert set(lb) == set(ll) and len(lb) == len(formats) ** 2
+        for key in ll:
+            assert abs(lb[key] - ll[key]) <= 2e-3 * ll[key], (key, lb[key], ll[key])
+        assert (wf, af) == (wl, al)
+        assert (wf, af) == min(ll, key=ll.get)
+    # what the losses are made of: the quantized operands of two samples and of a slice of the weight, against the oracle
+    tab6, tab4 = {"fp6_e2m3": "e2m3", "fp6_e3m2": "e3m2"}, {"fp_e1": "e1m2", "fp_e2": "e2m1", "fp_e3": "e3m0"}
+    for j in (3, 77):
+        xc = xs[j].cpu()
+        for f, t in tab6.items():
+            assert_bits_equal(fs.quantizer(f)(xs[j]), orc.per_token_kernel_sem(xc, t), f"sample {j} {f}")
+        for f, t in tab4.items():
+            assert_bits_equal(fs.quantizer(f)(xs[j]), orc.per_group_kernel_sem(xc, t, 128), f"sample {j} {f}")
+    wc = w[:256].cpu()
+    for f, t in tab6.items():
+        assert_bits_equal(fs.quantizer(f)(w)[:256], orc.per_token_kernel_sem(wc, t), f"weight {f}")
+    for f, t in tab4.items():
+        assert_bits_equal(fs.quantizer(f)(w)[:256], orc.per_group_kernel_sem(wc, t, 128), f"weight {f}")
+    # the batched form's precondition: a sample's rows come out of the concatenated launch as out of its own
+    x_all = torch.cat([x.reshape(-1, 1920) for x in xs])
+    for f in list(tab6) + list(tab4):
+        q_all = fs.quantizer(f)(x_all)
+        o = sum(x.numel() // 1920 for x in xs[:77])
+        assert torch.equal(q_all[o:o + xs[77].numel() // 1920].view(torch.int16), fs.quantizer(f)(xs[77]).reshape(-1, 1920).view(torch.int16))
+
+
+def test_format_search_batched_default_only_for_row_local_quantizers(dev, qu):
+    """An injected quantizer is not assumed to be row-local: the default then is the sample-by-sample loop (a per-tensor
+    quantizer sees another tensor once the samples are concatenated); fp32 samples against an fp16 weight are quantized
+    in THEIR dtype in both forms."""
+    from fpqvar_amd import format_search as fs
+    g = torch.Generator(device=dev).manual_seed(5)
+    xs = [torch.randn(2, n, 512, device=dev, generator=g) * (1 + j) for j, n in enumerate((4, 9, 16))]     # fp32 samples
+    w = (torch.randn(256, 512, device=dev, generator=g) * 0.05).half()
+    _, _, lb = fs.search_layer(xs, w, fs.FP4_FORMATS)
+    _, _, ll = fs.search_layer(xs, w, fs.FP4_FORMATS, batched=False)
+    for key in ll:
+        assert abs(lb[key] - ll[key]) <= 1e-4 * ll[key], (key, lb[key], ll[key])
+
+    def per_tensor(fmt):
+        return lambda t: qu.fp_quant_e2_per_tensor(t)[0].to(t.dtype)
+    _, _, ld = fs.search_layer(xs, w, ("a", "b"), quant=per_tensor)                    # default: the loop
+    _, _, lf = fs.search_layer(xs, w, ("a", "b"), quant=per_tensor, batched=False)
+    assert ld == lf
+    _, _, lt = fs.search_layer(xs, w, ("a", "b"), quant=per_tensor, batched=True)      # forced: another (wrong) number
+    assert abs(lt[("a", "a")] - lf[("a", "a")]) > 1e-3 * lf[("a", "a")]
+
+
+def test_config4_format_search_sharded_two_ranks_share_the_gpu():
+    """search_blocks_sharded at config-4 size: 4 blocks of [5760 x 1920] x 100 samples on 2 real ranks sharing the GPU (gloo)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPQ_CHECK_BACKEND="gloo", FPQ_CHECK_ONLY="search", FPQ_CHECK_SEARCH="config4")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", os.path.join(root, "tools", "rccl_world2_check.py")],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-2000:]
+    assert text.count("equals the single-process result: True") == 2, text[-2000:]

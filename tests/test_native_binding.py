@@ -24,6 +24,15 @@ def test_native_module_is_built_and_bound():
     for n in NAMES:
         assert callable(getattr(_native, n)), n
     assert quant_cuda.quant is _native.quant
+    # BASELINE north_star / SURVEY 8b L1: the reference-named fused functions hang off the module `quant_cuda` itself
+    assert quant_cuda.fp_quant_e2_per_group_cuda is _native.fp_quant_e2_per_group_cuda
+    assert quant_cuda.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda is _native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda
+    assert quant_cuda.fp6_quant_int_neg_e2m3_pos_per_group_cuda is _native.fp6_quant_int_neg_e2m3_pos_per_group_cuda
+    for n in quant_cuda.FP_QUANT_NAMES:
+        assert getattr(quant_cuda, n) is getattr(qu, n), n
+    for n in ("rotate_quant_mx", "adaln_rotate_quant_mx", "adaln_rotate_quant_token", "adaln_rotate_quant_token_codes",
+              "kv_cache_step", "linear_fp4"):
+        assert callable(getattr(_native, n)), n
     assert qu.fp_quant_e2_per_group_cuda is _native.fp_quant_e2_per_group_cuda
     assert qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda is _native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda
     # no CPU path in the compiled module either
@@ -111,3 +120,68 @@ def test_native_dual_under_graph_capture():
         torch.cuda.synchronize()
         assert_bits_equal(y, eager, f"replay {trial}")
         assert bool((y == 0).all()) == poison
+
+
+@pytest.mark.gpu
+def test_native_q_path_equals_ctypes_path(monkeypatch):
+    """The operand-emitting producers, the per-token producer, the KV-cache step and the FP4 GEMM through the compiled
+    binding against the same calls through ctypes (the wrappers with `_native` taken away): same C entry points."""
+    from fpqvar_amd import _native, gemm, ops, rotation as rot
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    B, L, C = 4, 37, 1920
+    x16 = torch.randn(B, L, C, generator=g).half().to(dev)
+    x32 = torch.randn(B, L, C, generator=g).to(dev)
+    sc = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    sh = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    sm = (torch.rand(C, generator=g) + 0.5).to(dev)
+
+    def both(fn):
+        assert rot._native is _native and ops._native is _native and gemm._native is _native
+        a = fn()
+        with monkeypatch.context() as m:
+            for mod in (rot, ops, gemm):
+                m.setattr(mod, "_native", None)
+            b = fn()
+        return a, b
+
+    def same(a, b, what):
+        a, b = (a, b) if isinstance(a, tuple) else ((a,), (b,))
+        for i, (p, q) in enumerate(zip(a, b)):
+            assert p.dtype == q.dtype and p.shape == q.shape and torch.equal(p.view(torch.uint8), q.view(torch.uint8)), f"{what}[{i}]"
+
+    for x in (x16, x32):
+        for smooth in (None, sm):
+            same(*both(lambda: rot.rotate_quant_mx(x, smooth=smooth)), "rotate_quant_mx")
+            same(*both(lambda: rot.adaln_rotate_quant_mx(x, sc, sh, smooth=smooth)), "adaln_rotate_quant_mx")
+            for emit in ("values", "fp8", "fp6"):
+                same(*both(lambda: rot.adaln_rotate_quant_token(x, sc, sh, "e2m3", smooth=smooth, emit=emit)), "token " + emit)
+    with pytest.raises(RuntimeError):
+        rot.adaln_rotate_quant_token(x16, sc, sh, "e3m2", emit="fp6")
+    with pytest.raises(RuntimeError):
+        rot.adaln_rotate_quant_token(x16, sc, sh, "e2m3", emit="nibbles")
+    # the FP4 GEMM with and without the gated residual of the AdaLN block
+    a = gemm.quantize_mx(x16.reshape(-1, C))
+    w = gemm.quantize_mx((torch.randn(256, C, generator=g) * 0.02).to(dev))
+    bias = torch.randn(256, generator=g).half().to(dev)
+    gate = torch.randn(B, 1, 256, generator=g).half().to(dev)
+    res = torch.randn(B, L, 256, generator=g).half().to(dev)
+    same(*both(lambda: gemm.linear_fp4(*a, *w)), "linear_fp4")
+    same(*both(lambda: gemm.linear_fp4(*a, *w, bias, gate, res)), "linear_fp4 + epilogue")
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp4(a[0][:, :-64], a[1], *w)
+    # the KV-cache step
+    from fpqvar_amd import kv_cache as kvc
+    outs = []
+    for native in (True, False):
+        with monkeypatch.context() as m:
+            if not native:
+                m.setattr(ops, "_native", None)
+            cache = kvc.IncrementalKVCache(2, 16, 30, 64, 6, device=dev)
+            gg = torch.Generator().manual_seed(3)
+            for n in (1, 4, 9):
+                k = torch.randn(2, n, 30, 64, generator=gg).half().to(dev)
+                v = torch.randn(2, n, 30, 64, generator=gg).half().to(dev)
+                kk, vv = cache.append(k, v)
+            outs.append((kk.clone(), vv.clone()))
+    same(outs[0], outs[1], "kv_cache_step")

@@ -10,6 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["FPQ_NO_NATIVE"] = "1"   # the compiled binding is linked to the stock library: every case goes through ctypes here
 import torch  # noqa: E402
 
 from fpqvar_amd import _lib, ops, rotation as rot  # noqa: E402
@@ -39,6 +40,8 @@ def burst(fn, n=20):
 
 def main():
     libs = {"A": load(sys.argv[1]), "B": load(sys.argv[2])}
+    for n, l in libs.items():
+        print(f"{n}: {sys.argv[1 if n == 'A' else 2]}  build tag {l.fpq_build_tag().decode() if hasattr(l, 'fpq_build_tag') else 'untagged'}", flush=True)
     want = sys.argv[3:]
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)

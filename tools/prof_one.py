@@ -5,18 +5,15 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("FPQ_PROF_LIB"):
+    os.environ["FPQ_NO_NATIVE"] = "1"   # the compiled binding is linked to the stock library: keep the wrappers on ctypes
 import torch  # noqa: E402
 
 from fpqvar_amd import _lib, ops, quant_utils as qu, rotation as rot  # noqa: E402
 
 if os.environ.get("FPQ_PROF_LIB"):   # a variant build of the library (tools/build_variant.sh), for A/B profiling
-    import ctypes
-    _l = ctypes.CDLL(os.path.abspath(os.environ["FPQ_PROF_LIB"]))
-    for _name, (_res, _args) in _lib._SIGS.items():
-        if hasattr(_l, _name):
-            _fn = getattr(_l, _name)
-            _fn.restype, _fn.argtypes = _res, _args
-    _lib._lib = _l
+    _lib.use_variant(os.environ["FPQ_PROF_LIB"])
+    print("library:", os.environ["FPQ_PROF_LIB"], "build tag:", _lib.build_tag(), file=sys.stderr, flush=True)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "sym"
 dev = torch.device("cuda:0")

@@ -2,15 +2,12 @@
 sets (FPQ_SYM_BIGTAB="U,cap", FPQ_WAVE_CAP, FPQ_BLOCK_RPB) existed only in a temporary diagnostic build of fpq_kernels.hip
 (three getenv lines in fpq_quant_rows / launch_fast16_block); the measured choices are the defaults now, so against the
 regular library every line of this script prints the same figure.      python tools/sym_exp.py <libfpq_hip.so>"""
-import ctypes, os, sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["FPQ_NO_NATIVE"] = "1"
 import torch
 from fpqvar_amd import _lib, ops
-l = ctypes.CDLL(os.path.abspath(sys.argv[1]))
-for name, (res, args) in _lib._SIGS.items():
-    if hasattr(l, name):
-        fn = getattr(l, name); fn.restype, fn.argtypes = res, args
-_lib._lib = l
+_lib.use_variant(sys.argv[1])
 dev = torch.device("cuda:0")
 xs = [torch.randn(65536, 1920, device=dev).half() for _ in range(4)]
 hs = [torch.randn(16384, 7680, device=dev).half() for _ in range(4)]

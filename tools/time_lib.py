@@ -1,14 +1,11 @@
 #!/usr/bin/env python3
 """Time adaln_rotate_quant (fp16 rows, e2m1) through a given build of the library: time_lib.py <lib.so> [B L C]"""
-import ctypes, os, sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["FPQ_NO_NATIVE"] = "1"   # the compiled binding is linked to the stock library (the values case measured stock whatever was passed)
 import torch
 from fpqvar_amd import _lib, rotation as rot
-l = ctypes.CDLL(os.path.abspath(sys.argv[1]))
-for name, (res, args) in _lib._SIGS.items():
-    if hasattr(l, name):
-        fn = getattr(l, name); fn.restype, fn.argtypes = res, args
-_lib._lib = l
+_lib.use_variant(sys.argv[1])
 dev = torch.device("cuda:0")
 B, L, C = (int(a) for a in sys.argv[2:5]) if len(sys.argv) > 4 else (100, 655, 1920)
 xs = [torch.randn(B, L, C, device=dev).half() for _ in range(3)]
@@ -46,4 +43,4 @@ if os.environ.get("TIME_SUSTAIN"):   # the same call for seconds on end: does th
         series.append(round(e0.elapsed_time(e1) / 200 * 1e3, 1))
     print("sustained, 200 launches per figure:", series, flush=True)
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith(("FPQ_", "TIME_CASE", "TIME_X32")))
-print(f"{os.path.basename(sys.argv[1]):22s} {tag:24s} [{B}x{L}x{C}] {best:7.1f} us  frac {B*L*C*4/best/1e6/8:.3f}", flush=True)
+print(f"{os.path.basename(sys.argv[1]):22s} tag={_lib.build_tag():10s} {tag:24s} [{B}x{L}x{C}] {best:7.1f} us  frac {B*L*C*4/best/1e6/8:.3f}", flush=True)
