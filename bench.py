@@ -53,10 +53,14 @@ class Stage:
     """What the run is doing right now (for the watchdog): assigning stage[0] restarts its clock."""
 
     def __init__(self):
-        self.name, self.t0, self.done = "starting", time.monotonic(), threading.Event()
+        self.name, self.t0, self.done, self.limit = "starting", time.monotonic(), threading.Event(), WATCHDOG_S
 
     def __setitem__(self, _, name):
-        self.name, self.t0 = name, time.monotonic()
+        self.name, self.t0, self.limit = name, time.monotonic(), WATCHDOG_S
+
+    def set(self, name, limit):
+        """A stage whose honest duration grows with the arguments (warm-up, the timed region) brings its own limit."""
+        self.name, self.t0, self.limit = name, time.monotonic(), max(WATCHDOG_S, limit)
 
     def __getitem__(self, _):
         return self.name
@@ -393,7 +397,64 @@ def other_kernels(dev):
         out["gemm_fp4_w4a4_mat_qkv_65536x1920x5760"] = {"ms": round(ms, 4),
                                                         "TFLOPs": round(2.0 * ROWS * COLS * 3 * COLS / ms / 1e9, 1)}
 
-    groups = [("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4), ("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6),
+    def configs():
+        """One driver-written number per BASELINE.json configuration that is not the metric's own (config 3 at the metric
+        shape is everything above; its real row counts and config 5's are config3_steps / config5_steps of the line)."""
+        from fpqvar_amd import calibrate as cal, format_search as fs, quant_utils as qu
+        # config 1: single [4096 x 1024] fp32 tensor, per-tensor E2M1 through the pure-torch (argmin) semantics
+        # (search/baseline/plot_weight_distribution_for_motivation.py:286-297): two launches (maxima, then scale + lookup),
+        # 4 B read twice + 4 B written per element
+        t1 = [torch.randn(4096, 1024, device=dev, generator=g) for _ in range(3)]
+        hbm("config1_fp_quant_e2_per_tensor_fp32_4096x1024", timed(lambda: qu.fp_quant_e2_per_tensor(nxt(t1))), t1[0].numel() * 12)
+        out["config1_fp_quant_e2_per_tensor_fp32_4096x1024"]["bytes_per_element"] = "4 (absmax pass) + 4 + 4"
+        # config 2: the 16 mat_qkv weights of VAR-d16, [3072 x 1024] fp32, per group of 128 E2M1 -> fp32 as from_float does
+        # (tr/quant_utils.py:828-837): 16 calls, and ONE launch over a segment table
+        ws = {f"blocks.{b}.attn.mat_qkv": torch.randn(3072, 1024, device=dev, generator=g) * 0.02 for b in range(16)}
+        n2 = sum(w.numel() for w in ws.values())
+        hbm("config2_d16_mat_qkv_16_calls_fp32_to_fp32", timed(lambda: [qu.fp_quant_e2_per_group_cuda(w, 4, 128) for w in ws.values()],
+                                                                iters=20, lead=2), n2 * 8)
+        shard = cal.LocalShard(ws, out_dtype=torch.float32)
+        hbm("config2_d16_mat_qkv_one_segment_launch_fp32_to_fp32", timed(shard.quantize, iters=50, lead=5), n2 * 8)
+        del shard, ws
+        # config 4: the format search of one d30 mat_qkv layer over its 100 dumped samples (13600 rows), batched
+        # (search/search_fp6_format.py:589-608: FP6 2 x 2; search_fp4_format.py:782-821: FP4 3 x 3); ms per layer incl. its one read-back
+        pns = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
+        xs = [torch.randn(2, pns[j % 10] ** 2, COLS, device=dev, generator=g).half() for j in range(100)]
+        w = (torch.randn(3 * COLS, COLS, device=dev, generator=g) * 0.02).half()
+        for label, formats in (("fp6_2x2", fs.FP6_FORMATS), ("fp4_3x3", fs.FP4_FORMATS)):
+            fs.search_layer(xs, w, formats)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                best = fs.search_layer(xs, w, formats)
+            ms = (time.perf_counter() - t0) / 5 * 1e3
+            out[f"config4_format_search_d30_mat_qkv_{label}_100_samples"] = {"ms_per_layer": round(ms, 3), "winner": list(best[:2]),
+                                                                             "rows": 13600, "clock": "host wall clock incl. the read-back"}
+        del xs, w
+        # config 5: VAR-d36 512 x 512, the widths of its activations at the 44800 rows of one batch (B = 20 conditioned rows,
+        # 2240 tokens): producers on the fp32 residual stream (C = 2304), dual format on the hidden width 9216
+        B5, L5, C5 = 20, 2240, 2304
+        x5 = [torch.randn(B5, L5, C5, device=dev, generator=g) for _ in range(2)]
+        sc5 = (torch.randn(B5, 1, C5, device=dev, generator=g) * 0.3).half()
+        sh5 = (torch.randn(B5, 1, C5, device=dev, generator=g) * 0.3).half()
+        s5 = torch.rand(C5, device=dev, generator=g) + 0.5
+        n5 = B5 * L5 * C5
+        hbm("config5_adaln_rotate_quant_e2m1_fp32rows_44800x2304",
+            timed(lambda: rot.adaln_rotate_quant(nxt(x5), sc5, sh5, "e2m1", smooth=s5)), n5 * 6)
+        hbm("config5_adaln_rotate_quant_codes_mx_fp32rows_44800x2304",
+            timed(lambda: rot.adaln_rotate_quant_mx(nxt(x5), sc5, sh5, smooth=s5)), n5 * (4 + 0.5 + 2.0 / GROUP))
+        x5h = [t.half() for t in x5]
+        del x5
+        hbm("config5_adaln_rotate_quant_e2m1_fp16rows_44800x2304",
+            timed(lambda: rot.adaln_rotate_quant(nxt(x5h), sc5, sh5, "e2m1", smooth=s5)), n5 * 4)
+        a5 = [t.view(B5 * L5, C5) for t in x5h]
+        hbm("config5_act_quant_e2m1_g128_fp16_44800x2304", timed(lambda: ops.quant_rows(nxt(a5), "e2m1", GROUP)), n5 * 4)
+        del x5h, a5
+        h5 = [torch.nn.functional.gelu(torch.randn(B5 * L5, 4 * C5, device=dev, generator=g), approximate="tanh").half() for _ in range(2)]
+        hbm("config5_dual_fc2_e1m2neg_e2m1pos_fp16_44800x9216",
+            timed(lambda: ops.quant_rows_dual(nxt(h5), "e1m2_neg", "e2m1_pos", GROUP, 1.0)), h5[0].numel() * 4)
+
+    groups = [("baseline_configs_1_2_4_5", configs), ("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4), ("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6),
               ("activations_fp16_65536x1920", act16), ("operand_emitting_producers_65536x1920", operands),
               ("weights_fp32_32768x1920", weights), ("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", consumers)]
     only = os.environ.get("FPQ_BENCH_GROUPS")   # profiling aid: a comma-separated subset of the group functions' names
@@ -569,6 +630,7 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
     dt, dt_g, dt_c = float("nan"), float("nan"), float("nan")
     total = 0
     err = None
+    codes_err = None
     own, shapes, cal = {}, {}, None
     try:
         stage[0] = "local quantization"
@@ -617,26 +679,43 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_g = float(t.item())
                 del plan
-                # the same with the packed exchange format (nibble codes + one fp32 scale per group: 0.53 B per element
-                # on the wire instead of 2, decoded locally, bit-identical): a second curve for the same run
-                stage[0] = "sharded calibration, codes exchange + all_gather_into_tensor"
-                codes_run = getattr(plat, "codes_calibration", None)
-                if codes_run is None:   # slabs + the two segment tables built once (not timed), as for the fp16 form
-                    codes_plan = cal.ShardedCodesCalibration(own_all(shapes, own, dev), group=None)
-                    codes_run = codes_plan.run
-                codes_run()
-                plat.synchronize()
-                dist.barrier()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    codes_run()
-                plat.synchronize()
-                dist.barrier()
-                t = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt_c = float(t.item())
             except Exception as e:
-                err = f"gathered calibration: {e!r}"[:300]
+                err = f"gathered calibration (fp16 exchange): {e!r}"[:300]
+            # the same with the packed exchange format (nibble codes + one fp32 scale per group: 0.53 B per element on the
+            # wire instead of 2, decoded locally, bit-identical): a second curve for the same run.  Its own try block and
+            # its own status exchange: a rank that failed above (or fails building the plan) must not leave the others
+            # blocked in this phase's collectives.
+            codes_run, cerr = None, None
+            try:
+                stage[0] = "codes calibration plan"
+                if err is None:
+                    codes_run = getattr(plat, "codes_calibration", None)
+                    if codes_run is None:   # slabs + the two segment tables built once (not timed), as for the fp16 form
+                        codes_plan = cal.ShardedCodesCalibration(own_all(shapes, own, dev), group=None)
+                        codes_run = codes_plan.run
+            except Exception as e:
+                cerr = f"codes calibration plan: {e!r}"[:300]
+            stage[0] = "all_reduce of the codes-plan status"
+            okc = torch.tensor([0.0 if (err or cerr or codes_run is None) else 1.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+            if okc.item() > 0.5:
+                try:
+                    stage[0] = "sharded calibration, codes exchange + all_gather_into_tensor"
+                    codes_run()
+                    plat.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        codes_run()
+                    plat.synchronize()
+                    dist.barrier()
+                    t = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt_c = float(t.item())
+                except Exception as e:
+                    cerr = f"codes exchange: {e!r}"[:300]
+            if cerr and err is None:
+                codes_err = cerr
     stage[0] = "done"
     try:
         own.clear()
@@ -661,6 +740,8 @@ def weight_calibration(plat, dist, world, rank, stage, depth=None, iters=10, war
         ag = max(dt_g - dt, 1e-9)
         res["all_gather_ms"] = round(ag * 1e3, 3)                                  # = ms_with_all_gather - ms
         res["all_gather_GBps_per_rank"] = round(2 * total * (world - 1) / world / ag / 1e9, 1)   # bytes a rank receives / time
+    if codes_err is not None:
+        res["codes_exchange"] = {"error": codes_err}
     if dt_c == dt_c:
         res["codes_exchange"] = {"exchange": "nibble codes + fp32 group scales (0.53 B per element), decoded locally",
                                  "ms_with_all_gather": round(dt_c * 1e3, 3), "Gelem_s_with_all_gather": round(total / dt_c / 1e9, 1),
@@ -690,6 +771,14 @@ def pmc_traffic():
             except Exception:
                 continue
     return None, None
+
+
+def headline_kernel_label():
+    """Which instantiation fpq_quant_rows picks for the metric shape: FPQ_NO_HW4 (read per call by the library) keeps the
+    bucket table; the vectors per lane are build-time constants of fpq_kernels.hip (FPQ_FAST16_HW4_U = 1, FPQ_FAST16_U = 2)."""
+    if os.environ.get("FPQ_NO_HW4"):
+        return "rows16_lut_subwave_kernel<16 lanes/group, U=2, bucket table in LDS (FPQ_NO_HW4)>"
+    return "rows16_lut_subwave_kernel<16 lanes/group, U=1, HW4: E2M1 levels from the FP4 conversion hardware>"
 
 
 def build_result(args, world, elems, elapsed, kernel_ms, calib, rccl_ranks, data):
@@ -722,7 +811,7 @@ def build_result(args, world, elems, elapsed, kernel_ms, calib, rccl_ranks, data
                      "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                         "from an earlier run (gfx950 FETCH_SIZE x2 correction applied); a constant, not a "
                                         "measurement of this timed region") if traffic_src else None,
-                     "kernel": "rows16_lut_subwave_kernel<16 lanes/group, U=1, HW4: E2M1 levels from the FP4 conversion hardware>",
+                     "kernel": headline_kernel_label(),
                      "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes": elems * BYTES_PER_ELEM},
     }
@@ -756,10 +845,10 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
     partial = [None]        # a function building the line from what has been measured so far
 
     def watchdog():
-        limit = WATCHDOG_S if rank == 0 else 1.5 * WATCHDOG_S + 5.0   # rank 0 reports first: the line is its to print
         while not stage.done.wait(0.5):
+            limit = stage.limit if rank == 0 else 1.5 * stage.limit + 5.0   # rank 0 reports first: the line is its to print
             if stage.age() > limit:
-                err = {"error": f"timeout after {WATCHDOG_S:.0f} s in {stage[0]}"}
+                err = {"error": f"timeout after {stage.limit:.0f} s in {stage[0]}"}
                 if rank == 0:
                     line = partial[0](err) if partial[0] is not None else dict(
                         metric="Gelements/s + achieved HBM GB/s, per-group FP4 quant [65536x1920,g=128]", value=None,
@@ -782,7 +871,9 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
         if rccl_ranks != world:
             raise SystemExit(f"bench.py: the process group has {rccl_ranks} ranks, WORLD_SIZE says {world}")
 
-    stage[0] = "warm-up"
+    # (a step of the hot path takes ~0.1 ms; the limits of these two stages grow with --warmup / --steps so that a long
+    # honest run is not reported as a blocked collective)
+    stage.set("warm-up", WATCHDOG_S + 0.01 * args.warmup)
     step, elems, x0 = plat.hot_path(rank)
     for _ in range(args.warmup):
         step()
@@ -791,7 +882,7 @@ def main(argv=None, script=None, platform_factory=GpuPlatform):
     if dist is not None:
         dist.barrier()
     plat.synchronize()
-    stage[0] = "timed region"
+    stage.set("timed region", WATCHDOG_S + 0.01 * args.steps)
     start, stop, elapsed_ms = plat.timer()
     t0 = time.perf_counter()
     start()                       # same stream the kernel is launched on

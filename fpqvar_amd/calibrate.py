@@ -226,7 +226,9 @@ class ShardedCalibration:
             else:
                 raise RuntimeError("ShardedCalibration: this rank holds no weights; pass `device=`")
         self.device = torch.device(device)
-        self.slab = torch.empty((self.world, self.plan.width), dtype=torch.float16, device=self.device)
+        # zeros, once: ranks with a short share gather the padding behind it, and a gathered slab should be a
+        # deterministic function of the weights (the launches only ever write the layers)
+        self.slab = torch.zeros((self.world, self.plan.width), dtype=torch.float16, device=self.device)
         self.local = LocalShard(OrderedDict((n, weights[n]) for n in mine), self.plan.shapes, weight_fp_type,
                                 out=self.slab[self.rank])
 
@@ -299,8 +301,14 @@ class ShardedCodesCalibration:
     name; only this rank's layers are read (others may be zero-stride placeholders of the right shape)."""
 
     def __init__(self, weights, group=None, gather: bool = True, rank: Optional[int] = None, world: Optional[int] = None):
+        """A reusable plan: slabs, segment tables and the output buffer are built HERE, once.  Two consequences for a caller
+        that keeps the object: (1) the device pointers of the owned weights are baked into the segment table - a weight that
+        is float32, contiguous and 16-byte aligned is read in place by every run() (updates are seen), anything else is
+        converted ONCE into a private copy (`snapshot_names`; later updates of the original are NOT seen - rebuild the plan);
+        (2) every run() returns views of the same `out` buffer, so the result of an earlier run() is overwritten."""
         from . import _lib
         self._lib = _lib
+        self.snapshot_names = []
         r0, w0 = _world(group)
         self.rank = r0 if rank is None else rank
         self.world = w0 if world is None else world
@@ -323,7 +331,7 @@ class ShardedCodesCalibration:
         wc = (wc + 15) // 16 * 16
         ws = max(sum(n_scales[n] for n in self.plan[r]) for r in range(world))
         width = (wc + 4 * ws + 15) // 16 * 16
-        self.slab = torch.empty((world, width), dtype=torch.uint8, device=dev)
+        self.slab = torch.zeros((world, width), dtype=torch.uint8, device=dev)   # padding zeroed once (see ShardedCalibration)
         if self.slab.data_ptr() % 16 != 0:
             raise RuntimeError("calibrate_sharded(exchange='codes'): the slab is not 16-byte aligned")
 
@@ -340,10 +348,13 @@ class ShardedCodesCalibration:
         for n, off, soff in layout(rank):
             w = weights[n]
             _lib.require_gpu(w, f"calibrate_sharded({n})")
+            w0 = w
             w = w.float() if w.dtype != torch.float32 else w
             w = w if w.is_contiguous() else w.contiguous()
             if w.data_ptr() % 16 != 0:
                 w = w.clone()
+            if w.data_ptr() != w0.data_ptr():
+                self.snapshot_names.append(n)
             self._inputs.append(w)
             q_desc.append([w.data_ptr(), base + off, base + soff, n_scales[n]])
         self._q_rows = max((d[3] for d in q_desc), default=0)

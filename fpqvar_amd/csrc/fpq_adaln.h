@@ -757,8 +757,9 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   // One row.  `cur` holds it; `next_row` >= 0: that row is requested - DB: into `nxt`, at once; otherwise into `cur`,
   // once the current row has left it.
 #ifdef FPQ_ADALN_STAMPS
-  unsigned long long st_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_rows = 0;
+  unsigned long long st_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_rows = 0, st_first = 0;
   const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole chip
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) : : "memory");   // phase 0 of the first row = the prologue
 #endif
   u32x4 pend = {0, 0, 0, 0};      // PAIRABLE: the parked slot chunk of the pair's first row, and that row
   int64_t pend_row = 0;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
     FPQ_STAMP(0);                                   // between rows (loop control; the first row: the prologue)
 #ifdef FPQ_ADALN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ++st_rows;
+    if (++st_rows == 1) st_first = __builtin_amdgcn_s_memrealtime();   // the wavefront's first row has arrived
 #endif
     FPQ_STAMP(1);                                   // waiting for the row (and, in this build, the previous row's stores)
 #ifdef FPQ_ADALN_COPYONLY   // experiment: the kernel's memory access pattern alone (rows in, rows out, nothing computed; 2: no staging either)
@@ -1153,6 +1154,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
       dst[12] = hw_id;
       dst[13] = xcc_id;
+      dst[14] = st_first;
     }
   }
 #endif

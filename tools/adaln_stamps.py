@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Where a wavefront's row time goes in the adaLN producer: needs a library built with -DFPQ_ADALN_STAMPS
 (tools/build_variant.sh stamps -DFPQ_ADALN_STAMPS), whose kernel sums s_memtime differences per phase and wavefront.
-usage: adaln_stamps.py tools/ab/libstamps.so [fp16|fp32] [B L C]"""
+usage: adaln_stamps.py tools/ab/libstamps.so [fp16|fp32] [B L C] [cold]
+"cold": the stamped launch works on a tensor the caches have not seen (a 512 MiB write in front of it), as a launch of a
+hipGraph over rotating inputs does (bench.generation_steps); default: the 30th launch on the same tensor."""
 import ctypes
 import os
 import sys
@@ -23,12 +25,18 @@ x = x.half() if dt == "fp16" else x
 scale = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
 shift = (torch.randn(B, C, device=dev, generator=g) * 0.3).half()
 s = torch.rand(C, device=dev, generator=g) + 0.5
+cold = len(sys.argv) > 6 and sys.argv[6] == "cold"
+x_cold = torch.randn(B, L, C, device=dev, generator=g).to(x.dtype) if cold else None
+flush = torch.empty(1 << 29, dtype=torch.uint8, device=dev) if cold else None
 out = torch.empty(B, L, C, dtype=torch.float16, device=dev)
 stamps = torch.zeros(16 * (1 << 19), dtype=torch.int64, device=dev)
 mask = rot._mask_arg(None)
 for it in range(30):
     if it == 29:
         stamps.zero_()
+        if cold:
+            flush.zero_()
+            x = x_cold
     _lib.check(lib.fpq_adaln_rotate_quant_rows(x.data_ptr(), out.data_ptr(), None, stamps.data_ptr(), B * L, C,
                                                _lib.dtype_id(x.dtype), scale.data_ptr(), shift.data_ptr(), _lib.F16, L, 1e-6,
                                                s.data_ptr(), mask, _lib.TABLE_IDS["e2m1"], _lib.stream_ptr(dev)), "stamps")
@@ -57,6 +65,19 @@ print(f"launch: {(end - start) * 0.01:.1f} us from the first wavefront's start t
       f"mean {float((t1 - t0).mean()) * 0.01:.1f} us, min {float((t1 - t0).min()) * 0.01:.1f}, max {float((t1 - t0).max()) * 0.01:.1f}")
 print(f"distinct CUs seen: {len(set(cu_key.tolist()))}; wavefronts per CU: min {min(collections.Counter(cu_key.tolist()).values())} "
       f"max {max(collections.Counter(cu_key.tolist()).values())}")
+# when the wavefronts start, get their first row, and end (us from the first start; percentiles over the wavefronts)
+if st.shape[1] > 14 and float(st[:, 14].max()) > 0:
+    def pct(v):
+        q = torch.quantile((v - start) * 0.01, torch.tensor([0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0], dtype=torch.float64))
+        return " ".join(f"{float(x):5.1f}" for x in q)
+    print("percentiles over the wavefronts      min   10%   25%   50%   75%   90%   max   (us after the first wavefront's start)")
+    print("  start                            " + pct(t0))
+    print("  first row has arrived            " + pct(st[:, 14]))
+    print("  end                              " + pct(t1))
+    late = t0 > (t0.min() + 100)   # started more than 1 us after the first: a later generation
+    print(f"  wavefronts of later generations: {int(late.sum())} of {st.shape[0]}; their wait for the first row: "
+          f"median {float(((st[:, 14] - t0)[late]).median()) * 0.01 if late.any() else 0:.1f} us against "
+          f"{float(((st[:, 14] - t0)[~late]).median()) * 0.01:.1f} us for the first generation")
 nb = 20
 edges = [start + (end - start) * k / nb for k in range(nb + 1)]
 print("resident wavefronts per CU (average over the chip) by twentieth of the launch:")
