@@ -677,31 +677,67 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   const h2v_t ones = {(_Float16)1.0f, (_Float16)1.0f};
 
   // ---- the folded modulation of batch entry b:  A = half(scale + 1) * s * D,  B = shift * s * D;  zeros beyond the row ----
-  auto stage = [&](int64_t b) {
-    for (int v = threadIdx.x; v < PV; v += 64 * NW) {
+  // Two steps: the loads (raw words into registers), then arithmetic + LDS writes.  The loads are issued BEFORE the
+  // wavefront's first row is requested and for all of a thread's plane vectors at once (round 4).  Until then the row came
+  // first and the staging loop loaded, waited and stored one vector per trip: a wavefront's loads return in order and a
+  // CU's L1 works its misses off in order, so the modulation words (L2 hits after the first workgroup of a batch entry)
+  // sat behind every row request the CU had issued, and rows of 17 - 20 groups (320 plane vectors: two trips of a
+  // 256-thread workgroup) paid the latency twice - tools/adaln_stamps.py: at [20 x 324 x 2304] fp32 no wavefront had its
+  // first row before 4.7 us after its start (2.4 us at [100 x 64 x 1920]).
+  constexpr int NST = (PV + 64 * NW - 1) / (64 * NW);   // plane vectors per thread
+  struct StageRaw {
+    u32x4 w[MOD16 ? 2 : 4];   // scale, shift (fp16: one vector each; fp32: two)
+    u32x4 s[2];               // smoothing factors
+  };
+  auto stage_load = [&](int64_t b, StageRaw (&raw)[NST]) {
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+      const int v = threadIdx.x + t * 64 * NW;
+      if (v < PV && (TIGHT || v < vpr)) {
+        const int64_t col = (int64_t)v * 8;
+        if constexpr (MOD16) {
+          raw[t].w[0] = *(const u32x4*)((const _Float16*)ad.scale + b * ad.cols + col);
+          raw[t].w[1] = *(const u32x4*)((const _Float16*)ad.shift + b * ad.cols + col);
+        } else {
+          const u32x4* ap = (const u32x4*)((const float*)ad.scale + b * ad.cols + col);
+          const u32x4* bp = (const u32x4*)((const float*)ad.shift + b * ad.cols + col);
+          raw[t].w[0] = ap[0];
+          raw[t].w[1] = ap[1];
+          raw[t].w[2] = bp[0];
+          raw[t].w[3] = bp[1];
+        }
+        if (r.smooth) {
+          const u32x4* sp = (const u32x4*)(r.smooth + col);
+          raw[t].s[0] = sp[0];
+          raw[t].s[1] = sp[1];
+        }
+      }
+    }
+  };
+  auto stage_store = [&](const StageRaw (&raw)[NST]) {
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+      const int v = threadIdx.x + t * 64 * NW;
+      if (v >= PV) break;
       float sc[8], sh[8];
       if (TIGHT || v < vpr) {
-        const int64_t col = (int64_t)v * 8;
+        float sm[8];
+        if (r.smooth) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            sm[k] = u2f(raw[t].s[0][k]);
+            sm[4 + k] = u2f(raw[t].s[1][k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sm[k] = 1.0f;
+        }
         if constexpr (MOD16) {
           // fp16 modulation: the sign vector D goes onto the PACKED words (one xor per pair; vector v of a row carries
           // the signs of chunk v % 16 = lane % 16: the lane constants sx), and one v_fma_mix_f32 per element widens and
           // applies the smoothing factor (h * s - 0 == h * s, signed zeros included) - about half the vector
           // instructions of convert, multiply, per-element sign flip, in a prologue every wavefront pays per two rows
-          const u32x4 ws = *(const u32x4*)((const _Float16*)ad.scale + b * ad.cols + col);
-          const u32x4 wh = *(const u32x4*)((const _Float16*)ad.shift + b * ad.cols + col);
-          float sm[8];
-          if (r.smooth) {
-            const u32x4* sp = (const u32x4*)(r.smooth + col);
-            const u32x4 s0 = sp[0], s1 = sp[1];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              sm[k] = u2f(s0[k]);
-              sm[4 + k] = u2f(s1[k]);
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sm[k] = 1.0f;
-          }
+          const u32x4 ws = raw[t].w[0], wh = raw[t].w[1];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint32_t s1p = pk_add_f16(ws[k], 0x3C003C00u) ^ sx[k];   // scale.add(1) is an fp16 op in the reference
@@ -712,9 +748,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
             sh[2 * k + 1] = fma_h_hi(shp, sm[2 * k + 1], -0.0f);
           }
         } else {
-          const u32x4* ap = (const u32x4*)((const float*)ad.scale + b * ad.cols + col);
-          const u32x4* bp = (const u32x4*)((const float*)ad.shift + b * ad.cols + col);
-          const u32x4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+          const u32x4 a0 = raw[t].w[0], a1 = raw[t].w[1], b0 = raw[t].w[2], b1 = raw[t].w[3];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             sc[k] = u2f(a0[k]) + 1.0f;
@@ -723,14 +757,10 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
             sh[4 + k] = u2f(b1[k]);
           }
           if (r.smooth) {
-            const u32x4* sp = (const u32x4*)(r.smooth + col);
-            const u32x4 s0 = sp[0], s1 = sp[1];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              sc[k] *= u2f(s0[k]);
-              sh[k] *= u2f(s0[k]);
-              sc[4 + k] *= u2f(s1[k]);
-              sh[4 + k] *= u2f(s1[k]);
+            for (int k = 0; k < 8; ++k) {
+              sc[k] *= sm[k];
+              sh[k] *= sm[k];
             }
           }
           // the rotation's sign vector D rides on the modulation: half(-t) == -half(t), so h * D = half(fma(ln, A*D, B*D))
@@ -1122,11 +1152,22 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   // ---- the workgroup's rows: wavefront w takes rows lo + w, lo + w + 4, ... ----
   u32x4 cur[RV], alt[DB ? RV : 1];
   int64_t i = lo + RPU * wave;
-  if (i < hi) load_row(cur, i);                  // requested before the staging below
-  if constexpr (!HW4) lut16_stage(lut, tab, a.shift);
 #if !defined(FPQ_ADALN_COPYONLY) || FPQ_ADALN_COPYONLY < 2
-  stage(b);
+  StageRaw sraw[NST];
+#ifndef FPQ_ADALN_ROW_FIRST   // A/B: the round-3 order (row requested first)
+  stage_load(b, sraw);
+  __builtin_amdgcn_sched_barrier(0);             // keep the modulation's loads in front of the row's in the instruction stream
+  if (i < hi) load_row(cur, i);
+#else
+  if (i < hi) load_row(cur, i);
+  __builtin_amdgcn_sched_barrier(0);
+  stage_load(b, sraw);
+#endif
+  if constexpr (!HW4) lut16_stage(lut, tab, a.shift);
+  stage_store(sraw);
   __syncthreads();
+#else
+  if (i < hi) load_row(cur, i);
 #endif
   if constexpr (DB) {
     for (; i < hi; i += 2 * W) {                 // two register sets alternate: no row is copied between registers

@@ -17,6 +17,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if "--lib" in sys.argv:
+    os.environ["FPQ_NO_NATIVE"] = "1"   # a variant build is reached through ctypes only (fpqvar_amd._lib.use_variant)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
@@ -78,9 +80,16 @@ def main():
     ap.add_argument("--mode", default="rotating", choices=("rotating", "resident"))
     ap.add_argument("--ops", default=None, help="comma-separated subset of adaln,act,dual")
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--lib", default=None, help="a variant build of the library (tools/build_variant.sh) instead of the stock one")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.lib:
+        from fpqvar_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
+        _lib.use_variant(a.lib)
     res = dict(stamp())
+    if a.lib:
+        res["build_tag"] = _lib.build_tag()
     res.update(bench.generation_steps(dev, a.model, a.rows, a.mode, only_ops=a.ops.split(",") if a.ops else None))
     if a.eager:
         res["eager"] = eager(dev, a.model, a.rows)
