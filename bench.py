@@ -586,6 +586,13 @@ def generation_steps(dev, model="d30", rows_dtype="fp32", mode="rotating", repla
         t = sum(s[n]["us"] for s in steps)
         b = sum(s[n]["bytes"] for s in steps)
         by_kernel[n] = {"sum_us": round(t, 1), "bytes": b, "frac_of_8TBps": round(b / t / 1e3 / HBM_PEAK_GBS, 3)}
+        # least-squares line us = fixed + rows * slope over the ten steps: what a call costs before it moves a byte, and the
+        # rate it approaches (the time-weighted fraction above mixes the two)
+        xs_, ys_ = [float(s["rows"]) for s in steps], [s[n]["us"] for s in steps]
+        mx, my = sum(xs_) / len(xs_), sum(ys_) / len(ys_)
+        slope = sum((x - mx) * (y - my) for x, y in zip(xs_, ys_)) / sum((x - mx) ** 2 for x in xs_)
+        by_kernel[n]["fit"] = {"fixed_us_per_call": round(my - slope * mx, 2), "ns_per_row": round(slope * 1e3, 3),
+                               "frac_of_8TBps_of_the_slope": round(steps[-1][n]["bytes"] / steps[-1]["rows"] / slope / 1e3 / HBM_PEAK_GBS, 3)}
         tot_t += weights[n] * t
         tot_b += weights[n] * b
     for s in steps:
@@ -608,6 +615,7 @@ def steps_summary(full):
     out = {k: full[k] for k in ("model", "rows_dtype_of_the_residual_stream", "mode", "clock", "per_block_and_step",
                                 "block_us_over_the_ten_steps", "bytes_per_block", "time_weighted_frac_of_8TBps")}
     out["by_kernel"] = {n: v["frac_of_8TBps"] for n, v in full["by_kernel"].items()}
+    out["fit_us_fixed_plus_ns_per_row"] = {n: v["fit"] for n, v in full["by_kernel"].items()}
     out["rows"] = [s["rows"] for s in full["steps"]]
     for n in full["by_kernel"]:
         out[n + "_us"] = [s[n]["us"] for s in full["steps"]]

@@ -1154,15 +1154,23 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   int64_t i = lo + RPU * wave;
 #if !defined(FPQ_ADALN_COPYONLY) || FPQ_ADALN_COPYONLY < 2
   StageRaw sraw[NST];
-#ifndef FPQ_ADALN_ROW_FIRST   // A/B: the round-3 order (row requested first)
-  stage_load(b, sraw);
-  __builtin_amdgcn_sched_barrier(0);             // keep the modulation's loads in front of the row's in the instruction stream
-  if (i < hi) load_row(cur, i);
+  // fp32 rows (10 - 40 KiB of row requests per workgroup): the modulation's loads go first; fp16 rows: the row first, as in
+  // round 3 (ten scale steps cold: fp32 rows 176.3 -> 172.9 us for d30 with the modulation first, fp16 rows
+  // 137.1 -> 139.2; profiles/r04_adaln_stage_order.txt)
+#ifdef FPQ_ADALN_ROW_FIRST
+  constexpr bool MOD_FIRST = false;
 #else
-  if (i < hi) load_row(cur, i);
-  __builtin_amdgcn_sched_barrier(0);
-  stage_load(b, sraw);
+  constexpr bool MOD_FIRST = X32;
 #endif
+  if constexpr (MOD_FIRST) {
+    stage_load(b, sraw);
+    __builtin_amdgcn_sched_barrier(0);           // keep the modulation's loads in front of the row's in the instruction stream
+    if (i < hi) load_row(cur, i);
+  } else {
+    if (i < hi) load_row(cur, i);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_load(b, sraw);
+  }
   if constexpr (!HW4) lut16_stage(lut, tab, a.shift);
   stage_store(sraw);
   __syncthreads();

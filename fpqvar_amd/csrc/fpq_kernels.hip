@@ -1081,9 +1081,12 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       const char* rows_env = FPQ_ENV("FPQ_ADALN_ROWS");
       // Large launches: chunks of 16 rows (4 per wavefront) amortise the staging of the modulation; small launches (the
       // early scale steps of a generation: 100 .. 3600 rows) are latency-bound and want every CU busy: one row per wavefront
-      // (profiles/r02_small_steps.json).  FPQ_ADALN_ROWS=n: n rows per workgroup everywhere; FPQ_ADALN_TAIL=rows: how many
-      // rows at the end of the grid go to each of the two finer tiers (default 8192: two generations of resident
-      // workgroups at 4 rows and one at 8).
+      // (profiles/r02_small_steps.json; round 4, cold inputs, 4 / 8 / 12 / 16 rows per workgroup over the ten steps of d30 and
+      // d36-512: 4 is the best or within 2 % of it up to 10 000 rows, 8 from 16 900 on - profiles/r04_adaln_rows_sweep.txt).
+      // FPQ_ADALN_ROWS=n: n rows per workgroup everywhere; FPQ_ADALN_TAIL=rows: how many rows at the end of the grid go to
+      // each of two finer tiers (8 and 4 rows per workgroup).  The tiers are OFF by default (0): they never beat a plain grid
+      // of 8 - 12 rows (profiles/r03_adaln_partition.txt); the tier decode stays reachable through the variable and is
+      // covered by tests/test_gpu_parity.py::test_adaln_tail_tiers_switch in a child process.
       // (third generation, large launches: 8 rows = two per wavefront for the stream-bound forms - E2M1 values out, fp32
       // rows; 12 for the forms bound by vector issue - operands out or a bucket table, from fp16 rows - where the
       // prologue's instructions per row count: 73.3 -> 70.5 us for codes, 89.7 -> 87.1 for E4M3 bytes, 96.2 -> 93.4 for

@@ -797,6 +797,50 @@ def test_rotate_butterfly_switch(dev, tmp_path):
     assert_bits_equal(o, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "matrix-core form: quant of rotated")
 
 
+def test_adaln_tail_tiers_switch(dev, tmp_path):
+    """FPQ_ADALN_TAIL / FPQ_ADALN_ROWS (read once per process, hence a child process): the last batch entries of the grid cut
+    into finer tiers of 8 and 4 rows per workgroup - off by default (profiles/r03_adaln_partition.txt: never faster), but
+    the tier decode and the magic-number division of adaln_mfma_kernel ship, so they are covered: results must not depend
+    on how rows are cut into workgroups."""
+    import subprocess
+    import sys
+    from fpqvar_amd import rotation as rot
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from fpqvar_amd import rotation as rot\n"
+        "d = torch.load(sys.argv[1])\n"
+        "dev = torch.device('cuda:0')\n"
+        "res = {}\n"
+        "for k in ('x16', 'x32', 'x2304'):\n"
+        "    x = d[k].to(dev)\n"
+        "    c = x.shape[-1]\n"
+        "    res[k] = rot.adaln_rotate_quant(x, d['scale'][..., :c].contiguous().to(dev), d['shift'][..., :c].contiguous().to(dev), 'e2m1',\n"
+        "                                    smooth=d['smooth'][:c].contiguous().to(dev)).cpu()\n"
+        "    res[k + '_mx'] = tuple(t.cpu() for t in rot.adaln_rotate_quant_mx(x, d['scale'][..., :c].contiguous().to(dev),\n"
+        "                                                                      d['shift'][..., :c].contiguous().to(dev)))\n"
+        "torch.save(res, sys.argv[2])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = torch.Generator().manual_seed(78)
+    B, L = 7, 53          # batch entries of 53 rows: chunks of 12, 8 and 4 rows all end ragged
+    d = {"x16": torch.randn(B, L, 1920, generator=g).half(), "x32": torch.randn(B, L, 1920, generator=g),
+         "x2304": torch.randn(B, L, 2304, generator=g).half(),
+         "scale": (torch.randn(B, 1, 2304, generator=g) * 0.3).half(), "shift": (torch.randn(B, 1, 2304, generator=g) * 0.3).half(),
+         "smooth": torch.rand(2304, generator=g) + 0.5}
+    fin, fout = str(tmp_path / "in.pt"), str(tmp_path / "out.pt")
+    torch.save(d, fin)
+    env = dict(os.environ, FPQ_ADALN_TAIL="120", FPQ_ADALN_ROWS="12")   # tiers: 12 rows, then 8 (3 entries), then 4 (3 entries)
+    subprocess.run([sys.executable, "-c", script, fin, fout], check=True, env=env, timeout=300)
+    b = torch.load(fout)
+    for k in ("x16", "x32", "x2304"):
+        x = d[k].to(dev)
+        c = x.shape[-1]
+        sc, sh, sm = d["scale"][..., :c].contiguous().to(dev), d["shift"][..., :c].contiguous().to(dev), d["smooth"][:c].contiguous().to(dev)
+        assert_bits_equal(b[k], rot.adaln_rotate_quant(x, sc, sh, "e2m1", smooth=sm), f"{k}: tiers vs the plain grid")
+        codes, scales = rot.adaln_rotate_quant_mx(x, sc, sh)
+        assert torch.equal(b[k + "_mx"][0], codes.cpu()) and torch.equal(b[k + "_mx"][1].view(torch.int16), scales.cpu().view(torch.int16)), k
+
+
 @pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
 def test_producers_at_full_size_equal_their_slices(dev, x_dtype):
     """BASELINE-size launches ([65536 x 1920]: persistent wavefronts, several passes per wavefront, 100 batch entries of 655
