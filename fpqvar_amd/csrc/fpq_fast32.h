@@ -186,6 +186,108 @@ __global__ __launch_bounds__(kBlock) void groups32_lut_kernel(const Seg32* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// fp32 groups of 128 -> CODES + one fp32 scale per group (round 4): the quantize side of the calibration's packed
+// exchange (fpq_quant_rows_codes[_segments] on fp32 weights; calibrate.ShardedCodesCalibration).  Until now that side ran
+// codes128_kernel<float>: IEEE fp32 division + the closed form per element, ~50 vector instructions per element, 0.25 -
+// 0.30 of 8 TB/s - twice the time of the fp16-slab form it is meant to beat.  Same mapping and the same
+// approximate-then-verify quotient as groups32_lut_kernel above; the LDS table holds the CODE of each bucket (index in
+// the sorted de-duplicated table: zero_code +- level index) instead of its level, the slow path is the generic code
+// emitter's arithmetic.  Output: PACK - 4 nibbles = 2 bytes per lane and iteration (64 lanes x 2 B = one 128-byte line
+// per store instruction), else 4 bytes per lane; lane 0 of a group writes the scale.
+// ---------------------------------------------------------------------------------------------------------------
+struct CodesSeg32 {   // = CodesSeg of fpq_kernels.hip = fpq_codes_segment_t (include/fpq.h)
+  const void* x;
+  uint8_t* codes;
+  void* scales;
+  int64_t rows;
+};
+
+__device__ __forceinline__ void lut32_fill_codes(uint32_t* lut, const Lut32Args& a) {
+  const uint32_t lo_bucket = a.lo_clamp >> a.bshift, hi_bucket = a.hi_clamp >> a.bshift;
+  const uint32_t n = hi_bucket - lo_bucket + 1u, wrap = (1u << a.nbits) - 1u;
+  for (uint32_t i = threadIdx.x; i < 2u * n; i += blockDim.x) {
+    const uint32_t neg = i >= n ? 1u : 0u, b = lo_bucket + (i - neg * n);
+    const float q = b == lo_bucket ? 0.0f : quant_mag(u2f(b << a.bshift), 0u, a.f);   // everything below the smallest boundary: zero
+    const int li = level_index(q, a.f);
+    lut[(neg << a.nbits) | (b & wrap)] = (uint32_t)(neg ? a.f.zero_code - li : a.f.zero_code + li);
+  }
+}
+
+__device__ __forceinline__ void codes4_fast32(const u32x4& raw, float s, float r, bool slow, const Lut32Args& a,
+                                              const uint32_t* lut, uint32_t low_mask, uint32_t idx_mask, uint32_t (&c4)[4]) {
+  uint32_t near = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xf = u2f(raw[i]);
+    const float y0 = xf * r;
+    const float e = __builtin_fmaf(-y0, s, xf);
+    const float y = __builtin_fmaf(e, r, y0);
+    const uint32_t yb = fbits(y);
+    const uint32_t uu = (yb & 0x7FFFFFFFu) - (yb >> 31);          // negative: magnitude pattern - 1
+    uint32_t c;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(uu), "s"(a.lo_clamp), "v"(a.hi_clamp));
+    const uint32_t d = (c + 3u) & low_mask;
+    near = near < d ? near : d;
+    const uint32_t off = ((c >> (a.bshift - 2)) & idx_mask) | ((yb >> 31) << (a.nbits + 2));
+    c4[i] = *(const uint32_t*)((const char*)lut + off);
+  }
+  slow |= near <= 6u;
+  if (__builtin_amdgcn_ballot_w64(slow) != 0) {   // rare: the generic emitter's arithmetic (codes128_body)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xn = u2f(raw[i]) / s;
+      const uint32_t neg = (xn < 0.0f) ? 1u : 0u;
+      const int li = level_index(quant_mag(__builtin_fabsf(xn), neg, a.f), a.f);
+      c4[i] = (uint32_t)(neg ? a.f.zero_code - li : a.f.zero_code + li);
+    }
+  }
+}
+
+template <bool PACK, int U>
+__global__ __launch_bounds__(kBlock) void groups32_codes_kernel(const CodesSeg32* __restrict__ segs, CodesSeg32 one, Lut32Args a) {
+  __shared__ uint32_t lut[2 << kLut32MaxBits];
+  const CodesSeg32 sg = segs ? segs[blockIdx.y] : one;   // wave-uniform: scalar loads
+  const int64_t n_vec = sg.rows * 32;                     // 16-byte input vectors (4 floats)
+  if ((int64_t)blockIdx.x * (kBlock * U) >= n_vec) return;
+  const int64_t v0 = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  const u32x4* __restrict__ x = (const u32x4*)sg.x;
+  u32x4 raw[U];
+  bool live[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t v = v0 + u * kBlock;
+    live[u] = v < n_vec;
+    raw[u] = live[u] ? __builtin_nontemporal_load(x + v) : u32x4{0, 0, 0, 0};
+  }
+  lut32_fill_codes(lut, a);
+  __syncthreads();
+  const uint32_t low_mask = (1u << a.bshift) - 1u;
+  const uint32_t idx_mask = ((1u << a.nbits) - 1u) << 2;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t ab = raw[u][i] & 0x7FFFFFFFu;
+      m = m > ab ? m : ab;
+    }
+    m = group32_max(m);
+    float s, r;
+    bool slow;
+    scale_fast32(m, a.f.gmax, &s, &r, &slow);
+    slow = slow && live[u];
+    uint32_t c4[4];
+    codes4_fast32(raw[u], s, r, slow, a, lut, low_mask, idx_mask, c4);
+    const int64_t v = v0 + u * kBlock;
+    if (live[u]) {
+      if ((threadIdx.x & 31) == 0) ((float*)sg.scales)[v >> 5] = s;
+      if constexpr (PACK) ((uint16_t*)sg.codes)[v] = (uint16_t)(c4[0] | (c4[1] << 4) | (c4[2] << 8) | (c4[3] << 12));
+      else ((uint32_t*)sg.codes)[v] = c4[0] | (c4[1] << 8) | (c4[2] << 16) | (c4[3] << 24);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Long fp32 rows, one scale per row (per-channel weights of the W6A6 runs: fp6_quant_e2m3_per_token_cuda on the fp32
 // [out, in] weight, tr/quant_utils.py:808-811, result fp16).  LANES = 64: one wavefront per row (in <= 2048),
 // LANES = 256: one workgroup per row.  A lane holds vectors c * LANES + lane of its row (4 floats each, every load a

@@ -1333,6 +1333,19 @@ inline int launch_fast32(const Seg32* segs, int n_segs, const Seg32& one, int64_
   return check_launch();
 }
 
+// fp32 groups of 128 -> codes + fp32 scales: one tensor (segs == nullptr) or a device-resident segment table
+inline int launch_codes32(const CodesSeg32* segs, int n_segs, const CodesSeg32& one, int64_t max_rows, int table_id, bool pack,
+                          hipStream_t st) {
+  constexpr int U = 4;
+  const Lut32Args a = lut32_args(table_id);
+  const int64_t tiles = (max_rows * 32 + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+  if (tiles > 0x7FFFFFFF || n_segs > 65535) return FPQ_ERR_SHAPE;
+  const dim3 grid((unsigned)tiles, (unsigned)n_segs);
+  if (pack) hipLaunchKernelGGL((groups32_codes_kernel<true, U>), grid, dim3(kBlock), 0, st, segs, one, a);
+  else hipLaunchKernelGGL((groups32_codes_kernel<false, U>), grid, dim3(kBlock), 0, st, segs, one, a);
+  return check_launch();
+}
+
 // long fp32 rows (per-channel weights): one wavefront or one workgroup per row (fpq_fast32.h)
 inline bool rows32_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int table_id) {
   return in_dtype == FPQ_F32 && cols % 8 == 0 && cols >= 512 && cols / 4 <= 256 * 10 && kTables[table_id].symmetric &&
@@ -2056,6 +2069,11 @@ int fpq_quant_rows_codes(const void* x, uint8_t* codes, void* scales, int64_t ro
   if (!x || !codes || !scales) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   Fmt f = make_fmt(table_id);
+  if (in_dtype == FPQ_F32 && cols == 128 && (((uintptr_t)x | (uintptr_t)codes) & 15) == 0 && (((uintptr_t)scales) & 3) == 0 &&
+      !getenv("FPQ_NO_FAST32")) {   // fp32 weights: the approximate-then-verify path (fpq_fast32.h, groups32_codes_kernel)
+    const CodesSeg32 one = {x, codes, scales, rows};
+    return launch_codes32(nullptr, 1, one, rows, table_id, pack_nibbles != 0, st);
+  }
   if (cols == 128 && (((uintptr_t)x | (uintptr_t)codes | (uintptr_t)scales) & 15) == 0) {
     const int64_t n_vec = rows * (in_dtype == FPQ_F16 ? 16 : 32);
     const int gv = grid_for((n_vec + kBlock - 1) / kBlock, 1 << 20);
@@ -2129,6 +2147,11 @@ int fpq_quant_rows_codes_segments(const fpq_codes_segment_t* segments_device, in
   if (n_segments == 0 || max_rows == 0) return FPQ_OK;
   if (!segments_device || (((uintptr_t)segments_device) & 7) != 0) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == FPQ_F32 && !getenv("FPQ_NO_FAST32")) {   // (segments are 16-byte aligned by contract, include/fpq.h)
+    static_assert(sizeof(CodesSeg32) == sizeof(CodesSeg), "one segment layout");
+    return launch_codes32((const CodesSeg32*)segments_device, n_segments, CodesSeg32{nullptr, nullptr, nullptr, 0}, max_rows, table_id,
+                          pack_nibbles != 0, st);
+  }
   const Fmt f = make_fmt(table_id);
   const int64_t n_vec = max_rows * (in_dtype == FPQ_F16 ? 16 : 32);
   // a few vectors per thread in the largest segment: the grid's y dimension multiplies it by the segment count

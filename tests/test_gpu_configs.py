@@ -159,6 +159,65 @@ def test_fast32_groups_vs_oracle(dev, table, out_dtype):
         assert_bits_equal(ops.quant_rows(x[:rows].to(dev), table, 128, out_dtype), want[:rows], f"fast32 {table} rows={rows}")
 
 
+@pytest.mark.parametrize("pack", (False, True))
+@pytest.mark.parametrize("table", SYM)
+def test_fast32_codes_vs_generic_emitter_and_oracle(dev, table, pack):
+    """fp32 groups -> codes + fp32 scales through the approximate-then-verify path (groups32_codes_kernel, round 4) against
+    the generic emitter (FPQ_NO_FAST32=1, read per call: IEEE division + closed form) on the boundary-saturated groups and
+    the edge rows of test_fast32_groups_vs_oracle, and decoded against the oracle's values."""
+    import os
+    from fpqvar_amd import ops
+    if pack and table in ("e2m3", "e3m2"):
+        pytest.skip("FP6 codes do not fit a nibble")
+    g = torch.Generator().manual_seed(43)
+    parts = [torch.randn(300, 128, generator=g) * 0.02, _boundary_groups(table), _boundary_groups(table) * 0.0371,
+             _boundary_groups(table) * 3.0e-20, _boundary_groups(table) * 1.7e19]
+    edge = torch.randn(14, 128, generator=g)
+    edge[0] = 0.0
+    edge[1, 5] = float("nan")
+    edge[2, 7] = float("inf")
+    edge[3, 9] = float("-inf")
+    edge[4] *= 1e-41
+    edge[5] *= 1e-38
+    edge[6] *= 3e38 / 6
+    edge[7, ::2] = -0.0
+    edge[8] = 1e-45
+    edge[9, 1:] = 0.0
+    edge[10] = -edge[10].abs()
+    edge[11] = edge[11].abs()
+    edge[12] *= 1e-30
+    edge[13] *= 1e30
+    parts.append(edge)
+    x = torch.cat(parts).to(dev)
+    for rows in (x.shape[0], 1, 31, 33):
+        xr = x[:rows].contiguous()
+        codes, scales = ops.quant_rows_codes(xr, table, 128, pack)
+        os.environ["FPQ_NO_FAST32"] = "1"
+        try:
+            codes_g, scales_g = ops.quant_rows_codes(xr, table, 128, pack)
+        finally:
+            del os.environ["FPQ_NO_FAST32"]
+        assert torch.equal(codes, codes_g), f"{table} pack={pack} rows={rows}: codes differ from the generic emitter"
+        assert_bits_equal(scales, scales_g, f"{table} pack={pack} rows={rows}: scales")
+        deq = ops.dequant_rows_codes(codes, scales, table, 128, torch.float32, pack)
+        assert_bits_equal(deq, orc.per_group_kernel_sem(xr.cpu(), table, 128), f"{table} pack={pack} rows={rows}: decoded values vs oracle")
+
+
+def test_fast32_codes_equal_generic_on_64m_weights(dev):
+    import os
+    from fpqvar_amd import ops
+    g = torch.Generator(device=dev).manual_seed(6)
+    for kind in ("weights", "uniform"):
+        x = torch.randn(1 << 26, device=dev, generator=g) * 0.02 if kind == "weights" else (torch.rand(1 << 26, device=dev, generator=g) * 2 - 1)
+        codes, scales = ops.quant_rows_codes(x.view(-1, 128), "e2m1", 128, True)
+        os.environ["FPQ_NO_FAST32"] = "1"
+        try:
+            codes_g, scales_g = ops.quant_rows_codes(x.view(-1, 128), "e2m1", 128, True)
+        finally:
+            del os.environ["FPQ_NO_FAST32"]
+        assert torch.equal(codes, codes_g) and torch.equal(scales.view(torch.int32), scales_g.view(torch.int32)), kind
+
+
 def test_fast32_equals_ieee_path_on_64m_weights(dev):
     """Fast path (approximate division + verification) against the generic kernel (IEEE division) on 2^26 random
     weights per distribution, on the GPU: bit-equal, i.e. every value the approximation cannot decide was caught."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE kernel a few times (for rocprofv3 --pmc passes).
-usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
+usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|token6|group6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -62,6 +62,12 @@ elif which == "calib":
 elif which == "channel":
     x = torch.randn(32768, C, device=dev) * 0.02
     fn = lambda: ops.quant_rows(x, "e2m3", C, torch.float16)
+elif which == "token6":   # per-token E2M3 on rows of 1920 (the W6A6 activations): one wavefront per row, 2 x 512-bucket table in LDS
+    xs = [torch.randn(65536, C, device=dev).half() for _ in range(3)]
+    fn = lambda: ops.quant_rows(nxt(xs), "e2m3", C, torch.float16)
+elif which == "group6":   # per-group(128) E2M3
+    xs = [torch.randn(65536, C, device=dev).half() for _ in range(3)]
+    fn = lambda: ops.quant_rows(nxt(xs), "e2m3", 128, torch.float16)
 elif which == "dual6":
     x = torch.nn.functional.gelu(torch.randn(65536, 4 * C, device=dev)).half()
     fn = lambda: ops.quant_rows_dual(x, "int_neg", "e2m3_pos", 128, None)
