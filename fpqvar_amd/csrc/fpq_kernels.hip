@@ -746,6 +746,61 @@ template <typename Ts, typename Tout, bool PACK>
 __device__ __forceinline__ void decode128_body(const uint8_t* __restrict__ codes, const Ts* __restrict__ scales,
                                                Tout* __restrict__ out, int64_t n_oct, const Fmt& fs) {
   const int nsub = (int)(fs.kmin * fs.inv_step0);
+  if constexpr (PACK) {
+    // nibble codes (round 4): the two signed levels of every code BYTE from a 256-entry table in LDS, filled once per
+    // workgroup from the closed form below - shift, mask, one 8-byte LDS read and two multiplies per pair instead of ~24
+    // vector instructions (the decode side of the calibration's packed exchange ran at 0.45 of 8 TB/s on them)
+    __shared__ float pair_lut[256][2];
+    {
+      const int t = threadIdx.x;   // kBlock == 256: one entry per thread
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int li = (int)((t >> (4 * h)) & 15) - fs.zero_code;
+        const uint32_t neg = li < 0;
+        li = neg ? -li : li;
+        const float q = (li < nsub) ? (float)li * fs.step0 : u2f(((uint32_t)li + fs.kmin_code_base) << fs.mshift);
+        pair_lut[t][h] = neg ? -q : q;
+      }
+    }
+    __syncthreads();
+    // tiles of U x 256 octets: all of a tile's code words are requested before the first is decoded (one octet per
+    // thread and trip, as before, cycled workgroups that write 4 KiB each - the rate of the headline quantizer's
+    // workgroups, which move twice that)
+    constexpr int U = 4;
+    const int64_t n_tiles = (n_oct + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const int64_t v0 = tile * ((int64_t)kBlock * U) + threadIdx.x;
+      uint32_t w[U];
+      float s[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = v0 + u * kBlock;
+        w[u] = v < n_oct ? __builtin_nontemporal_load((const uint32_t*)codes + v) : 0u;
+        s[u] = v < n_oct ? load_scalar<Ts>(scales + (v >> 4)) : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = v0 + u * kBlock;
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t off = j == 0 ? (w[u] << 3) & 0x7F8u : (w[u] >> (8 * j - 3)) & 0x7F8u;   // byte j of the word, times 8
+          const v2f_t q = *(const v2f_t*)((const char*)pair_lut + off);
+          p[2 * j] = q[0] * s[u];
+          p[2 * j + 1] = q[1] * s[u];
+        }
+        if (v < n_oct) {
+          if constexpr (sizeof(Tout) == 2) {
+            __builtin_nontemporal_store(u32x4{f2h2(p[0], p[1]), f2h2(p[2], p[3]), f2h2(p[4], p[5]), f2h2(p[6], p[7])}, (u32x4*)out + v);
+          } else {
+            __builtin_nontemporal_store(u32x4{fbits(p[0]), fbits(p[1]), fbits(p[2]), fbits(p[3])}, (u32x4*)out + 2 * v);
+            __builtin_nontemporal_store(u32x4{fbits(p[4]), fbits(p[5]), fbits(p[6]), fbits(p[7])}, (u32x4*)out + 2 * v + 1);
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_oct; v += (int64_t)gridDim.x * kBlock) {
     uint32_t c[8];
     if constexpr (PACK) {
@@ -2110,7 +2165,8 @@ int fpq_dequant_rows_codes(const uint8_t* codes, const void* scales, void* out, 
   Fmt f = make_fmt(table_id);
   if (cols == 128 && (((uintptr_t)out | (uintptr_t)codes) & 15) == 0) {
     const int64_t n_oct = rows * 16;
-    const int gv = grid_for((n_oct + kBlock - 1) / kBlock, 1 << 20);
+    const int64_t per_wg = pack_nibbles ? 4 * kBlock : kBlock;   // the nibble form decodes tiles of 4 x 256 octets
+    const int gv = grid_for((n_oct + per_wg - 1) / per_wg, 1 << 20);
 #define FPQ_DEC(TS, TO, PK) hipLaunchKernelGGL((decode128_kernel<TS, TO, PK>), dim3(gv), dim3(kBlock), 0, st, codes, (const TS*)scales, (TO*)out, n_oct, f)
     if (scale_dtype == FPQ_F16 && out_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DEC(_Float16, _Float16, true); else FPQ_DEC(_Float16, _Float16, false); }
     else if (scale_dtype == FPQ_F16) { if (pack_nibbles) FPQ_DEC(_Float16, float, true); else FPQ_DEC(_Float16, float, false); }
