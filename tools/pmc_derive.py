@@ -42,13 +42,13 @@ def main():
     c = {}
     for k in ("p1", "p2", "p3", "p4"):
         c.update(counters(f"{d}/{k}.summary.txt"))
-    t_ns = None
+    t_ns, best_total = None, -1.0
     try:
-        for r in csv.reader(open(f"{d}/kernel_stats.csv")):
-            if r and ("_GLOBAL__N_" in r[0] or "anonymous namespace" in r[0]) and "zero_if_flag" not in r[0]:
-                t_ns = float(r[3])   # Name, Calls, TotalDurationNs, AverageNs, ...
-                break
-    except OSError:
+        for r in csv.reader(open(f"{d}/kernel_stats.csv")):   # Name, Calls, TotalDurationNs, AverageNs, ...
+            ours = r and ("_GLOBAL__N_" in r[0] or r[0].startswith("void (anonymous namespace)::")) and "at::native" not in r[0]
+            if ours and "zero_if_flag" not in r[0] and float(r[2]) > best_total:   # this library's kernel with the most time
+                best_total, t_ns = float(r[2]), float(r[3])
+    except (OSError, ValueError, IndexError):
         pass
     print(f"# derived ({what}; {n} elements, {bpe:.3f} algorithmic B/element = {n * bpe / 1e6:.1f} MB per launch):")
     if t_ns:
