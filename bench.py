@@ -770,7 +770,7 @@ def own_all(shapes, own, dev):
 def pmc_traffic():
     """HBM bytes per launch of the headline kernel.  NOT measured by this process (rocprofv3 counters cannot be read
     from inside the run): the figure of the committed rocprofv3 --pmc passes of this same command, with its source."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -821,6 +821,10 @@ def build_result(args, world, elems, elapsed, kernel_ms, calib, rccl_ranks, data
                                         "measurement of this timed region") if traffic_src else None,
                      "kernel": headline_kernel_label(),
                      "kernel_ms": round(kernel_ms, 5),
+                     "clocks": "two clocks in this line: roofline.achieved / frac use kernel_ms = HIP events on the launch stream "
+                               "around the K timed launches / K (the kernel's average launch duration); value / ms_per_step use "
+                               "the host's wall clock around the same K launches including the closing synchronize and, at N > 1, "
+                               "the barriers (the contract's whole-job figure); the first is the larger by the host's share",
                      "algorithmic_bytes": elems * BYTES_PER_ELEM},
     }
     if calib is not None:
