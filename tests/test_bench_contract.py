@@ -195,3 +195,29 @@ def test_bench_reports_a_blocked_collective_as_failure(tmp_path):
     res = json.loads(lines[0])
     assert "timeout" in res["weight_calibration"]["error"] and "all_gather" in res["weight_calibration"]["error"]
     assert res["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_generation_steps_record():
+    """bench.generation_steps (the bench line's config3_steps / config5_steps): ten steps, the three kernels, bytes and fractions
+    that follow from the times, the dual quantizer's scratch back at zero, and the compact summary the line carries."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    for model, rows0, cols in (("d30", 100, 1920), ("d36-512", 20, 2304)):
+        full = bench.generation_steps(dev, model, "fp32", "rotating", replays=3)
+        assert [s["rows"] for s in full["steps"]][0] == rows0 and len(full["steps"]) == 10
+        last = full["steps"][-1]
+        assert last["adaln"]["bytes"] == last["rows"] * cols * 6 and last["act"]["bytes"] == last["rows"] * cols * 4
+        assert last["dual"]["bytes"] == last["rows"] * 4 * cols * 4
+        for s in full["steps"]:
+            for k in ("adaln", "act", "dual"):
+                assert 0.5 < s[k]["us"] < 1000 and 0.0 < s[k]["frac_of_8TBps"] < 1.0, (model, s["rows"], k, s[k])
+                assert abs(s[k]["frac_of_8TBps"] - s[k]["bytes"] / s[k]["us"] / 1e3 / 8000.0) < 2e-3
+        assert last["act"]["frac_of_8TBps"] > 0.5 and last["dual"]["frac_of_8TBps"] > 0.5 and last["adaln"]["frac_of_8TBps"] > 0.4
+        tw = full["time_weighted_frac_of_8TBps"]
+        assert 0.3 < tw < 0.9 and abs(tw - full["bytes_per_block"] / full["block_us_over_the_ten_steps"] / 1e3 / 8000.0) < 1e-3
+        summ = bench.steps_summary(full)
+        assert summ["time_weighted_frac_of_8TBps"] == tw and len(summ["adaln_us"]) == 10 and set(summ["by_kernel"]) == {"adaln", "act", "dual"}
+        json.dumps(summ)
