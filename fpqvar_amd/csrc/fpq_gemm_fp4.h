@@ -261,18 +261,36 @@ FPQ_NOPK __device__ __forceinline__ int glds_chunk_perm(int q) { return (0x78 >>
 template <typename Tsw, int BM, int BN, int NTHR>
 FPQ_NOPK __device__ __forceinline__ void load_scale_tiles(const _Float16* __restrict__ sa, const Tsw* __restrict__ sw, float* lsa,
                                                  float* lsw, int t0, int o0, int T, int O, int G, int tid) {
+  // a row's scales in batches of GB loads, all in flight before the first is stored (round 4; batches of 5 were three
+  // dependent trips to L2 for the 15 groups of C = 1920 in a prologue that every tile waits for)
+#ifndef FPQ_GEMM_SCALE_BATCH
+#define FPQ_GEMM_SCALE_BATCH 16
+#endif
+  constexpr int GB = FPQ_GEMM_SCALE_BATCH;
   for (int r = tid; r < BM + BN; r += NTHR) {
     if (r < BM) {   // wave-uniform: BM is a multiple of 64
       const bool ok = t0 + r < T;
       const _Float16* src = sa + (int64_t)(ok ? t0 + r : 0) * G;
-#pragma unroll 5
-      for (int g = 0; g < G; ++g) lsa[g * BM + r] = ok ? (float)src[g] : 0.0f;
+      for (int g0 = 0; g0 < G; g0 += GB) {
+        _Float16 v[GB];
+#pragma unroll
+        for (int i = 0; i < GB; ++i) v[i] = src[g0 + i < G ? g0 + i : G - 1];
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+          if (g0 + i < G) lsa[(g0 + i) * BM + r] = ok ? (float)v[i] : 0.0f;
+      }
     } else {
       const int c = r - BM;
       const bool ok = o0 + c < O;
       const Tsw* src = sw + (int64_t)(ok ? o0 + c : 0) * G;
-#pragma unroll 5
-      for (int g = 0; g < G; ++g) lsw[g * BN + c] = ok ? (float)src[g] : 0.0f;
+      for (int g0 = 0; g0 < G; g0 += GB) {
+        Tsw v[GB];
+#pragma unroll
+        for (int i = 0; i < GB; ++i) v[i] = src[g0 + i < G ? g0 + i : G - 1];
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+          if (g0 + i < G) lsw[(g0 + i) * BN + c] = ok ? (float)v[i] : 0.0f;
+      }
     }
   }
 }
