@@ -239,6 +239,44 @@ __device__ __forceinline__ uint32_t pk_fma0_f16(uint32_t a, uint32_t b) {   // a
   const h2_t z = {(_Float16)0.0f, (_Float16)0.0f};
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), z));
 }
+// FP6 levels without a table (round 4), for a lane that holds exactly 32 quotients (16 packed words): the FP6 conversion
+// hardware takes two tuples of 16 floats, writes 32 six-bit codes (v_cvt_scalef32_2xpk16_{fp6,bf6}_f32: E2M3 / E3M2) and
+// decodes them again (v_cvt_scalef32_pk32_f16_{fp6,bf6}).  It rounds to nearest-even; the reference's scan sends a tie to
+// the LARGER value: float(xn) + 2^-17 - exact in fp32 for |xn| < 2^6, far below the distance of any fp16 value from a
+// rounding threshold (thresholds are multiples of 2^-5 (E2M3) / 2^-6 (E3M2), fp16 values near them multiples of 2^-14 or
+// coarser) - removes every tie towards the larger value and moves nothing else: tools/probe/cvt_fp6_probe.hip runs all
+// 63 488 finite fp16 inputs through it against the scan (profiles/r03_cvt_fp6_probe.txt: 0 mismatches but -0 for inputs in
+// (-step/2, 0), which the dequantizing fma with +0 repairs, as for E2M1).  Non-finite quotients saturate where the scan
+// gives 0: they only occur under a non-finite scale, which scale_nan_if_not_finite turns into NaN (the reference's 0 * inf).
+// ~2.2 pipe cycles per element each way (70 per instruction) + the bias: about the cost of the table lookups it
+// replaces - what it buys is the staging of 2 KiB of table per workgroup, its barrier, and the LDS latency in every
+// wavefront's short life (profiles/r04_pmc_token6.txt: the table form is not bound by vector issue, 39 % busy).
+typedef uint32_t fp6_u16v_t __attribute__((ext_vector_type(16)));
+typedef uint32_t fp6_u6v_t __attribute__((ext_vector_type(6)));
+typedef float fp6_f16v_t __attribute__((ext_vector_type(16)));
+template <bool BF6>
+__device__ __forceinline__ void fp6_levels_hw32(const uint32_t (&xn)[16], uint32_t (&lv)[16]) {
+  // the two source tuples INTERLEAVE in the result: code 2 i comes from a[i], code 2 i + 1 from b[i] (seen on hardware with
+  // distinct inputs - the probe's neighbouring patterns quantize alike and hid it): a = the low halves, b = the high halves
+  fp6_f16v_t a, b;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    a[j] = fmaf_h_lo(xn[j], 1.0f, 0x1p-17f);
+    b[j] = fmaf_h_hi(xn[j], 1.0f, 0x1p-17f);
+  }
+  fp6_u6v_t c;
+  fp6_u16v_t d;
+  if constexpr (BF6) {
+    asm("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, 1.0" : "=&v"(c) : "v"(a), "v"(b));   // early clobber: a multi-pass
+    asm("v_cvt_scalef32_pk32_f16_bf6 %0, %1, 1.0" : "=&v"(d) : "v"(c));                  // instruction must not write over its sources
+  } else {
+    asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, 1.0" : "=&v"(c) : "v"(a), "v"(b));
+    asm("v_cvt_scalef32_pk32_f16_fp6 %0, %1, 1.0" : "=&v"(d) : "v"(c));
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) lv[j] = d[j];
+}
+
 // Quantize the 8 halves of one 16-byte vector.  s16x2 = scale replicated in both halves; inv_hi + inv_lo = 1 / scale
 // (0 for a zero scale).  In DUAL mode each element picks the negative or positive side's scale.
 __device__ __forceinline__ uint32_t fbits16(float f) { return __builtin_bit_cast(uint32_t, f); }
@@ -826,17 +864,24 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
 
 // Medium rows (<= 64*MAXC vectors, e.g. per-token 1920 = 240 vectors): one WAVEFRONT per row, the
 // row max by DPP/shuffles only - no LDS, no barrier in the row loop.
-template <bool DUAL, int MAXC, bool TAB_ARG>
+// HW6 (1: E2M3, 2: E3M2; rows of 193 .. 256 vectors = exactly 4 per lane, symmetric table): the levels from the FP6
+// conversion hardware (fp6_levels_hw32) - no table, no LDS, no barrier.
+template <bool DUAL, int MAXC, bool TAB_ARG, int HW6 = 0>
 __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t* __restrict__ x,
                                                                 uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                                                 Lut16Args a, Lut16Tab tab) {
-  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
-  if (TAB_ARG) {
-    lut16_stage(lut, tab, a.shift);
-  } else {
-    lut16_fill(lut, a);
+  static_assert(HW6 == 0 || (!DUAL && MAXC == 4), "hardware FP6 levels: symmetric tables, 32 elements per lane");
+  uint16_t* lut = nullptr;
+  if constexpr (HW6 == 0) {
+    __shared__ __attribute__((aligned(16))) uint16_t lut_s[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
+    lut = lut_s;
+    if (TAB_ARG) {
+      lut16_stage(lut, tab, a.shift);
+    } else {
+      lut16_fill(lut, a);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t vpr = cols >> 3;
   constexpr int R = kBlock / 64;
@@ -890,6 +935,23 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t*
       m = row_max_dpp<64>(m);
       sn = row_scale16(m, a.fpos.gmax, a.inv_gpos);
       sp = sn;
+    }
+    if constexpr (HW6 != 0) {
+      scale_nan_if_not_finite(sn);
+      uint32_t q[16], lv[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[4 * c + k] = div_pair16(raw[c][k], sn.inv, sn.inv_lo, sn.inv, sn.inv_lo);
+      fp6_levels_hw32<HW6 == 2>(q, lv);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t v = (int64_t)c * 64 + lane;
+        if (v < vpr)
+          __builtin_nontemporal_store(u32x4{pk_fma0_f16(lv[4 * c], sn.s16x2), pk_fma0_f16(lv[4 * c + 1], sn.s16x2),
+                                            pk_fma0_f16(lv[4 * c + 2], sn.s16x2), pk_fma0_f16(lv[4 * c + 3], sn.s16x2)}, orow + v);
+      }
+      continue;
     }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {

@@ -1330,6 +1330,21 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
     if (g > capw) g = capw;
 #define FPQ_WAVE(M) do { if (h.tab_valid) hipLaunchKernelGGL((rows16_lut_wave_kernel<DUAL, M, true>), dim3((unsigned)g), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out, rows, cols, args, h.tab); \
                          else hipLaunchKernelGGL((rows16_lut_wave_kernel<DUAL, M, false>), dim3((unsigned)g), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out, rows, cols, args, h.tab); } while (0)
+    // rows of exactly four vectors per lane on E2M3 / E3M2 (per-token FP6 at C = 1920, 2048): levels from the FP6
+    // conversion hardware, no table (fpq_fast16.h, fp6_levels_hw32); FPQ_NO_HW6 (read at every call) keeps the table
+    if constexpr (!DUAL) {
+      if (mc == 4 && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !getenv("FPQ_NO_HW6")) {
+        int64_t g6 = (rows + 3) / 4;
+        if (g6 > (1 << 20)) g6 = 1 << 20;   // nothing to amortise: one pass of four rows per workgroup
+        if (neg_id == FPQ_E2M3)
+          hipLaunchKernelGGL((rows16_lut_wave_kernel<false, 4, true, 1>), dim3((unsigned)g6), dim3(kBlock), lds, st, (const uint16_t*)x,
+                             (uint16_t*)out, rows, cols, args, h.tab);
+        else
+          hipLaunchKernelGGL((rows16_lut_wave_kernel<false, 4, true, 2>), dim3((unsigned)g6), dim3(kBlock), lds, st, (const uint16_t*)x,
+                             (uint16_t*)out, rows, cols, args, h.tab);
+        return check_launch();
+      }
+    }
     if (mc <= 1) FPQ_WAVE(1);
     else if (mc <= 2) FPQ_WAVE(2);
     else if (mc <= 4) FPQ_WAVE(4);

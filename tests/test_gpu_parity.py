@@ -414,6 +414,53 @@ def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, monkeypatch):
     assert len(distinct_out) > 1000                                   # the sweep really produced a spread of results
 
 
+@pytest.mark.parametrize("table", ("e2m3", "e3m2"))
+def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, monkeypatch):
+    """The per-token FP6 quantizer on rows of 1920 (W6A6 activations) takes its levels from the FP6 conversion hardware since
+    round 4 (rows16_lut_wave_kernel<HW6>, fp6_levels_hw32: float(xn) + 2^-17 in front of a round-to-nearest-even conversion).
+    EVERY (row maximum, element) pair of finite fp16 values through it, through the table form (FPQ_NO_HW6=1, read at
+    every call) and through the generic kernel (IEEE division + closed form, selected by asking for a float32 result)."""
+    from fpqvar_amd import ops
+    cols = 1920
+    per = cols - 1
+    total = 0
+    step = 1024
+    for lo in range(0, 0x7C00, step):
+        p = torch.arange(lo, min(lo + step, 0x7C00), device=dev, dtype=torch.int64)          # maxima, as bit patterns
+        n_val = 2 * (p + 1)                                                                  # signed candidates <= max
+        n_row = (n_val + per - 1) // per
+        gm = torch.repeat_interleave(p, n_row)
+        first = torch.cumsum(n_row, 0) - n_row
+        start = (torch.arange(gm.numel(), device=dev) - torch.repeat_interleave(first, n_row)) * per
+        idx = start[:, None] + torch.arange(per, device=dev)[None, :]
+        ok = idx < (2 * (gm + 1))[:, None]
+        pat = torch.where(ok, (idx >> 1) | ((idx & 1) << 15), torch.zeros_like(idx))
+        x = torch.cat([gm[:, None], pat], dim=1).to(torch.int32).to(torch.int16).view(torch.float16)
+        fast = ops.quant_rows(x, table, cols, torch.float16)
+        ieee = ops.quant_rows(x, table, cols, torch.float32).half()
+        bad = fast.view(torch.int16) != ieee.view(torch.int16)
+        assert not bool(bad.any()), (table, lo, x[bad][:4].tolist(), fast[bad][:4].tolist(), ieee[bad][:4].tolist())
+        with monkeypatch.context() as m:
+            m.setenv("FPQ_NO_HW6", "1")
+            tab = ops.quant_rows(x, table, cols, torch.float16)
+        assert torch.equal(fast.view(torch.int16), tab.view(torch.int16)), (table, lo, "hardware levels vs table form")
+        total += int(ok.sum())
+    assert total == sum(2 * (q + 1) for q in range(0x7C00)) == 1_007_713_280
+    # rows with non-finite and zero content, ragged row counts (1 .. 9 rows: partial workgroups)
+    g = torch.Generator().manual_seed(12)
+    e = torch.randn(9, cols, generator=g).half()
+    e[1] = 0.0
+    e[2, 5] = float("nan")
+    e[3, 7] = float("inf")
+    e[4, 9] = float("-inf")
+    e[5] *= 1e-4
+    e[6, ::2] = -0.0
+    e[7] = -e[7].abs() * 1e-3
+    for rows in (9, 1, 3):
+        assert_bits_equal(ops.quant_rows(e[:rows].to(dev), table, cols, torch.float16),
+                          orc.per_token_kernel_sem(e[:rows], table), f"{table} edge rows={rows}")
+
+
 # ------------------------------------------------------------------ shapes, raggedness, errors
 def test_edge_shapes_and_errors(dev, qu):
     from fpqvar_amd import ops
