@@ -563,13 +563,16 @@ struct AdalnTiers {
 // (they are contiguous in memory: the loads, the image, the transform and the stores do not know) - with LayerNorm
 // statistics and the modulation per half.  One row per tile leaves half of every epilogue instruction's lanes idle:
 // 0.53 of 8 TB/s at [32768 x 1024] (profiles/r03_survey_shapes.txt).
-template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN, bool X32, bool HW4, bool TIGHT = false, int NW = 4, bool PAIR2 = false>
+// HW6 (1: E2M3, 2: E3M2; value output, rows of at most 16 groups): the levels of a lane's 32 outputs from the FP6 conversion
+// hardware (fpq_fast16.h, fp6_levels_hw32) - per group and per token alike; no table is staged.
+template <typename Tmod, int MAXC, bool CODES, bool EMIT, bool TOKEN, bool X32, bool HW4, bool TIGHT = false, int NW = 4, bool PAIR2 = false, int HW6 = 0>
 __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ? 5 : 4) void adaln_mfma_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out,
                                                               u32x4* __restrict__ h_out, u32x4* __restrict__ y_out,
                                                               int64_t rows, AdaLnArgs ad, RotArgs r, Lut16Args a,
                                                               Lut16Tab tab, AdalnTiers tiers) {
   static_assert(MAXC >= 1 && MAXC <= 5, "rows of at most 20 groups");
   static_assert(!HW4 || !TOKEN, "hardware E2M1 levels / codes: per group only");
+  static_assert(HW6 == 0 || (!HW4 && !CODES && MAXC <= 4 && !PAIR2), "hardware FP6 levels: values of one tile");
   static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 31 KiB form: fp16 rows of 15 groups, no table");
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   static_assert(NW == 4, "four wavefronts per workgroup");
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
   constexpr int INS = TIGHT ? kRqOutStride : kRqInStride;
   constexpr bool DB = FPQ_ADALN_DB && !X32 && !EMIT;
   uint16_t* lut = nullptr;                       // symmetric tables only: at most 2 x 512 buckets (E2M3)
-  if constexpr (!HW4) {
+  if constexpr (!HW4 && HW6 == 0) {
     __shared__ __attribute__((aligned(16))) uint16_t lut_s[1024];
     lut = lut_s;
   }
@@ -1045,6 +1048,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
         if constexpr (MAXC == 5) scale_nan_if_not_finite(s1);
       }
     }
+    if constexpr (HW6 != 0) scale_nan_if_not_finite(s);
     FPQ_STAMP(5);                                   // group maximum across the quarters, scale and its reciprocal
     // MAXC == 5: this lane's chunk of groups 16 .. 19 - of this row, or (closing a pair) lanes 0 .. 31 the parked row's
     // and lanes 32 .. 63 this row's
@@ -1102,6 +1106,18 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
         }
       }
     } else {
+      if constexpr (HW6 != 0) {
+        uint32_t q6[16], lv6[16];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) q6[2 * c + rr] = div_pair16(yw[c][rr], s.inv, s.inv_lo, s.inv, s.inv_lo);
+        fp6_levels_hw32<HW6 == 2>(q6, lv6);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) yw[c][rr] = pk_fma0_f16(lv6[2 * c + rr], s.s16x2);
+      } else
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -1171,7 +1187,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
     __builtin_amdgcn_sched_barrier(0);
     stage_load(b, sraw);
   }
-  if constexpr (!HW4) lut16_stage(lut, tab, a.shift);
+  if constexpr (!HW4 && HW6 == 0) lut16_stage(lut, tab, a.shift);
   stage_store(sraw);
   __syncthreads();
 #else

@@ -1185,12 +1185,28 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       // E2M1 values per group: levels from the FP4 conversion hardware, no table (fpq_adaln.h)
       const bool hw4 = table_id == FPQ_E2M1 && !token_mode && !getenv("FPQ_NO_HW4");
       static const bool tight_ok = FPQ_ADALN_TIGHT && !FPQ_ENV("FPQ_ADALN_NO_TIGHT");
+      // E2M3 / E3M2 values (per group, or per token: token_mode 1): levels from the FP6 conversion hardware, no table
+      const int hw6 = (token_mode <= 1 && !code_scales && !getenv("FPQ_NO_HW6")) ? (table_id == FPQ_E2M3 ? 1 : table_id == FPQ_E3M2 ? 2 : 0) : 0;
 #define FPQ_ADALN3(M, CODES, EMIT, TOKEN, HW4, TIGHT)                                                                  \
   hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, CODES, EMIT, TOKEN, X32, HW4, TIGHT>), g3, dim3(kBlock), lds2, st,    \
                      (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, tiers)
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
     if (!adaln_butterfly) {                                                                                            \
+      if constexpr (M == 4 && !(CODES) && !(EMIT)) {   /* E2M3 / E3M2 values, rows of 13 .. 16 groups: hardware levels */ \
+        if (hw6 == 1) {                                                                                                \
+          hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, 4, false, false, TOKEN, X32, false, false, 4, false, 1>), g3,    \
+                             dim3(kBlock), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,       \
+                             rows, ad, r, h.args, tab, tiers);                                                         \
+          break;                                                                                                       \
+        }                                                                                                              \
+        if (hw6 == 2) {                                                                                                \
+          hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, 4, false, false, TOKEN, X32, false, false, 4, false, 2>), g3,    \
+                             dim3(kBlock), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,       \
+                             rows, ad, r, h.args, tab, tiers);                                                         \
+          break;                                                                                                       \
+        }                                                                                                              \
+      }                                                                                                                \
       if constexpr (M == 2 && !X32 && !(EMIT) && !(TOKEN)) {                                                           \
         if (pair2) {                                                                                                   \
           if (hw4)                                                                                                     \

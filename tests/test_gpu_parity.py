@@ -844,6 +844,42 @@ def test_rotate_butterfly_switch(dev, tmp_path):
     assert_bits_equal(o, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "matrix-core form: quant of rotated")
 
 
+@pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
+@pytest.mark.parametrize("table", ("e2m3", "e3m2"))
+def test_adaln_fp6_hardware_levels_equal_the_table_form(dev, table, x_dtype, monkeypatch):
+    """The adaLN producer's E2M3 / E3M2 value outputs (per group and per token, rows of 13 .. 16 groups) take their levels
+    from the FP6 conversion hardware since round 4; FPQ_NO_HW6=1 (read at every call) keeps the bucket table: bit-equal,
+    including rows with non-finite values, all-zero rows and ragged batch entries; and the quantization is the oracle's on
+    the rotated rows the kernel emits."""
+    from fpqvar_amd import rotation as rot
+    g = torch.Generator().manual_seed(90)
+    B, L, C = 5, 23, 1920
+    x = (torch.randn(B, L, C, generator=g) * torch.exp(0.5 * torch.randn(B, L, C, generator=g))).to(x_dtype)
+    x[0, 1] = 0.0
+    x[1, 2, 77] = float("inf")
+    x[2, 3, 5] = float("nan")
+    x[3, 4] *= 1e-3
+    sc = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    sh = (torch.randn(B, 1, C, generator=g) * 0.3).half().to(dev)
+    sm = (torch.rand(C, generator=g) + 0.5).to(dev)
+    xd = x.to(dev)
+
+    def both(fn):
+        a = fn()
+        with monkeypatch.context() as m:
+            m.setenv("FPQ_NO_HW6", "1")
+            b = fn()
+        return a, b
+    a, b = both(lambda: rot.adaln_rotate_quant(xd, sc, sh, table, smooth=sm))
+    assert_bits_equal(a, b, f"adaLN {table} per group: hardware levels vs table")
+    a, b = both(lambda: rot.adaln_rotate_quant_token(xd, sc, sh, table, smooth=sm))
+    assert_bits_equal(a, b, f"adaLN {table} per token: hardware levels vs table")
+    out, h, y = rot.adaln_rotate_quant(xd, sc, sh, table, smooth=sm, return_intermediates=True)   # the emitting (table) form
+    assert_bits_equal(rot.adaln_rotate_quant(xd, sc, sh, table, smooth=sm), out, "emit vs no-emit")
+    assert_bits_equal(out, orc.per_group_kernel_sem(y.cpu().reshape(-1, C), table, 128, out_dtype=torch.float16).view_as(out),
+                      f"adaLN {table}: quantization of the rotated rows vs oracle")
+
+
 def test_adaln_tail_tiers_switch(dev, tmp_path):
     """FPQ_ADALN_TAIL / FPQ_ADALN_ROWS (read once per process, hence a child process): the last batch entries of the grid cut
     into finer tiers of 8 and 4 rows per workgroup - off by default (profiles/r03_adaln_partition.txt: never faster), but
