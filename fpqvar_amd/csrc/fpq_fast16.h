@@ -513,12 +513,15 @@ inline void lut16_build_host(uint16_t* lut, const Lut16Args& a) {
 // maximum read from a device scalar (fpq_absmax) - two packed instructions per pair on the fast path instead of the
 // generic kernel (0.23 -> of 8 TB/s, profiles/r03_survey_shapes.txt).  Group maxima are taken on the raw words (a NaN
 // is still seen) and clamped afterwards (clamping is monotonic).
-template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true, bool HW4 = false, bool CLIP = false>
+// HW6 (1: E2M3, 2: E3M2; U = 4: a lane's four vectors are the 32 values of one FP6 conversion, each with the scale of its own
+// row): levels from the FP6 conversion hardware (fp6_levels_hw32) - no table, no LDS, no barrier.
+template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true, bool HW4 = false, bool CLIP = false, int HW6 = 0>
 __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4* __restrict__ x,
                                                                    u32x4* __restrict__ out, int64_t n_vec,
                                                                    Lut16Args a, Lut16Tab tab) {
+  static_assert(HW6 == 0 || (U == 4 && !DUAL && !HW4 && !CLIP), "hardware FP6 levels: symmetric tables, four vectors per lane");
   uint16_t* lut = nullptr;
-  if constexpr (!HW4) {
+  if constexpr (!HW4 && HW6 == 0) {
     __shared__ __attribute__((aligned(16))) uint16_t lut_s[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
     lut = lut_s;
   }
@@ -541,6 +544,29 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
       int64_t v = v0 + u * kBlock;
       live[u] = v < n_vec;
       raw[u] = live[u] ? (NTL ? __builtin_nontemporal_load(x + v) : x[v]) : u32x4{0, 0, 0, 0};
+    }
+    if constexpr (HW6 != 0) {
+      uint32_t q6[16], lv6[16], sc6[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t m = row_max_dpp<LPR>(vec_absmax16(raw[u]));
+        RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+        scale_nan_if_not_finite(s);
+        sc6[u] = s.s16x2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q6[4 * u + k] = div_pair16(raw[u][k], s.inv, s.inv_lo, s.inv, s.inv_lo);
+      }
+      fp6_levels_hw32<HW6 == 2>(q6, lv6);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const u32x4 o = {pk_fma0_f16(lv6[4 * u], sc6[u]), pk_fma0_f16(lv6[4 * u + 1], sc6[u]), pk_fma0_f16(lv6[4 * u + 2], sc6[u]),
+                         pk_fma0_f16(lv6[4 * u + 3], sc6[u])};
+        if (live[u]) {
+          if (NTS) __builtin_nontemporal_store(o, out + v0 + u * kBlock);
+          else out[v0 + u * kBlock] = o;
+        }
+      }
+      continue;
     }
     if (first && !HW4) {
       if (TAB_ARG) {

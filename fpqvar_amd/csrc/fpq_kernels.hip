@@ -1034,6 +1034,21 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
       return check_launch();
     }
   }
+  if constexpr (!DUAL) {
+    // E2M3 / E3M2 per group of 128 and per row of 64 (the KV cache's head rows): levels from the FP6 conversion hardware, four
+    // vectors per lane = the 32 values of one conversion, full grid (no table to amortise); FPQ_NO_HW6 keeps the table
+    if ((lpr == 16 || lpr == 8) && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !getenv("FPQ_NO_HW6")) {
+      const int64_t tiles4 = (n_vec + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4);
+      const dim3 g4(grid_for(tiles4, 1 << 20));
+#define FPQ_HW6_GO(L, H)                                                                                                         \
+  hipLaunchKernelGGL((rows16_lut_subwave_kernel<L, false, 4, true, NTL, NTS, false, false, H>), g4, dim3(kBlock), lds, st,      \
+                     (const u32x4*)x, (u32x4*)out, n_vec, args, h.tab)
+      if (lpr == 16) { if (neg_id == FPQ_E2M3) FPQ_HW6_GO(16, 1); else FPQ_HW6_GO(16, 2); }
+      else { if (neg_id == FPQ_E2M3) FPQ_HW6_GO(8, 1); else FPQ_HW6_GO(8, 2); }
+#undef FPQ_HW6_GO
+      return check_launch();
+    }
+  }
 #define FPQ_FAST16_CASE(L) \
   case L: return go(rows16_lut_subwave_kernel<L, DUAL, U, true, NTL, NTS>, rows16_lut_subwave_kernel<L, DUAL, U, false, NTL, NTS>);
   switch (lpr) {

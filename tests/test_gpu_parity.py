@@ -345,11 +345,12 @@ def test_exhaustive_fp16_scale_pairs(dev, qu):
                       orc.dual_per_group_kernel_sem(x, "e1m2_neg", "e2m1_pos", 128, 1.0), "scale sweep dual")
 
 
-@pytest.mark.parametrize("table", ("e2m1", "e2m1/table", "e1m2", "e3m0", "e2m3", "e3m2", "e1m2_neg+e2m1_pos", "int_neg+e2m3_pos"))
+@pytest.mark.parametrize("table", ("e2m1", "e2m1/table", "e1m2", "e3m0", "e2m3", "e2m3/table", "e3m2", "e3m2/table", "e1m2_neg+e2m1_pos",
+                                   "int_neg+e2m3_pos"))
 def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, monkeypatch):
     """EVERY (group maximum, element) pair of finite fp16 values - 1.0e9 per table, both signs - through the fast
-    fp16 kernel (one-multiply division, level from the bucket table or - "e2m1": the default for E2M1 in groups of 128 -
-    from the FP4 conversion hardware, packed fp16 multiply) and through the generic kernel (IEEE fp32
+    fp16 kernel (one-multiply division, level from the bucket table or - "e2m1", "e2m3", "e3m2": the defaults in groups of
+    128 - from the FP4 / FP6 conversion hardware, packed fp16 multiply) and through the generic kernel (IEEE fp32
     division, closed form, fp32 product; selected by asking for a float32 result), which the tests above pin to the
     oracle, and through the reference's own ~11-op torch sequence on this GPU around the literal scan kernel.
     The division of fpq_fast16.h (margin: 0.05 %) and the tie-breaking bias in front of the hardware conversion are
@@ -357,8 +358,9 @@ def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, monkeypatch):
     producers (fpq_rotate_mfma.h, fpq_adaln.h) quantize with the same two functions.
     Dual formats: the group holds +max and -max, so both sides' scales sweep every magnitude too."""
     from fpqvar_amd import ops
-    if table.endswith("/table"):
-        monkeypatch.setenv("FPQ_NO_HW4", "1")      # read by the library at every call
+    if table.endswith("/table"):                   # the bucket-table forms behind the conversion-hardware defaults (round 3: E2M1;
+        monkeypatch.setenv("FPQ_NO_HW4", "1")      # round 4: E2M3 / E3M2); both variables are read by the library at every call
+        monkeypatch.setenv("FPQ_NO_HW6", "1")
         table = table.split("/")[0]
     dual = "+" in table
     lead = 2 if dual else 1
