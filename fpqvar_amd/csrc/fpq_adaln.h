@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
                                                               Lut16Tab tab, AdalnTiers tiers) {
   static_assert(MAXC >= 1 && MAXC <= 5, "rows of at most 20 groups");
   static_assert(!HW4 || !TOKEN, "hardware E2M1 levels / codes: per group only");
-  static_assert(HW6 == 0 || (!HW4 && !CODES && MAXC <= 4 && !PAIR2), "hardware FP6 levels: values of one tile");
+  static_assert(HW6 == 0 || (!HW4 && !CODES && !PAIR2), "hardware FP6 levels: value outputs");
   static_assert(!TIGHT || (HW4 && !X32 && !EMIT && MAXC == 4), "the 31 KiB form: fp16 rows of 15 groups, no table");
   constexpr bool MOD16 = sizeof(Tmod) == 2;
   static_assert(NW == 4, "four wavefronts per workgroup");
@@ -1048,7 +1048,10 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
         if constexpr (MAXC == 5) scale_nan_if_not_finite(s1);
       }
     }
-    if constexpr (HW6 != 0) scale_nan_if_not_finite(s);
+    if constexpr (HW6 != 0) {
+      scale_nan_if_not_finite(s);
+      if constexpr (MAXC == 5) scale_nan_if_not_finite(s1);
+    }
     FPQ_STAMP(5);                                   // group maximum across the quarters, scale and its reciprocal
     // MAXC == 5: this lane's chunk of groups 16 .. 19 - of this row, or (closing a pair) lanes 0 .. 31 the parked row's
     // and lanes 32 .. 63 this row's
@@ -1151,6 +1154,13 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             o1[k] = pk_fma0_f16(e2m1_levels_hw(div_pair16(y1[k], s1.inv, s1.inv_lo, s1.inv, s1.inv_lo)), s1.s16x2);
+        } else if constexpr (HW6 != 0) {   // the slot chunk: 8 live values in a conversion of 32
+          uint32_t q5[4], l5[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q5[k] = div_pair16(y1[k], s1.inv, s1.inv_lo, s1.inv, s1.inv_lo);
+          fp6_levels_hw32<HW6 == 2, 4>(q5, l5);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o1[k] = pk_fma0_f16(l5[k], s1.s16x2);
         } else {
           o1 = quant_vec16<false>(y1, lut, a.shift, s1.inv, s1.inv_lo, s1.s16x2, 0.f, 0.f, 0u);
         }

@@ -254,15 +254,21 @@ __device__ __forceinline__ uint32_t pk_fma0_f16(uint32_t a, uint32_t b) {   // a
 typedef uint32_t fp6_u16v_t __attribute__((ext_vector_type(16)));
 typedef uint32_t fp6_u6v_t __attribute__((ext_vector_type(6)));
 typedef float fp6_f16v_t __attribute__((ext_vector_type(16)));
-template <bool BF6>
-__device__ __forceinline__ void fp6_levels_hw32(const uint32_t (&xn)[16], uint32_t (&lv)[16]) {
+// NW < 16: only the first NW packed words are live (a lane's fifth vector on rows of 17 - 20 groups: 8 values in a conversion
+// of 32 - the instruction costs the same, but the table, its staging and its barrier still go).
+template <bool BF6, int NW = 16>
+__device__ __forceinline__ void fp6_levels_hw32(const uint32_t (&xn)[NW], uint32_t (&lv)[NW]) {
   // the two source tuples INTERLEAVE in the result: code 2 i comes from a[i], code 2 i + 1 from b[i] (seen on hardware with
   // distinct inputs - the probe's neighbouring patterns quantize alike and hid it): a = the low halves, b = the high halves
   fp6_f16v_t a, b;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    a[j] = fmaf_h_lo(xn[j], 1.0f, 0x1p-17f);
-    b[j] = fmaf_h_hi(xn[j], 1.0f, 0x1p-17f);
+    if (j < NW) {
+      a[j] = fmaf_h_lo(xn[j], 1.0f, 0x1p-17f);
+      b[j] = fmaf_h_hi(xn[j], 1.0f, 0x1p-17f);
+    } else {
+      a[j] = b[j] = 0.0f;
+    }
   }
   fp6_u6v_t c;
   fp6_u16v_t d;
@@ -274,7 +280,7 @@ __device__ __forceinline__ void fp6_levels_hw32(const uint32_t (&xn)[16], uint32
     asm("v_cvt_scalef32_pk32_f16_fp6 %0, %1, 1.0" : "=&v"(d) : "v"(c));
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) lv[j] = d[j];
+  for (int j = 0; j < NW; ++j) lv[j] = d[j];
 }
 
 // Quantize the 8 halves of one 16-byte vector.  s16x2 = scale replicated in both halves; inv_hi + inv_lo = 1 / scale
@@ -896,7 +902,7 @@ template <bool DUAL, int MAXC, bool TAB_ARG, int HW6 = 0>
 __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t* __restrict__ x,
                                                                 uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                                                 Lut16Args a, Lut16Tab tab) {
-  static_assert(HW6 == 0 || (!DUAL && MAXC == 4), "hardware FP6 levels: symmetric tables, 32 elements per lane");
+  static_assert(HW6 == 0 || (!DUAL && (MAXC == 4 || MAXC == 5)), "hardware FP6 levels: symmetric tables, 32 (+ 8) elements per lane");
   uint16_t* lut = nullptr;
   if constexpr (HW6 == 0) {
     __shared__ __attribute__((aligned(16))) uint16_t lut_s[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
@@ -976,6 +982,16 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_wave_kernel(const uint16_t*
         if (v < vpr)
           __builtin_nontemporal_store(u32x4{pk_fma0_f16(lv[4 * c], sn.s16x2), pk_fma0_f16(lv[4 * c + 1], sn.s16x2),
                                             pk_fma0_f16(lv[4 * c + 2], sn.s16x2), pk_fma0_f16(lv[4 * c + 3], sn.s16x2)}, orow + v);
+      }
+      if constexpr (MAXC == 5) {   // the fifth vector of lanes 0 .. (vpr - 256): a second conversion with 8 live values
+        uint32_t q5[4], l5[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q5[k] = div_pair16(raw[4][k], sn.inv, sn.inv_lo, sn.inv, sn.inv_lo);
+        fp6_levels_hw32<HW6 == 2, 4>(q5, l5);
+        const int64_t v = 256 + lane;
+        if (v < vpr)
+          __builtin_nontemporal_store(u32x4{pk_fma0_f16(l5[0], sn.s16x2), pk_fma0_f16(l5[1], sn.s16x2), pk_fma0_f16(l5[2], sn.s16x2),
+                                            pk_fma0_f16(l5[3], sn.s16x2)}, orow + v);
       }
       continue;
     }

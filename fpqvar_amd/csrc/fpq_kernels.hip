@@ -1208,15 +1208,15 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
 #define FPQ_ADALN2K(M, CODES, EMIT, TOKEN)                                                                             \
   do {                                                                                                                 \
     if (!adaln_butterfly) {                                                                                            \
-      if constexpr (M == 4 && !(CODES) && !(EMIT)) {   /* E2M3 / E3M2 values, rows of 13 .. 16 groups: hardware levels */ \
+      if constexpr ((M == 4 || M == 5) && !(CODES) && !(EMIT)) {   /* E2M3 / E3M2 values, rows of 13 .. 20 groups: hardware levels */ \
         if (hw6 == 1) {                                                                                                \
-          hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, 4, false, false, TOKEN, X32, false, false, 4, false, 1>), g3,    \
+          hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, false, false, TOKEN, X32, false, false, 4, false, 1>), g3,    \
                              dim3(kBlock), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,       \
                              rows, ad, r, h.args, tab, tiers);                                                         \
           break;                                                                                                       \
         }                                                                                                              \
         if (hw6 == 2) {                                                                                                \
-          hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, 4, false, false, TOKEN, X32, false, false, 4, false, 2>), g3,    \
+          hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, false, false, TOKEN, X32, false, false, 4, false, 2>), g3,    \
                              dim3(kBlock), lds2, st, (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out,       \
                              rows, ad, r, h.args, tab, tiers);                                                         \
           break;                                                                                                       \
@@ -1361,18 +1361,17 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
     if (g > capw) g = capw;
 #define FPQ_WAVE(M) do { if (h.tab_valid) hipLaunchKernelGGL((rows16_lut_wave_kernel<DUAL, M, true>), dim3((unsigned)g), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out, rows, cols, args, h.tab); \
                          else hipLaunchKernelGGL((rows16_lut_wave_kernel<DUAL, M, false>), dim3((unsigned)g), dim3(kBlock), lds, st, (const uint16_t*)x, (uint16_t*)out, rows, cols, args, h.tab); } while (0)
-    // rows of exactly four vectors per lane on E2M3 / E3M2 (per-token FP6 at C = 1920, 2048): levels from the FP6
+    // rows of four or five vectors per lane on E2M3 / E3M2 (per-token FP6 at C = 1920, 2048, 2304): levels from the FP6
     // conversion hardware, no table (fpq_fast16.h, fp6_levels_hw32); FPQ_NO_HW6 (read at every call) keeps the table
     if constexpr (!DUAL) {
-      if (mc == 4 && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !getenv("FPQ_NO_HW6")) {
+      if ((mc == 4 || mc == 5) && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !getenv("FPQ_NO_HW6")) {
         int64_t g6 = (rows + 3) / 4;
         if (g6 > (1 << 20)) g6 = 1 << 20;   // nothing to amortise: one pass of four rows per workgroup
-        if (neg_id == FPQ_E2M3)
-          hipLaunchKernelGGL((rows16_lut_wave_kernel<false, 4, true, 1>), dim3((unsigned)g6), dim3(kBlock), lds, st, (const uint16_t*)x,
-                             (uint16_t*)out, rows, cols, args, h.tab);
-        else
-          hipLaunchKernelGGL((rows16_lut_wave_kernel<false, 4, true, 2>), dim3((unsigned)g6), dim3(kBlock), lds, st, (const uint16_t*)x,
-                             (uint16_t*)out, rows, cols, args, h.tab);
+#define FPQ_WAVE6(M, H) hipLaunchKernelGGL((rows16_lut_wave_kernel<false, M, true, H>), dim3((unsigned)g6), dim3(kBlock), lds, st, \
+                                           (const uint16_t*)x, (uint16_t*)out, rows, cols, args, h.tab)
+        if (mc == 4) { if (neg_id == FPQ_E2M3) FPQ_WAVE6(4, 1); else FPQ_WAVE6(4, 2); }
+        else { if (neg_id == FPQ_E2M3) FPQ_WAVE6(5, 1); else FPQ_WAVE6(5, 2); }
+#undef FPQ_WAVE6
         return check_launch();
       }
     }

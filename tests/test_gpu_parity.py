@@ -416,14 +416,15 @@ def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, monkeypatch):
     assert len(distinct_out) > 1000                                   # the sweep really produced a spread of results
 
 
+@pytest.mark.parametrize("cols", (1920, 2304))
 @pytest.mark.parametrize("table", ("e2m3", "e3m2"))
-def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, monkeypatch):
+def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, cols, monkeypatch):
     """The per-token FP6 quantizer on rows of 1920 (W6A6 activations) takes its levels from the FP6 conversion hardware since
     round 4 (rows16_lut_wave_kernel<HW6>, fp6_levels_hw32: float(xn) + 2^-17 in front of a round-to-nearest-even conversion).
     EVERY (row maximum, element) pair of finite fp16 values through it, through the table form (FPQ_NO_HW6=1, read at
-    every call) and through the generic kernel (IEEE division + closed form, selected by asking for a float32 result)."""
+    every call) and through the generic kernel (IEEE division + closed form, selected by asking for a float32 result).
+    cols = 2304 (d36): a lane's fifth vector goes through a second conversion with 8 live values."""
     from fpqvar_amd import ops
-    cols = 1920
     per = cols - 1
     total = 0
     step = 1024
@@ -846,16 +847,17 @@ def test_rotate_butterfly_switch(dev, tmp_path):
     assert_bits_equal(o, orc.per_group_kernel_sem(y.cpu(), "e2m1", 128), "matrix-core form: quant of rotated")
 
 
+@pytest.mark.parametrize("C", (1920, 2304))
 @pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
 @pytest.mark.parametrize("table", ("e2m3", "e3m2"))
-def test_adaln_fp6_hardware_levels_equal_the_table_form(dev, table, x_dtype, monkeypatch):
+def test_adaln_fp6_hardware_levels_equal_the_table_form(dev, table, x_dtype, C, monkeypatch):
     """The adaLN producer's E2M3 / E3M2 value outputs (per group and per token, rows of 13 .. 16 groups) take their levels
     from the FP6 conversion hardware since round 4; FPQ_NO_HW6=1 (read at every call) keeps the bucket table: bit-equal,
     including rows with non-finite values, all-zero rows and ragged batch entries; and the quantization is the oracle's on
     the rotated rows the kernel emits."""
     from fpqvar_amd import rotation as rot
     g = torch.Generator().manual_seed(90)
-    B, L, C = 5, 23, 1920
+    B, L = 5, 23
     x = (torch.randn(B, L, C, generator=g) * torch.exp(0.5 * torch.randn(B, L, C, generator=g))).to(x_dtype)
     x[0, 1] = 0.0
     x[1, 2, 77] = float("inf")
