@@ -58,6 +58,30 @@ def eager(dev, model, rows_dtype):
     shift = (torch.randn(B, 1, C, device=dev, generator=g) * 0.3).half()
     smooth = torch.rand(C, device=dev, generator=g) + 0.5
     out = []
+    # the "Q" path's calls at the first step (the compiled binding covers them since round 4): operand-emitting producers,
+    # per-token producer with its two code forms, the KV-cache step, the FP4 GEMM
+    from fpqvar_amd import gemm, kv_cache
+    L0 = m["pn"][0] ** 2
+    x0 = torch.randn(B, L0, C, device=dev, generator=g)
+    x0 = x0 if rows_dtype == "fp32" else x0.half()
+    heads = C // 64
+    cache = kv_cache.IncrementalKVCache(B, 4096, heads, 64, 6, device=dev)
+    kk = torch.randn(B, L0, heads, 64, device=dev, generator=g).half()
+    a_codes, a_scales = gemm.quantize_mx(torch.randn(B * L0, C, device=dev, generator=g).half())
+    w_codes, w_scales = gemm.quantize_mx(torch.randn(C, C, device=dev, generator=g) * 0.02)
+
+    def kv_step():
+        if cache.len + L0 > 4096:
+            cache.len = cache._prev = 0
+        cache.append(kk, kk)
+    q_path = {"rotate_quant_mx": lambda: rot.rotate_quant_mx(x0.view(-1, C), smooth=smooth),
+              "adaln_rotate_quant_mx": lambda: rot.adaln_rotate_quant_mx(x0, scale, shift, smooth=smooth),
+              "adaln_rotate_quant_token": lambda: rot.adaln_rotate_quant_token(x0, scale, shift, "e2m3", smooth=smooth),
+              "adaln_rotate_quant_token_fp8": lambda: rot.adaln_rotate_quant_token(x0, scale, shift, "e2m3", smooth=smooth, emit="fp8"),
+              "adaln_rotate_quant_token_fp6": lambda: rot.adaln_rotate_quant_token(x0, scale, shift, "e2m3", smooth=smooth, emit="fp6"),
+              "kv_cache_step": kv_step,
+              "linear_fp4": lambda: gemm.linear_fp4(a_codes, a_scales, w_codes, w_scales)}
+    out.append({"q_path_eager_us_at_the_first_step": {k: round(eager_us(f), 2) for k, f in q_path.items()}, "rows": B * L0})
     for pn in m["pn"]:
         L = pn * pn
         x = torch.randn(B, L, C, device=dev, generator=g)
