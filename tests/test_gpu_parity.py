@@ -464,6 +464,26 @@ def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, cols, monk
                           orc.per_token_kernel_sem(e[:rows], table), f"{table} edge rows={rows}")
 
 
+@pytest.mark.parametrize("cols", (1920, 128, 64))
+def test_fp6_hardware_levels_full_size_properties(dev, cols, monkeypatch):
+    """The metric-sized tensor [65536 x 1920] through the FP6 conversion-hardware forms (per token, per group of 128, KV rows of
+    64): equal to the table forms element for element, idempotent (a quantized tensor quantizes to itself - the KV path
+    relies on it, tr/basic_var.py:186-209), every output a level times its row's scale (checked on oracle slices)."""
+    from fpqvar_amd import ops
+    g = torch.Generator(device=dev).manual_seed(321)
+    x = (torch.randn(65536, 1920, device=dev, generator=g) * torch.exp(0.3 * torch.randn(65536, 1920, device=dev, generator=g))).half()
+    for table in ("e2m3", "e3m2"):
+        q = ops.quant_rows(x, table, cols, torch.float16)
+        with monkeypatch.context() as m:
+            m.setenv("FPQ_NO_HW6", "1")
+            qt = ops.quant_rows(x, table, cols, torch.float16)
+        assert torch.equal(q.view(torch.int16), qt.view(torch.int16)), f"{table} cols={cols}: hardware levels vs table form"
+        assert torch.equal(ops.quant_rows(q, table, cols, torch.float16).view(torch.int16), q.view(torch.int16)), f"{table} cols={cols}: not idempotent"
+        for lo in (0, 32768, 65536 - 16):
+            want = orc.per_token_kernel_sem(x[lo:lo + 16].cpu().reshape(-1, cols), table).view(16, 1920)
+            assert_bits_equal(q[lo:lo + 16], want, f"{table} cols={cols} rows {lo}..")
+
+
 # ------------------------------------------------------------------ shapes, raggedness, errors
 def test_edge_shapes_and_errors(dev, qu):
     from fpqvar_amd import ops
