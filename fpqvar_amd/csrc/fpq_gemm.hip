@@ -131,11 +131,14 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
   const int G = (int)(k / 128);
   hipStream_t st = (hipStream_t)stream;
-  // Default: the LDS-DMA kernel with 128 x 128 tiles (three workgroups per CU); the register-staged kernel
-  // when its LDS image does not fit (very long K).
-  // FPQ_GEMM_CFG (experiments): 0..2 register-staged tilings, 10 / 20 LDS-DMA tilings (256x128, 128x128).
+  // Default: the LDS-DMA kernel - 256 x 128 tiles (two workgroups per CU) when there are at least 1024 of them (two rounds
+  // of the chip's 512 resident workgroups: round 4, 3 - 5 % faster than 128 x 128 on the VAR-d30 shapes from 25 600 tokens
+  // on), else 128 x 128 tiles (three per CU); the register-staged kernel when the LDS image does not fit (very long K).
+  // FPQ_GEMM_CFG (experiments, tests): 0..2 register-staged tilings, 10 / 20 LDS-DMA tilings (256x128, 128x128).
   const char* env = getenv("FPQ_GEMM_CFG");
-  const int cfg = env ? atoi(env) : 20;
+  const int64_t big_tiles = ((tokens + 255) / 256) * ((outs + 127) / 128);
+  // (the LDS-DMA kernel reads the bias four outputs at a time: a bias that is not 8-byte aligned goes to the other kernel)
+  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : env ? atoi(env) : big_tiles >= 1024 ? 10 : 20;
 #define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
   do {                                                                                                               \
     using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
@@ -171,7 +174,7 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
     }                                                                                                                \
   } while (0)
   if (cfg == 10) FPQ_GEMM_GLDS(8, 4);
-  if (cfg == 20) FPQ_GEMM_GLDS(4, 4);
+  if (cfg == 10 || cfg == 20) FPQ_GEMM_GLDS(4, 4);   // (the larger tile's LDS image may not fit where the smaller one's does)
 #undef FPQ_GEMM_GLDS
   if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
   else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);

@@ -45,6 +45,7 @@ struct GemmEpi {
   int rows_per_gate;
 };
 typedef _Float16 fpq_h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 fpq_h4_t __attribute__((ext_vector_type(4)));
 
 // (macros, not functions: the kernels carry different target attributes and a callee is only inlined into a kernel
 // with the same ones)
@@ -321,7 +322,11 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
   const int t0 = row_blk * BM, o0 = col_blk * BN;
 
-  // LDS-DMA sources of this wavefront's pieces (block = wave + 4*i of the stage), group 0
+  // LDS-DMA sources of this wavefront's pieces (block = wave + 4*i of the stage), group 0.
+  // The weight rows are DEALT over a wavefront's NT = 4 blocks (round 4): row q of block n holds output 4*q + n of the
+  // wavefront's 64, so the lane that holds column q of the NT result tiles holds four CONSECUTIVE outputs 4*q .. 4*q + 3
+  // and the epilogue stores 8 bytes per lane, 128 contiguous bytes per 16 lanes, straight from the accumulators.
+  static_assert(NT == 4, "the epilogue packs a lane's NT results of one row into one 8-byte store");
   const uint8_t* src[PIECES];
   {
     const int q = lane >> 2, kb = (lane & 3) ^ glds_chunk_perm(q);
@@ -332,7 +337,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
         const int t = t0 + blk * 16 + q;
         src[i] = A + (int64_t)(t < T ? t : T - 1) * row_bytes + kb * 16;
       } else {
-        const int o = o0 + (blk - ABLK) * 16 + q;
+        const int wb = blk - ABLK;
+        const int o = o0 + (wb / NT) * (16 * NT) + NT * q + wb % NT;
         src[i] = W + (int64_t)(o < O ? o : O - 1) * row_bytes + kb * 16;
       }
     }
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   // fragment read offset inside a block: row lane & 15, chunk lane >> 4
   const int frag_off = ((lane & 15) << 6) + ((((lane >> 4) ^ glds_chunk_perm(lane & 15)) & 3) << 4);
   const int a_off = wm * MT * 1024 + frag_off, b_off = (ABLK + wn * NT) * 1024 + frag_off;
-  const int sa_off = wm * MT * 16 + 4 * (lane >> 4), sw_off = wn * NT * 16 + (lane & 15);
+  const int sa_off = wm * MT * 16 + 4 * (lane >> 4), sw_off = wn * NT * 16 + NT * (lane & 15);   // outputs 4q .. 4q+3: tile n holds 4q + n
 
   for (int g = 0; g < G; ++g) {
     FPQ_SYNC();   // stage g has landed (the fence drains the LDS-DMA queue); stage g^1's readers are done
@@ -368,12 +374,9 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
     // (Left to itself the compiler issues each row's reads right before their use and the VALU right behind its
     // own MFMAs, with s_nops in between.)
     u32x4 bq[NT];
-    float sw1[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      bq[n] = *(const u32x4*)(st + b_off + n * 1024);
-      sw1[n] = lsw[g * BN + sw_off + n * 16];
-    }
+    for (int n = 0; n < NT; ++n) bq[n] = *(const u32x4*)(st + b_off + n * 1024);
+    const v4f_t sw1 = *(const v4f_t*)(lsw + g * BN + sw_off);
     u32x4 aq = *(const u32x4*)(st + a_off);
     v4f_t sa4 = *(const v4f_t*)(lsa + g * BM + sa_off);
     v4f_t d_prev[NT], sa4_prev = sa4;
@@ -426,42 +429,49 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
       sa4 = sa4_n;
     }
   }
-  FPQ_SYNC();   // every wavefront is done with the staging buffers: the epilogue reuses them
-
-  // epilogue: bias, fp16, transpose each wavefront tile through LDS for 16-byte row stores
-  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT, LDW = WCOLS + 8;
-  _Float16* lo = (_Float16*)smem + wave * (WROWS * LDW);
+  // epilogue, from the registers (round 4): a lane's results of row i in the NT tiles are four consecutive outputs -> + bias,
+  // one rounding to fp16, gate / residual, one 8-byte store; 16 lanes write 128 contiguous bytes.  Rounds 1-3 turned the
+  // tile through LDS for 16-byte row stores (64 x (add, convert, ds_write_b16), two barriers, the re-read: ~330 of the
+  // ~2850 vector instructions of a wavefront's tile at K = 1920).  outs % 8 == 0 and o % 4 == 0: o < O means o + 4 <= O.
+  // Loads are unconditional on clamped addresses (a lane past the edge reads what a neighbour reads and stores nothing):
+  // a load inside a divergent branch is waited for inside it.
+  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT;
+  const int o = o0 + wn * WCOLS + NT * (lane & 15);
+  const int oc = o < O ? o : O - 4;
+  v4f_t b4 = v4f_t{0, 0, 0, 0};
+  if (bias) {
+    const fpq_h4_t bh = *(const fpq_h4_t*)(bias + oc);
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int n = 0; n < NT; ++n) b4[n] = (float)bh[n];
+  }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int col = n * 16 + (lane & 15);
-      const int o = o0 + wn * WCOLS + col;
-      const float b = (bias && o < O) ? (float)bias[o] : 0.0f;
+  for (int m = 0; m < MT; ++m) {
+    const int t_first = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4);
+    fpq_h4_t y[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) lo[(m * 16 + 4 * (lane >> 4) + i) * LDW + col] = (_Float16)(acc[m][n][i] + b);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) y[i][n] = (_Float16)(acc[m][n][i] + b4[n]);
+    int tc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tc[i] = t_first + i < T ? t_first + i : T - 1;
+    if (epi.gate) {
+      fpq_h4_t gt[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gt[i] = *(const fpq_h4_t*)(epi.gate + (int64_t)(tc[i] / epi.rows_per_gate) * O + oc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = y[i] * gt[i];
     }
-  FPQ_SYNC();
-  constexpr int EP = WROWS * (WCOLS / 8);
+    if (epi.resid) {
+      fpq_h4_t rs[4];
 #pragma unroll
-  for (int pass = 0; pass < (EP + 63) / 64; ++pass) {
-    const int piece = pass * 64 + lane;
-    if (piece < EP) {
-      const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
-      const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
-      if (t < T && o + 8 <= O) {
-        u32x4 y = *(const u32x4*)(lo + r * LDW + cpc * 8);
-        FPQ_GEMM_EPI_VEC(y, epi, t, o, O);
-        *(u32x4*)(out + (int64_t)t * O + o) = y;
-      } else if (t < T) {
-        for (int e = 0; e < 8; ++e)
-          if (o + e < O) {
-            _Float16 y = lo[r * LDW + cpc * 8 + e];
-            FPQ_GEMM_EPI_ONE(y, epi, t, o + e, O);
-            out[(int64_t)t * O + o + e] = y;
-          }
-      }
+      for (int i = 0; i < 4; ++i) rs[i] = *(const fpq_h4_t*)(epi.resid + (int64_t)tc[i] * O + oc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = rs[i] + y[i];
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (t_first + i < T && o < O) *(fpq_h4_t*)(out + (int64_t)tc[i] * O + oc) = y[i];
   }
 }
 
@@ -471,9 +481,7 @@ template <int MT, int NT>
 struct GemmGldsCfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds(int G) {
-    size_t main = 2 * (size_t)(BM + BN) * 64 + (size_t)G * (BM + BN) * 4;
-    size_t epi = (size_t)4 * (16 * MT) * (16 * NT + 8) * 2;
-    return main > epi ? main : epi;
+    return 2 * (size_t)(BM + BN) * 64 + (size_t)G * (BM + BN) * 4;   // two stages + the scale tiles (the epilogue uses no LDS)
   }
 };
 
