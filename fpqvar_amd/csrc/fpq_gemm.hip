@@ -138,7 +138,10 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   const char* env = getenv("FPQ_GEMM_CFG");
   const int64_t big_tiles = ((tokens + 255) / 256) * ((outs + 127) / 128);
   // (the LDS-DMA kernel reads the bias four outputs at a time: a bias that is not 8-byte aligned goes to the other kernel)
-  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : env ? atoi(env) : big_tiles >= 1024 ? 10 : 20;
+  // ... and while two of them fit a CU's 160 KB of LDS (the scale tiles grow with K: from K = 3840 on only one would, and
+  // the smaller tile is 15 % faster there - tools/gemm_k_sweep.py)
+  const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds(G) <= 160 * 1024;
+  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : env ? atoi(env) : (big_tiles >= 1024 && big_fits_twice) ? 10 : 20;
 #define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
   do {                                                                                                               \
     using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \

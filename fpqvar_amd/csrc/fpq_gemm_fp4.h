@@ -335,6 +335,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   // the loads write the stage nobody reads, and the barriers order them).  The compiler does not see these loads: the wait
   // for them is spelled out in front of the barrier that hands a stage to its readers (FPQ_GLDS_WAIT).
   // Issuing a stage's pieces between the MFMAs of the previous one instead of in front of them: 2.5 x slower (measured).
+  // A persistent form (one workgroup per resident slot looping over its tiles, the next tile's stage 0 and scale tiles
+  // requested in front of the current tile's stores): 5 - 10 % slower than one workgroup per tile (measured, round 4).
   const uint8_t* const gbase[2] = {A + (int64_t)t0 * row_bytes, W + (int64_t)o0 * row_bytes};
   uint32_t voff[PIECES];
   {
@@ -490,7 +492,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (t_first + i < T && o < O) *(fpq_h4_t*)(out + (int64_t)tc[i] * O + oc) = y[i];
+      // (non-temporal: a round of tiles writes as much as an XCD's L2 holds - the operands should stay there; +1-2 %)
+      if (t_first + i < T && o < O) __builtin_nontemporal_store(y[i], (fpq_h4_t*)(out + (int64_t)tc[i] * O + oc));
   }
 }
 
