@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""The round-4 tables of DESIGN.md, regenerated from the committed profiles (so that every figure in them can be traced):
+   python tools/design_tables.py figures   -> the "kernel at its BASELINE shape" table (profiles/r04_bench_n1.json + r04_pmc_*.txt)
+   python tools/design_tables.py steps     -> section 4c's per-step table and the time-weighted summary (profiles/r04_steps_*.json)"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def line(path):
+    return json.loads(open(os.path.join(P, path)).read().strip().split("\n")[-1])
+
+
+def pmc(case):
+    t = open(os.path.join(P, f"r04_pmc_{case}.txt")).read()
+    us = float(re.search(r"kernel-trace average\) ([0-9.]+) us", t).group(1))
+    fr = float(re.search(r"= ([0-9.]+) of 8 TB/s", t).group(1))
+    valu = float(re.search(r"= ([0-9.]+) vector instructions per element", t).group(1))
+    busy = float(re.search(r"cycles = ([0-9.]+) of them", t).group(1))
+    return f"{us:.1f}, {fr:.3f}, {valu:.2f}, {100 * busy:.0f} %"
+
+
+def figures():
+    b, e = line("r04_bench_n1.json"), line("r04_bench_n1_commit_006b3c6.json")
+    o, oe = b["other_kernels"], e["other_kernels"]
+
+    def k(name, d=o):
+        v = d[name]
+        return f"{1e3 * v['ms']:.1f}, {v['frac_of_8TBps']:.3f}"
+
+    def both(name):
+        return f"{k(name)} ({k(name, oe)})" if name in oe else k(name)
+    stats = open(os.path.join(P, "r04_bench_kernel_stats.csv")).read()
+    m = re.search(r'"rows16_lut_subwave_kernel<16, false, 1[^"]*",(\d+),\d+,([0-9.]+)', stats)
+    tr = json.load(open(os.path.join(P, "r04_pmc_traffic.json")))
+    r, re_ = b["roofline"], e["roofline"]
+    rows = [
+        ("headline E2M1 g=128, fp16 `[65536×1920]`", "4",
+         f"{1e3 * r['kernel_ms']:.1f} by HIP events over {b['steps']} steps, **{r['frac']:.4f}**; value {b['value']:.0f} Gelem/s "
+         f"({1e3 * re_['kernel_ms']:.1f}, {re_['frac']:.4f}; {e['value']:.0f})",
+         f"{float(m.group(2)) / 1e3:.2f} over {m.group(1)} launches = **{503316480 / (float(m.group(2)) * 1e-9) / 8e12:.3f}** (`r04_bench_kernel_stats.csv`); "
+         f"{pmc('sym')} (`r04_pmc_sym.txt`); traffic {tr['traffic_bytes_per_launch'] / 1e6:.2f} MB = {tr['ratio']:.5f} × algorithmic (`r04_pmc_traffic.json`)"),
+        ("dual E1M2⁻/E2M1⁺ g=128 `[65536×7680]` (two launches)", "4", both("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680"), "-"),
+        ("dual INT⁻/E2M3⁺ g=128 / per token `[65536×7680]`", "4",
+         f"{k('dual_fc2_intneg_e2m3pos_per_group_fp16_65536x7680')} / {k('dual_fc2_intneg_e2m3pos_per_token_fp16_65536x7680')} "
+         f"({k('dual_fc2_intneg_e2m3pos_per_group_fp16_65536x7680', oe)} / {k('dual_fc2_intneg_e2m3pos_per_token_fp16_65536x7680', oe)})",
+         f"per group: {pmc('dual6')} - the one value-emitting quantizer bound by vector issue (`r04_pmc_dual6.txt`)"),
+        ("E2M3 per token `[65536×1920]`, levels from the FP6 conversion hardware (§4c)", "4", both("fp6_e2m3_per_token_fp16_65536x1920"),
+         f"{pmc('token6')} (`r04_pmc_token6.txt`; table form: 84.5, 0.745, 10.57, 39 %, `r04_pmc_token6_table.txt`)"),
+        ("rotate + quant, values / FP4 operands", "4 / 2.52",
+         f"{k('fused_rotate_quant_e2m1_fp16_65536x1920')} / {k('rotate_quant_codes_mx_fp16_65536x1920')} "
+         f"({k('fused_rotate_quant_e2m1_fp16_65536x1920', oe)} / {k('rotate_quant_codes_mx_fp16_65536x1920', oe)})",
+         f"{pmc('rotate')} / {pmc('rotate_codes')}"),
+        ("adaLN producer, fp16 rows `[65500×1920]`, values / FP4 operands", "4 / 2.52",
+         f"{k('adaln_rotate_quant_e2m1_fp16_65500x1920')} / {k('adaln_rotate_quant_codes_mx_fp16_65500x1920')} "
+         f"({k('adaln_rotate_quant_e2m1_fp16_65500x1920', oe)} / {k('adaln_rotate_quant_codes_mx_fp16_65500x1920', oe)})",
+         f"{pmc('adaln')} / {pmc('adaln_codes')}"),
+        ("adaLN producer, fp32 rows (the model's residual stream), values / FP4 operands / E4M3 per token", "6 / 4.52 / 5",
+         " / ".join(k(n) for n in ("adaln_rotate_quant_e2m1_fp32rows_65500x1920", "adaln_rotate_quant_codes_mx_fp32rows_65500x1920",
+                                   "adaln_rotate_quant_token_codes_fp8_fp32rows_65500x1920")) + " (" +
+         " / ".join(k(n, oe) for n in ("adaln_rotate_quant_e2m1_fp32rows_65500x1920", "adaln_rotate_quant_codes_mx_fp32rows_65500x1920",
+                                       "adaln_rotate_quant_token_codes_fp8_fp32rows_65500x1920")) + ")",
+         f"values: {pmc('adaln32')}"),
+        ("adaLN producer at C = 2304 `[44800×2304]` (config 5): fp32 rows values / operands; fp16 rows values", "6 / 4.52 / 4",
+         " / ".join(k(n) for n in ("config5_adaln_rotate_quant_e2m1_fp32rows_44800x2304", "config5_adaln_rotate_quant_codes_mx_fp32rows_44800x2304",
+                                   "config5_adaln_rotate_quant_e2m1_fp16rows_44800x2304")) + " (" +
+         " / ".join(k(n, oe) for n in ("config5_adaln_rotate_quant_e2m1_fp32rows_44800x2304", "config5_adaln_rotate_quant_codes_mx_fp32rows_44800x2304",
+                                       "config5_adaln_rotate_quant_e2m1_fp16rows_44800x2304")) + ")", "-"),
+        ("config 5's other two calls: E2M1 g=128 `[44800×2304]`; dual `[44800×9216]`", "4",
+         f"{k('config5_act_quant_e2m1_g128_fp16_44800x2304')}; {k('config5_dual_fc2_e1m2neg_e2m1pos_fp16_44800x9216')} "
+         f"({k('config5_act_quant_e2m1_g128_fp16_44800x2304', oe)}; {k('config5_dual_fc2_e1m2neg_e2m1pos_fp16_44800x9216', oe)})", "-"),
+    ]
+    print("| kernel at its BASELINE shape | B / element | bench r04: µs, fraction of 8 TB/s (the same line at commit 006b3c6 on another box) | rocprofv3 r04: avg µs, fraction, VALU per element, vector pipe busy |")
+    print("|---|---|---|---|")
+    for row in rows:
+        print("| " + " | ".join(row) + " |")
+    for name in sorted(o):
+        if name.startswith(("config1", "config2", "config4", "weights", "gemm", "calib")):
+            print("|", name, "|", json.dumps(o[name]), "|", json.dumps(oe.get(name)), "|")
+    for kname in ("calibration", "calib_weights"):
+        if kname in b:
+            print(kname, json.dumps(b[kname])[:600])
+
+
+def steps():
+    for model in ("d30", "d36"):
+        d = json.load(open(os.path.join(P, f"r04_steps_{model}_fp32.json")))
+        st = d["steps"]
+        print(f"\n{model} fp32 rows cold, commit {d['git_head']}:")
+        print("| rows | " + " | ".join(str(s["rows"]) for s in st) + " | Σ | of 8 TB/s | fixed + slope |")
+        print("|" + "---|" * (len(st) + 4))
+        names = {"adaln": "adaLN producer (× 2 per block)", "act": "E2M1 g=128 (proj input)", "dual": "dual E1M2⁻/E2M1⁺ (fc2 input, 2 launches)"}
+        for key, label in names.items():
+            bk = d["by_kernel"][key]
+            f = bk["fit"]
+            print(f"| {label} | " + " | ".join(f"{s[key]['us']:.1f}" for s in st) + f" | {bk['sum_us']:.1f} | {bk['frac_of_8TBps']:.3f} | "
+                  f"{f['fixed_us_per_call']:.2f} µs + {f['ns_per_row']:.3f} ns/row ({f['frac_of_8TBps_of_the_slope']:.3f}) |")
+        print("| block (2 + 1 + 1 calls) | " + " | ".join(f"{s['block_us']:.0f}" for s in st) +
+              f" | **{d['block_us_over_the_ten_steps']:.1f}** | **{d['time_weighted_frac_of_8TBps']:.3f}** | |")
+    print()
+    for tag in ("fp32", "fp16", "fp32_resident"):
+        print(tag, " | ".join(f"{json.load(open(os.path.join(P, f'r04_steps_{m}_{tag}.json')))['time_weighted_frac_of_8TBps']:.3f}" for m in ("d30", "d36")))
+    b = line("r04_bench_n1.json")
+    print("bench line:", b["config3_steps"]["time_weighted_frac_of_8TBps"], b["config5_steps"]["time_weighted_frac_of_8TBps"])
+
+
+if __name__ == "__main__":
+    (steps if sys.argv[1:] == ["steps"] else figures)()
