@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
       const int t = t0 + sb * 32 + r;
       src[i] = A + (int64_t)(t < T ? t : T - 1) * row_bytes + c * 16;
     } else {
-      const int o = o0 + (sb - ASB) * 32 + r;
+      const int ti = 2 * (sb - ASB) + (r >> 4);      // 16-row tile of the weight side; its rows are dealt over a wavefront's
+      const int o = o0 + (ti / NT) * (16 * NT) + NT * (r & 15) + ti % NT;   // NT tiles (FPQ_GEMM_ROWS_EPILOGUE)
       src[i] = W + (int64_t)(o < O ? o : O - 1) * row_bytes + c * 16;
     }
   }
@@ -120,60 +121,14 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
     }
   }
 #undef FPQ_GLDS6_ISSUE
-  FPQ_SYNC();   // every wavefront is done with the staging buffers: the epilogue reuses them
-
-  // epilogue: row scale x column scale, bias, fp16, transpose each wavefront tile through LDS for 16-byte row stores
-  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT, LDW = WCOLS + 8;
-  _Float16* lo = (_Float16*)smem + wave * (WROWS * LDW);
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    float sr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4) + i;
-      sr[i] = (t < T) ? (float)sa[t] : 0.0f;
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int col = n * 16 + (lane & 15);
-      const int o = o0 + wn * WCOLS + col;
-      const float sc = (o < O) ? (float)sw[o] : 0.0f;
-      const float b = (bias && o < O) ? (float)bias[o] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) lo[(m * 16 + 4 * (lane >> 4) + i) * LDW + col] = (_Float16)(acc[m][n][i] * (sr[i] * sc) + b);
-    }
-  }
-  FPQ_SYNC();
-  constexpr int EP = WROWS * (WCOLS / 8);
-#pragma unroll
-  for (int pass = 0; pass < (EP + 63) / 64; ++pass) {
-    const int piece = pass * 64 + lane;
-    if (piece < EP) {
-      const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
-      const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
-      if (t < T && o + 8 <= O) {
-        u32x4 y = *(const u32x4*)(lo + r * LDW + cpc * 8);
-        FPQ_GEMM_EPI_VEC(y, epi, t, o, O);
-        *(u32x4*)(out + (int64_t)t * O + o) = y;
-      } else if (t < T) {
-        for (int e = 0; e < 8; ++e)
-          if (o + e < O) {
-            _Float16 y = lo[r * LDW + cpc * 8 + e];
-            FPQ_GEMM_EPI_ONE(y, epi, t, o + e, O);
-            out[(int64_t)t * O + o + e] = y;
-          }
-      }
-    }
-  }
+  FPQ_GEMM_ROWS_EPILOGUE();
 }
 
 template <int MT, int NT>
 struct GemmFp6Cfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds() {
-    size_t main = 2 * (size_t)(BM + BN) * 96;
-    size_t epi = (size_t)4 * (16 * MT) * (16 * NT + 8) * 2;
-    return main > epi ? main : epi;
+    return 2 * (size_t)(BM + BN) * 96;   // two stages (the epilogue uses no LDS)
   }
 };
 

@@ -18,6 +18,53 @@
 // (two 1 KiB pieces of 8 rows, lane j -> row j >> 3, physical chunk j & 7) reads whole 128-byte lines from memory.
 #pragma once
 
+// Epilogue of the row-scaled GEMMs, from the accumulators (round 4, as in gemm_fp4_glds_kernel): the weight rows are dealt
+// over a wavefront's NT = 4 tiles on their way into LDS (row q of tile n = output 4q + n of the wavefront's 64), so a lane's
+// results of one token in the four tiles are four consecutive outputs: row scale x column scale, bias, one rounding to fp16,
+// gate / residual, one non-temporal 8-byte store; 16 lanes write 128 contiguous bytes.  No turn through LDS, no barrier.
+// outs % 8 == 0 and o % 4 == 0: o < O means o + 4 <= O.  Loads are unconditional on clamped addresses (a lane past the edge
+// reads what a neighbour reads and stores nothing).  A macro: the kernels carry target attributes a callee would need too.
+#define FPQ_GEMM_ROWS_EPILOGUE()                                                                                    \
+  do {                                                                                                              \
+    static_assert(NT == 4, "the epilogue packs a lane's NT results of one row into one 8-byte store");              \
+    constexpr int WROWS_ = 16 * MT, WCOLS_ = 16 * NT;                                                               \
+    const int o_ = o0 + wn * WCOLS_ + NT * (lane & 15);                                                             \
+    const int oc_ = o_ < O ? o_ : O - 4;                                                                            \
+    float sc_[4], b_[4];                                                                                            \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                                 \
+      sc_[n] = (float)sw[oc_ + n];                                                                                  \
+      b_[n] = 0.0f;                                                                                                 \
+    }                                                                                                               \
+    if (bias) {                                                                                                     \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) b_[n] = (float)bias[oc_ + n];                                   \
+    }                                                                                                               \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                                \
+      const int t_first_ = t0 + wm * WROWS_ + m * 16 + 4 * (lane >> 4);                                             \
+      int tc_[4];                                                                                                   \
+      float sr_[4];                                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        tc_[i] = t_first_ + i < T ? t_first_ + i : T - 1;                                                           \
+        sr_[i] = (float)sa[tc_[i]];                                                                                 \
+      }                                                                                                             \
+      fpq_h4_t y_[4];                                                                                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+          _Pragma("unroll") for (int n = 0; n < 4; ++n) y_[i][n] = (_Float16)(acc[m][n][i] * (sr_[i] * sc_[n]) + b_[n]); \
+      if (epi.gate) {                                                                                               \
+        fpq_h4_t g_[4];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+            g_[i] = *(const fpq_h4_t*)(epi.gate + (int64_t)(tc_[i] / epi.rows_per_gate) * O + oc_);                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) y_[i] = y_[i] * g_[i];                                        \
+      }                                                                                                             \
+      if (epi.resid) {                                                                                              \
+        fpq_h4_t r_[4];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) r_[i] = *(const fpq_h4_t*)(epi.resid + (int64_t)tc_[i] * O + oc_); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) y_[i] = r_[i] + y_[i];                                        \
+      }                                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+          if (t_first_ + i < T && o_ < O) __builtin_nontemporal_store(y_[i], (fpq_h4_t*)(out + (int64_t)tc_[i] * O + oc_)); \
+    }                                                                                                               \
+  } while (0)
+
 FPQ_NOPK __device__ __forceinline__ int fp8_chunk_swz(int r) { return ((r >> 1) & 1) + ((r >> 3) << 2); }
 
 template <typename Tsa, typename Tsw, int MT, int NT>
@@ -54,7 +101,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
       const int t = t0 + blk * 16 + r;
       src[i] = A + (int64_t)(t < T ? t : T - 1) * C + c * 16;
     } else {
-      const int o = o0 + (blk - ABLK) * 16 + r;
+      const int wb = blk - ABLK;                     // weight rows dealt over a wavefront's NT tiles (FPQ_GEMM_ROWS_EPILOGUE)
+      const int o = o0 + (wb / NT) * (16 * NT) + NT * r + wb % NT;
       src[i] = W + (int64_t)(o < O ? o : O - 1) * C + c * 16;
     }
   }
@@ -97,60 +145,14 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
     }
   }
 #undef FPQ_GLDS8_ISSUE
-  FPQ_SYNC();   // every wavefront is done with the staging buffers: the epilogue reuses them
-
-  // epilogue: row scale x column scale, bias, fp16, transpose each wavefront tile through LDS for 16-byte row stores
-  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT, LDW = WCOLS + 8;
-  _Float16* lo = (_Float16*)smem + wave * (WROWS * LDW);
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    float sr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4) + i;
-      sr[i] = (t < T) ? (float)sa[t] : 0.0f;
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int col = n * 16 + (lane & 15);
-      const int o = o0 + wn * WCOLS + col;
-      const float sc = (o < O) ? (float)sw[o] : 0.0f;
-      const float b = (bias && o < O) ? (float)bias[o] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) lo[(m * 16 + 4 * (lane >> 4) + i) * LDW + col] = (_Float16)(acc[m][n][i] * (sr[i] * sc) + b);
-    }
-  }
-  FPQ_SYNC();
-  constexpr int EP = WROWS * (WCOLS / 8);
-#pragma unroll
-  for (int pass = 0; pass < (EP + 63) / 64; ++pass) {
-    const int piece = pass * 64 + lane;
-    if (piece < EP) {
-      const int r = piece / (WCOLS / 8), cpc = piece % (WCOLS / 8);
-      const int t = t0 + wm * WROWS + r, o = o0 + wn * WCOLS + cpc * 8;
-      if (t < T && o + 8 <= O) {
-        u32x4 y = *(const u32x4*)(lo + r * LDW + cpc * 8);
-        FPQ_GEMM_EPI_VEC(y, epi, t, o, O);
-        *(u32x4*)(out + (int64_t)t * O + o) = y;
-      } else if (t < T) {
-        for (int e = 0; e < 8; ++e)
-          if (o + e < O) {
-            _Float16 y = lo[r * LDW + cpc * 8 + e];
-            FPQ_GEMM_EPI_ONE(y, epi, t, o + e, O);
-            out[(int64_t)t * O + o + e] = y;
-          }
-      }
-    }
-  }
+  FPQ_GEMM_ROWS_EPILOGUE();
 }
 
 template <int MT, int NT>
 struct GemmFp8Cfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds() {
-    size_t main = 2 * (size_t)(BM + BN) * 128;
-    size_t epi = (size_t)4 * (16 * MT) * (16 * NT + 8) * 2;
-    return main > epi ? main : epi;
+    return 2 * (size_t)(BM + BN) * 128;   // two stages (the epilogue uses no LDS)
   }
 };
 

@@ -2,7 +2,7 @@
 """A/B two builds of libfpq_hip.so in ONE process on ONE box (box-to-box and run-to-run variance is +-7 %, larger than
 most kernel changes): alternates the two libraries over three rounds per shape and prints every burst.
 
-    python tools/ab_lib.py /path/libA.so /path/libB.so [fp4|fp6|quant|attn]
+    python tools/ab_lib.py /path/libA.so /path/libB.so [fp4|fp6|fp8|quant|attn]
 Build the variants with the flags of __graft_entry__.HIP_FLAGS into files outside fpqvar_amd/ (on the GPU box the
 libraries must travel inside the repo snapshot, e.g. under tools/ab/ - git-ignored)."""
 import ctypes
@@ -75,6 +75,15 @@ def main():
 
             def call(lib):
                 f = lib.fpq_gemm_fp6_rows
+                f.argtypes = [V, V, ctypes.c_int, V, V, ctypes.c_int, V, V, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, V]
+                return lambda: f(ac.data_ptr(), asc.data_ptr(), dtype_id(asc.dtype), wc.data_ptr(), wsc.data_ptr(),
+                                 dtype_id(wsc.dtype), None, out.data_ptr(), T, O, K, sp)
+        elif what == "fp8":
+            ac, asc = gemm.quantize_fp8(x)
+            wc, wsc = gemm.quantize_fp8(w)
+
+            def call(lib):
+                f = lib.fpq_gemm_fp8_rows
                 f.argtypes = [V, V, ctypes.c_int, V, V, ctypes.c_int, V, V, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, V]
                 return lambda: f(ac.data_ptr(), asc.data_ptr(), dtype_id(asc.dtype), wc.data_ptr(), wsc.data_ptr(),
                                  dtype_id(wsc.dtype), None, out.data_ptr(), T, O, K, sp)
