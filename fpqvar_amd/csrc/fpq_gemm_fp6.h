@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
                                                                                  (wave + 4 * i_) * 1024),           \
                                        16, 0, 0)
   FPQ_GLDS6_ISSUE(0, 0);
+  FPQ_GEMM_ROWS_STAGE_SCALES(STAGE);
 
   v4f_t acc[MT][NT];
 #pragma unroll
@@ -128,7 +129,7 @@ template <int MT, int NT>
 struct GemmFp6Cfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds() {
-    return 2 * (size_t)(BM + BN) * 96;   // two stages (the epilogue uses no LDS)
+    return 2 * (size_t)(BM + BN) * 96 + (size_t)(BM + BN) * 4;   // two stages + the row / column scales as fp32
   }
 };
 

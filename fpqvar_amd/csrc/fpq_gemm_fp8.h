@@ -23,29 +23,35 @@
 // results of one token in the four tiles are four consecutive outputs: row scale x column scale, bias, one rounding to fp16,
 // gate / residual, one non-temporal 8-byte store; 16 lanes write 128 contiguous bytes.  No turn through LDS, no barrier.
 // outs % 8 == 0 and o % 4 == 0: o < O means o + 4 <= O.  Loads are unconditional on clamped addresses (a lane past the edge
-// reads what a neighbour reads and stores nothing).  A macro: the kernels carry target attributes a callee would need too.
+// reads what a neighbour reads and stores nothing).  The two scale vectors of the tile wait in LDS as fp32 since the
+// prologue (FPQ_GEMM_ROWS_STAGE_SCALES: their loads ride with stage 0; fetched in the epilogue, four dependent 2-byte loads
+// per tile row stood between the last MFMA and the stores).  Macros: the kernels carry target attributes a callee would need too.
+#define FPQ_GEMM_ROWS_STAGE_SCALES(stage_bytes)                                                                     \
+  float* lsr = (float*)(smem + 2 * (stage_bytes));   /* [BM] row scales, then [BN] column scales */                 \
+  float* lsc = lsr + BM;                                                                                            \
+  for (int r_ = tid; r_ < BM + BN; r_ += 256) {                                                                     \
+    if (r_ < BM) {                                                                                                  \
+      lsr[r_] = (float)sa[t0 + r_ < T ? t0 + r_ : T - 1];                                                           \
+    } else {                                                                                                        \
+      lsc[r_ - BM] = (float)sw[o0 + r_ - BM < O ? o0 + r_ - BM : O - 1];                                            \
+    }                                                                                                               \
+  }
 #define FPQ_GEMM_ROWS_EPILOGUE()                                                                                    \
   do {                                                                                                              \
     static_assert(NT == 4, "the epilogue packs a lane's NT results of one row into one 8-byte store");              \
     constexpr int WROWS_ = 16 * MT, WCOLS_ = 16 * NT;                                                               \
     const int o_ = o0 + wn * WCOLS_ + NT * (lane & 15);                                                             \
     const int oc_ = o_ < O ? o_ : O - 4;                                                                            \
-    float sc_[4], b_[4];                                                                                            \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                                 \
-      sc_[n] = (float)sw[oc_ + n];                                                                                  \
-      b_[n] = 0.0f;                                                                                                 \
-    }                                                                                                               \
+    const v4f_t sc_ = *(const v4f_t*)(lsc + wn * WCOLS_ + NT * (lane & 15));                                        \
+    float b_[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                                                         \
     if (bias) {                                                                                                     \
       _Pragma("unroll") for (int n = 0; n < 4; ++n) b_[n] = (float)bias[oc_ + n];                                   \
     }                                                                                                               \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                                \
       const int t_first_ = t0 + wm * WROWS_ + m * 16 + 4 * (lane >> 4);                                             \
       int tc_[4];                                                                                                   \
-      float sr_[4];                                                                                                 \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
-        tc_[i] = t_first_ + i < T ? t_first_ + i : T - 1;                                                           \
-        sr_[i] = (float)sa[tc_[i]];                                                                                 \
-      }                                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) tc_[i] = t_first_ + i < T ? t_first_ + i : T - 1;               \
+      const v4f_t sr_ = *(const v4f_t*)(lsr + wm * WROWS_ + m * 16 + 4 * (lane >> 4));                              \
       fpq_h4_t y_[4];                                                                                               \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
           _Pragma("unroll") for (int n = 0; n < 4; ++n) y_[i][n] = (_Float16)(acc[m][n][i] * (sr_[i] * sc_[n]) + b_[n]); \
@@ -113,6 +119,7 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
                                                                                  (wave + 4 * i_) * 1024),           \
                                        16, 0, 0)
   FPQ_GLDS8_ISSUE(0, 0);
+  FPQ_GEMM_ROWS_STAGE_SCALES(STAGE);
 
   v4f_t acc[MT][NT];
 #pragma unroll
@@ -152,7 +159,7 @@ template <int MT, int NT>
 struct GemmFp8Cfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds() {
-    return 2 * (size_t)(BM + BN) * 128;   // two stages (the epilogue uses no LDS)
+    return 2 * (size_t)(BM + BN) * 128 + (size_t)(BM + BN) * 4;   // two stages + the row / column scales as fp32
   }
 };
 
