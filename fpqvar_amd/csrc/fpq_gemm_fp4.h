@@ -373,6 +373,14 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   // destination registers with vmcnt waits inside the main loop, and those wait for the stage just requested.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
+  // the tile's bias (four consecutive outputs per lane, see the epilogue) is requested here, not between the last MFMA and
+  // the stores
+  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT;
+  const int o = o0 + wn * WCOLS + NT * (lane & 15);
+  const int oc = o < O ? o : O - 4;
+  fpq_h4_t bias_h = fpq_h4_t{0, 0, 0, 0};
+  if (bias) bias_h = *(const fpq_h4_t*)(bias + oc);
+
   v4f_t acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -456,15 +464,11 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   // ~2850 vector instructions of a wavefront's tile at K = 1920).  outs % 8 == 0 and o % 4 == 0: o < O means o + 4 <= O.
   // Loads are unconditional on clamped addresses (a lane past the edge reads what a neighbour reads and stores nothing):
   // a load inside a divergent branch is waited for inside it.
-  constexpr int WROWS = 16 * MT, WCOLS = 16 * NT;
-  const int o = o0 + wn * WCOLS + NT * (lane & 15);
-  const int oc = o < O ? o : O - 4;
   v4f_t b4 = v4f_t{0, 0, 0, 0};
-  if (bias) {
-    const fpq_h4_t bh = *(const fpq_h4_t*)(bias + oc);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b4[n] = (float)bh[n];
-  }
+  for (int n = 0; n < NT; ++n) b4[n] = (float)bias_h[n];
+  // (requesting the gate / residual rows one tile row ahead of their use - the compiler may not move a load above a store
+  // that could alias it, and the residual may BE the output - was measured: 13 % slower with the fused tail, round 4)
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int t_first = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4);

@@ -129,7 +129,7 @@ template <int MT, int NT>
 struct GemmFp6Cfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds() {
-    return 2 * (size_t)(BM + BN) * 96 + (size_t)(BM + BN) * 4;   // two stages + the row / column scales as fp32
+    return 2 * (size_t)(BM + BN) * 96 + (size_t)(BM + 2 * BN) * 4;   // two stages + row scales, column scales, bias as fp32
   }
 };
 

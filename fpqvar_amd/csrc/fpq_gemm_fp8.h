@@ -27,13 +27,16 @@
 // prologue (FPQ_GEMM_ROWS_STAGE_SCALES: their loads ride with stage 0; fetched in the epilogue, four dependent 2-byte loads
 // per tile row stood between the last MFMA and the stores).  Macros: the kernels carry target attributes a callee would need too.
 #define FPQ_GEMM_ROWS_STAGE_SCALES(stage_bytes)                                                                     \
-  float* lsr = (float*)(smem + 2 * (stage_bytes));   /* [BM] row scales, then [BN] column scales */                 \
+  float* lsr = (float*)(smem + 2 * (stage_bytes));   /* [BM] row scales, [BN] column scales, [BN] bias */           \
   float* lsc = lsr + BM;                                                                                            \
+  float* lsb = lsc + BN;                                                                                            \
   for (int r_ = tid; r_ < BM + BN; r_ += 256) {                                                                     \
     if (r_ < BM) {                                                                                                  \
       lsr[r_] = (float)sa[t0 + r_ < T ? t0 + r_ : T - 1];                                                           \
     } else {                                                                                                        \
-      lsc[r_ - BM] = (float)sw[o0 + r_ - BM < O ? o0 + r_ - BM : O - 1];                                            \
+      const int oc0_ = o0 + r_ - BM < O ? o0 + r_ - BM : O - 1;                                                     \
+      lsc[r_ - BM] = (float)sw[oc0_];                                                                               \
+      lsb[r_ - BM] = bias ? (float)bias[oc0_] : 0.0f;                                                               \
     }                                                                                                               \
   }
 #define FPQ_GEMM_ROWS_EPILOGUE()                                                                                    \
@@ -43,10 +46,7 @@
     const int o_ = o0 + wn * WCOLS_ + NT * (lane & 15);                                                             \
     const int oc_ = o_ < O ? o_ : O - 4;                                                                            \
     const v4f_t sc_ = *(const v4f_t*)(lsc + wn * WCOLS_ + NT * (lane & 15));                                        \
-    float b_[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                                                         \
-    if (bias) {                                                                                                     \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n) b_[n] = (float)bias[oc_ + n];                                   \
-    }                                                                                                               \
+    const v4f_t b_ = *(const v4f_t*)(lsb + wn * WCOLS_ + NT * (lane & 15));                                         \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                                \
       const int t_first_ = t0 + wm * WROWS_ + m * 16 + 4 * (lane >> 4);                                             \
       int tc_[4];                                                                                                   \
@@ -159,7 +159,7 @@ template <int MT, int NT>
 struct GemmFp8Cfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds() {
-    return 2 * (size_t)(BM + BN) * 128 + (size_t)(BM + BN) * 4;   // two stages + the row / column scales as fp32
+    return 2 * (size_t)(BM + BN) * 128 + (size_t)(BM + 2 * BN) * 4;   // two stages + row scales, column scales, bias as fp32
   }
 };
 

@@ -3,6 +3,7 @@
 most kernel changes): alternates the two libraries over three rounds per shape and prints every burst.
 
     python tools/ab_lib.py /path/libA.so /path/libB.so [fp4|fp6|fp8|quant|attn]
+FPQ_AB_EPI=1: the GEMMs with bias, gate (one row per 256 tokens) and an in-place residual (the *_ex entry points).
 Build the variants with the flags of __graft_entry__.HIP_FLAGS into files outside fpqvar_amd/ (on the GPU box the
 libraries must travel inside the repo snapshot, e.g. under tools/ab/ - git-ignored)."""
 import ctypes
@@ -13,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from fpqvar_amd import gemm  # noqa: E402
-from fpqvar_amd._lib import F16, TABLE_IDS, dtype_id, stream_ptr  # noqa: E402
+from fpqvar_amd._lib import F16, TABLE_IDS, GemmEpilogue, dtype_id, stream_ptr  # noqa: E402
 
 V = ctypes.c_void_p
 
@@ -60,7 +61,26 @@ def main():
         x = torch.randn(T, K, device=dev).half()
         w = torch.randn(O, K, device=dev) * 0.02
         out = torch.empty(T, O, dtype=torch.float16, device=dev)
-        if what == "fp4":
+        with_epi = bool(os.environ.get("FPQ_AB_EPI")) and what in ("fp4", "fp6", "fp8")
+        if with_epi:
+            bias = (torch.randn(O, device=dev) * 0.1).half()
+            gate = torch.randn(T // 256, O, device=dev).half()
+            out.normal_()
+            ep = GemmEpilogue(gate.data_ptr(), out.data_ptr(), 256)
+
+            def call(lib, what=what):
+                if what == "fp4":
+                    f = lib.fpq_gemm_fp4_mx_ex
+                    f.argtypes = [V, V, V, V, ctypes.c_int, V, V, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, V, V]
+                    return lambda: f(ac.data_ptr(), asc.data_ptr(), wc.data_ptr(), wsc.data_ptr(), dtype_id(wsc.dtype), bias.data_ptr(),
+                                     out.data_ptr(), T, O, K, ctypes.byref(ep), sp)
+                f = lib.fpq_gemm_fp6_rows_ex if what == "fp6" else lib.fpq_gemm_fp8_rows_ex
+                f.argtypes = [V, V, ctypes.c_int, V, V, ctypes.c_int, V, V, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, V, V]
+                return lambda: f(ac.data_ptr(), asc.data_ptr(), dtype_id(asc.dtype), wc.data_ptr(), wsc.data_ptr(),
+                                 dtype_id(wsc.dtype), bias.data_ptr(), out.data_ptr(), T, O, K, ctypes.byref(ep), sp)
+            ac, asc = {"fp4": gemm.quantize_mx, "fp6": gemm.quantize_fp6, "fp8": gemm.quantize_fp8}[what](x)
+            wc, wsc = {"fp4": gemm.quantize_mx, "fp6": gemm.quantize_fp6, "fp8": gemm.quantize_fp8}[what](w)
+        elif what == "fp4":
             ac, asc = gemm.quantize_mx(x)
             wc, wsc = gemm.quantize_mx(w)
 
