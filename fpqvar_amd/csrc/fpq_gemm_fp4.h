@@ -467,6 +467,14 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   v4f_t b4 = v4f_t{0, 0, 0, 0};
 #pragma unroll
   for (int n = 0; n < NT; ++n) b4[n] = (float)bias_h[n];
+  const bool gate_far = epi.gate && epi.rows_per_gate >= WROWS;
+  int gq0 = 0, gr0 = 0, gq_last = 0;
+  if (epi.gate) {
+    const int first = t0 + wm * WROWS + 4 * (lane >> 4);
+    gq0 = first / epi.rows_per_gate;
+    gr0 = first - gq0 * epi.rows_per_gate;
+    gq_last = (T - 1) / epi.rows_per_gate;
+  }
   // (requesting the gate / residual rows one tile row ahead of their use - the compiler may not move a load above a store
   // that could alias it, and the residual may BE the output - was measured: 13 % slower with the fused tail, round 4)
 #pragma unroll
@@ -483,7 +491,14 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
     if (epi.gate) {
       fpq_h4_t gt[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) gt[i] = *(const fpq_h4_t*)(epi.gate + (int64_t)(tc[i] / epi.rows_per_gate) * O + oc);
+      for (int i = 0; i < 4; ++i) {
+        // a gate row spans at least the wavefront's rows: ONE division per tile (gq0, gr0 below) and a comparison per row,
+        // instead of a division per row - 32 of them were a fifth of a tile's vector instructions
+        const int off = gr0 + m * 16 + i;
+        int gq = gate_far ? gq0 + (off >= epi.rows_per_gate ? 1 : 0) : tc[i] / epi.rows_per_gate;
+        gq = gq < gq_last ? gq : gq_last;
+        gt[i] = *(const fpq_h4_t*)(epi.gate + (int64_t)gq * O + oc);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = y[i] * gt[i];
     }

@@ -47,6 +47,15 @@
     const int oc_ = o_ < O ? o_ : O - 4;                                                                            \
     const v4f_t sc_ = *(const v4f_t*)(lsc + wn * WCOLS_ + NT * (lane & 15));                                        \
     const v4f_t b_ = *(const v4f_t*)(lsb + wn * WCOLS_ + NT * (lane & 15));                                         \
+    /* a gate row that spans the wavefront's rows: one division per tile and a comparison per row (gemm_fp4_glds_kernel) */ \
+    const bool gate_far_ = epi.gate && epi.rows_per_gate >= WROWS_;                                                 \
+    int gq0_ = 0, gr0_ = 0, gq_last_ = 0;                                                                           \
+    if (epi.gate) {                                                                                                 \
+      const int first_ = t0 + wm * WROWS_ + 4 * (lane >> 4);                                                        \
+      gq0_ = first_ / epi.rows_per_gate;                                                                            \
+      gr0_ = first_ - gq0_ * epi.rows_per_gate;                                                                     \
+      gq_last_ = (T - 1) / epi.rows_per_gate;                                                                       \
+    }                                                                                                               \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                                \
       const int t_first_ = t0 + wm * WROWS_ + m * 16 + 4 * (lane >> 4);                                             \
       int tc_[4];                                                                                                   \
@@ -57,8 +66,12 @@
           _Pragma("unroll") for (int n = 0; n < 4; ++n) y_[i][n] = (_Float16)(acc[m][n][i] * (sr_[i] * sc_[n]) + b_[n]); \
       if (epi.gate) {                                                                                               \
         fpq_h4_t g_[4];                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
-            g_[i] = *(const fpq_h4_t*)(epi.gate + (int64_t)(tc_[i] / epi.rows_per_gate) * O + oc_);                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+          const int off_ = gr0_ + m * 16 + i;                                                                       \
+          int gq_ = gate_far_ ? gq0_ + (off_ >= epi.rows_per_gate ? 1 : 0) : tc_[i] / epi.rows_per_gate;            \
+          gq_ = gq_ < gq_last_ ? gq_ : gq_last_;                                                                    \
+          g_[i] = *(const fpq_h4_t*)(epi.gate + (int64_t)gq_ * O + oc_);                                            \
+        }                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) y_[i] = y_[i] * g_[i];                                        \
       }                                                                                                             \
       if (epi.resid) {                                                                                              \
