@@ -100,6 +100,8 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
       const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
       bf[n] = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
     }
+    // (requesting row m + 1's fragment before the MFMAs of row m - the compiler puts each row's three ds_reads right in front
+    // of their MFMAs with a full wait - was measured in round 4: no gain, the second wavefront of the SIMD covers that latency)
     int issued = 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
