@@ -396,6 +396,15 @@ def other_kernels(dev):
         ms = timed(lambda: gemm.linear_fp4(*a, *w))
         out["gemm_fp4_w4a4_mat_qkv_65536x1920x5760"] = {"ms": round(ms, 4),
                                                         "TFLOPs": round(2.0 * ROWS * COLS * 3 * COLS / ms / 1e9, 1)}
+        del a, w
+        # the W6A6 pair (per token x per channel): the 6-bit packed form and the E4M3-byte form of the same instruction
+        wf = torch.randn(3 * COLS, COLS, device=dev, generator=g) * 0.02
+        for tag, quant, lin in (("gemm_fp6_w6a6_mat_qkv_65536x1920x5760", gemm.quantize_fp6, gemm.linear_fp6),
+                                ("gemm_fp8_rows_mat_qkv_65536x1920x5760", gemm.quantize_fp8, gemm.linear_fp8)):
+            a, w = quant(x), quant(wf)
+            ms = timed(lambda: lin(*a, *w))
+            out[tag] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * ROWS * COLS * 3 * COLS / ms / 1e9, 1)}
+            del a, w
 
     def configs():
         """One driver-written number per BASELINE.json configuration that is not the metric's own (config 3 at the metric
