@@ -1405,6 +1405,45 @@ def test_fp4_gemm_tile_configurations_agree(dev, T, O, K, monkeypatch):
     assert_bits_equal(odd[0], ref[0], "misaligned bias goes to the register-staged kernel")
 
 
+@pytest.mark.parametrize("kind", ("fp6", "fp8"))
+@pytest.mark.parametrize("T,O,K", ((300, 392, 1920), (4100, 520, 256)))
+def test_row_scaled_gemm_tile_configurations_agree(dev, kind, T, O, K, monkeypatch):
+    """The two tilings of the FP6 / FP8 row-scaled GEMMs (FPQ_GEMM6_CFG / FPQ_GEMM8_CFG: 128 x 128 and 256 x 128) sum a tile's
+    K in the same order and share the epilogue: bit-equal outputs, plain and with bias + gate + residual, on ragged edges;
+    4100 tokens is past the size from which the larger FP6 tile is the default.  And against float64 on the decoded operands."""
+    from fpqvar_amd import gemm
+    g = torch.Generator().manual_seed(11 + T)
+    x = (torch.randn(T, K, generator=g) * torch.exp(0.3 * torch.randn(T, K, generator=g))).half().to(dev)
+    w = (torch.randn(O, K, generator=g) * 0.02).to(dev)
+    bias = (torch.randn(O, generator=g) * 0.1).half().to(dev)
+    B = 6 if T == 300 else 4                                     # 50 / 1025 rows per gate row
+    gate = torch.randn(B, 1, O, generator=g).half().to(dev)
+    resid = torch.randn(T, O, generator=g).half().to(dev)
+    quant, lin, env = {"fp6": (gemm.quantize_fp6, gemm.linear_fp6, "FPQ_GEMM6_CFG"),
+                       "fp8": (gemm.quantize_fp8, gemm.linear_fp8, "FPQ_GEMM8_CFG")}[kind]
+    a, wq = quant(x), quant(w)
+
+    def run(cfg):
+        if cfg is None:
+            monkeypatch.delenv(env, raising=False)
+        else:
+            monkeypatch.setenv(env, cfg)
+        return lin(*a, *wq, bias), lin(*a, *wq, bias, gate, resid)
+
+    base = run("0")
+    for cfg in ("1", None):
+        got = run(cfg)
+        assert_bits_equal(got[0], base[0], f"{kind} cfg {cfg} plain")
+        assert_bits_equal(got[1], base[1], f"{kind} cfg {cfg} fused")
+    assert_bits_equal(base[1].view(B, T // B, O), resid.view(B, T // B, O) + base[0].view(B, T // B, O).mul(gate), f"{kind} fused tail")
+    deq = {"fp6": gemm.dequantize_fp6, "fp8": gemm.dequantize_fp8}[kind]
+    a64, w64 = deq(*a).double().view(T, K), deq(*wq).double().view(O, K)
+    ref = a64 @ w64.t() + bias.double()
+    err = (base[0].double() - ref).abs()
+    tol = 2.0 ** -10 * ref.abs() + 1e-5 * (a64.abs() @ w64.abs().t()) + 1e-6     # fp16 output rounding + fp32 accumulation
+    assert bool((err <= tol).all()), float((err / tol).max())
+
+
 def test_fp4_linear_module(dev, golden):
     """FP4Linear vs the reference-path QuantizedLinear (fake-quant + fp16 GEMM) on the golden toy layer."""
     from fpqvar_amd import gemm
