@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
   if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
   const int t0 = row_blk * BM, o0 = col_blk * BN;
 
-  const uint8_t* src[PIECES];
+  // LDS-DMA sources: scalar base per operand + 32-bit lane offset, in assembly with explicit waits (as in gemm_fp4_glds_kernel)
+  const uint8_t* const gbase[2] = {A + (int64_t)t0 * C, W + (int64_t)o0 * C};
+  uint32_t voff[PIECES];
+  constexpr int APIECES = 2 * ABLK / 4;            // a wavefront's pieces i < APIECES are rows of A (ABLK % 2 == 0)
+  static_assert((2 * ABLK) % 4 == 0, "the A / W boundary falls between two rounds of the four wavefronts");
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
     const int piece = wave + 4 * i;                 // block piece >> 1, half piece & 1
@@ -118,19 +122,21 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
     const int blk = piece >> 1;
     if (blk < ABLK) {
       const int t = t0 + blk * 16 + r;
-      src[i] = A + (int64_t)(t < T ? t : T - 1) * C + c * 16;
+      voff[i] = (uint32_t)((t < T ? t : T - 1) - t0) * (uint32_t)C + (uint32_t)(c * 16);
     } else {
       const int wb = blk - ABLK;                     // weight rows dealt over a wavefront's NT tiles (FPQ_GEMM_ROWS_EPILOGUE)
       const int o = o0 + (wb / NT) * (16 * NT) + NT * r + wb % NT;
-      src[i] = W + (int64_t)(o < O ? o : O - 1) * C + c * 16;
+      voff[i] = (uint32_t)((o < O ? o : O - 1) - o0) * (uint32_t)C + (uint32_t)(c * 16);
     }
   }
 #define FPQ_GLDS8_ISSUE(s, buf)                                                                                     \
   _Pragma("unroll") for (int i_ = 0; i_ < PIECES; ++i_)                                                             \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i_] + (s) * 128),       \
-                                       (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +            \
-                                                                                 (wave + 4 * i_) * 1024),           \
-                                       16, 0, 0)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                 \
+                   :                                                                                                \
+                   : "v"(voff[i_]), "s"(gbase[i_ < APIECES ? 0 : 1] + (s) * 128),                                   \
+                     "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +     \
+                                                                                       (wave + 4 * i_) * 1024))    \
+                   : "m0")
   FPQ_GLDS8_ISSUE(0, 0);
   FPQ_GEMM_ROWS_STAGE_SCALES(STAGE);
 
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 1 : 2)) FPQ_NOPK void gemm_fp8
   const int a_base = wm * MT * 2048, b_base = (ABLK + wn * NT) * 2048;
 
   for (int s = 0; s < steps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler does not see the LDS-DMA loads above
     FPQ_SYNC();   // stage s has landed; the other buffer's readers are done
     if (s + 1 < steps) { FPQ_GLDS8_ISSUE(s + 1, (s + 1) & 1); }
     const uint8_t* st = smem + (s & 1) * STAGE;
