@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
   if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
   const int t0 = row_blk * BM, o0 = col_blk * BN;
 
-  const uint8_t* src[PIECES];
+  // LDS-DMA sources: scalar base per operand + 32-bit lane offset, in assembly with explicit waits (as in gemm_fp4_glds_kernel)
+  const uint8_t* const gbase[2] = {A + (int64_t)t0 * row_bytes, W + (int64_t)o0 * row_bytes};
+  uint32_t voff[PIECES];
+  static_assert((3 * ASB) % 4 == 0, "the A / W boundary falls between two rounds of the four wavefronts");
+  constexpr int APIECES = 3 * ASB / 4;              // a wavefront's pieces i < APIECES are rows of A
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
     const int piece = wave + 4 * i;                 // super-block piece / 3, part piece % 3
@@ -48,19 +52,21 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
     c = c < 0 ? c + 6 : c;                          // logical chunk this lane fetches
     if (sb < ASB) {
       const int t = t0 + sb * 32 + r;
-      src[i] = A + (int64_t)(t < T ? t : T - 1) * row_bytes + c * 16;
+      voff[i] = (uint32_t)((t < T ? t : T - 1) - t0) * (uint32_t)row_bytes + (uint32_t)(c * 16);
     } else {
       const int ti = 2 * (sb - ASB) + (r >> 4);      // 16-row tile of the weight side; its rows are dealt over a wavefront's
       const int o = o0 + (ti / NT) * (16 * NT) + NT * (r & 15) + ti % NT;   // NT tiles (FPQ_GEMM_ROWS_EPILOGUE)
-      src[i] = W + (int64_t)(o < O ? o : O - 1) * row_bytes + c * 16;
+      voff[i] = (uint32_t)((o < O ? o : O - 1) - o0) * (uint32_t)row_bytes + (uint32_t)(c * 16);
     }
   }
-#define FPQ_GLDS6_ISSUE(s, buf)                                                                                     \
-  _Pragma("unroll") for (int i_ = 0; i_ < PIECES; ++i_)                                                             \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i_] + (s) * 96),        \
-                                       (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +            \
-                                                                                 (wave + 4 * i_) * 1024),           \
-                                       16, 0, 0)
+#define FPQ_GLDS6_ONE(s, buf, i_)                                                                                   \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                     \
+               :                                                                                                    \
+               : "v"(voff[i_]), "s"(gbase[(i_) < APIECES ? 0 : 1] + (s) * 96),                                      \
+                 "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +         \
+                                                                                   (wave + 4 * (i_)) * 1024))      \
+               : "m0")
+#define FPQ_GLDS6_ISSUE(s, buf) _Pragma("unroll") for (int i_ = 0; i_ < PIECES; ++i_) FPQ_GLDS6_ONE(s, buf, i_)
   FPQ_GLDS6_ISSUE(0, 0);
   FPQ_GEMM_ROWS_STAGE_SCALES(STAGE);
 
@@ -82,17 +88,17 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
   }
   const int a_base = wm * MT * 1536, b_base = ASB * 3072 + wn * NT * 1536;   // tile row mt -> 1536 * mt (two per super-block)
 
-  // Two LDS stages, one barrier per step; the LDS-DMA instructions of step s+1 are issued one at a time between the
-  // MFMAs of step s.  Measured on mat_qkv [65536 x 1920 -> 5760] (ms; 128x128 / 256x128 tiles): DMA burst after the
-  // barrier 0.81 / 0.81, interleaved 0.79 / 0.75, register staging (global_load + ds_write) 0.88 / 0.85, three-stage
-  // ring with counted vmcnt 0.92, the burst loop without MFMAs 0.70, without DMA 0.60.  In-kernel stamps of the burst
-  // form: 2000 cycles per step = ~250 waiting at the barrier + 400-680 issuing six LDS-DMAs (65-110 cycles each)
-  // + the 16 MFMAs (608 cycles alone, 1216 for the two wavefronts of a SIMD): the operand feed, not the matrix pipe.
+  // Two LDS stages, one barrier per step; the LDS-DMA pieces of step s+1 are issued in one burst behind the barrier.
+  // History of that choice on mat_qkv [65536 x 1920 -> 5760] (ms): with the compiler's form of the load (per-lane 64-bit
+  // pointers) the burst measured 0.81 and one piece after every third MFMA 0.75 - 0.79, so rounds 1 - 3 interleaved;
+  // with scalar base + lane offset in assembly (round 4) the burst is the faster one: 0.627 interleaved, 0.603 burst.
+  // Also measured: register staging (global_load + ds_write) 0.85 - 0.88, a three-stage ring with counted vmcnt 0.92,
+  // requesting tile row m + 1's fragment before the MFMAs of row m (no gain: the SIMD's second wavefront covers it).
   for (int s = 0; s < steps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler does not see the LDS-DMA loads
     FPQ_SYNC();   // stage s has landed; the other buffer's readers are done
     const uint8_t* st = smem + (s & 1) * STAGE;
-    const bool more = s + 1 < steps;
-    const int nb = (s + 1) & 1;
+    if (s + 1 < steps) { FPQ_GLDS6_ISSUE(s + 1, (s + 1) & 1); }
     v8i_t bf[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -100,9 +106,6 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
       const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
       bf[n] = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
     }
-    // (requesting row m + 1's fragment before the MFMAs of row m - the compiler puts each row's three ds_reads right in front
-    // of their MFMAs with a full wait - was measured in round 4: no gain, the second wavefront of the SIMD covers that latency)
-    int issued = 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const uint8_t* p = st + a_base + m * 1536;
@@ -111,19 +114,15 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf[n], acc[m][n], 2, 2, 0, 0, 0, 0);   // fp6 e2m3, unscaled
-        constexpr int DMA_EVERY = (MT * NT) / PIECES > 0 ? (MT * NT) / PIECES : 1;   // one DMA piece after every DMA_EVERY-th MFMA
-        if (((m * NT + n) % DMA_EVERY) == DMA_EVERY - 1 && issued < PIECES) {
-          if (more)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[issued] + (s + 1) * 96),
-                                             (__attribute__((address_space(3))) void*)(smem + nb * STAGE + (wave + 4 * issued) * 1024),
-                                             16, 0, 0);
-          ++issued;
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        // a scheduling fence after every third MFMA - where the interleaved form issued its pieces: without the fences the
+        // compiler's order of the rows' ds_reads and MFMAs is 5 % slower (0.635 against 0.603 ms), measured both ways
+        // (a fence after every MFMA, every second or every fourth measures the same; in the FP8 kernel fences cost 2 %)
+        if ((m * NT + n) % 3 == 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
 #undef FPQ_GLDS6_ISSUE
+#undef FPQ_GLDS6_ONE
   FPQ_GEMM_ROWS_EPILOGUE();
 }
 
