@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE kernel a few times (for rocprofv3 --pmc passes).
-usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|token6|group6|sym|calib|channel|gemm}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
+usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|token6|group6|sym|calib|channel|gemm|gemm6|gemm8}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -52,6 +52,14 @@ elif which == "gemm":
     ac, asc = gemm.quantize_mx(x)
     wc, wsc = gemm.quantize_mx(w)
     fn = lambda: gemm.linear_fp4(ac, asc, wc, wsc)
+elif which in ("gemm6", "gemm8"):   # the row-scaled GEMMs of the W6A6 configuration (6-bit packed / E4M3 bytes)
+    from fpqvar_amd import gemm
+    x = torch.randn(65536, C, device=dev).half()
+    w = torch.randn(5760, C, device=dev) * 0.02
+    quant, lin = (gemm.quantize_fp6, gemm.linear_fp6) if which == "gemm6" else (gemm.quantize_fp8, gemm.linear_fp8)
+    ac, asc = quant(x)
+    wc, wsc = quant(w)
+    fn = lambda: lin(ac, asc, wc, wsc)
 elif which == "calib":
     from fpqvar_amd import calibrate as cal
     shapes = cal.var_linear_shapes(30)
