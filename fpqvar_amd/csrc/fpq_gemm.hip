@@ -131,17 +131,19 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
   const int G = (int)(k / 128);
   hipStream_t st = (hipStream_t)stream;
-  // Default: the LDS-DMA kernel - 256 x 128 tiles (two workgroups per CU) when there are at least 1024 of them (two rounds
-  // of the chip's 512 resident workgroups: round 4, 3 - 5 % faster than 128 x 128 on the VAR-d30 shapes from 25 600 tokens
-  // on), else 128 x 128 tiles (three per CU); the register-staged kernel when the LDS image does not fit (very long K).
-  // FPQ_GEMM_CFG (experiments, tests): 0..2 register-staged tilings, 10 / 20 LDS-DMA tilings (256x128, 128x128).
+  // Default: the LDS-DMA kernel with 128 x 128 tiles (three workgroups per CU); 256 x 128 tiles (two per CU) from 4000 of them
+  // on (round 4: 2 - 5 % faster at [65536 x 1920] x {1920, 5760, 7680} and from 16 900 tokens on for the wide Linears, 3 - 5 %
+  // slower between 1000 and 4000 tiles) while two of them fit a CU's 160 KB of LDS (the scale tiles grow with K: from K = 3840 on
+  // only one would, and the smaller tile is 15 % faster there - tools/gemm_k_sweep.py); 64 x 128 tiles while the 128 x 128 ones
+  // would fill less than half of the chip's 768 slots (the first scale steps of a generation: 8.4 against 11.4 us at 100 tokens;
+  // tools/gemm_small_steps.py); the register-staged kernel when the LDS image does not fit (very long K).
+  // FPQ_GEMM_CFG (experiments, tests): 0..2 register-staged tilings, 10 / 20 / 30 LDS-DMA tilings (256x128, 128x128, 64x128).
   const char* env = getenv("FPQ_GEMM_CFG");
   const int64_t big_tiles = ((tokens + 255) / 256) * ((outs + 127) / 128);
-  // (the LDS-DMA kernel reads the bias four outputs at a time: a bias that is not 8-byte aligned goes to the other kernel)
-  // ... and while two of them fit a CU's 160 KB of LDS (the scale tiles grow with K: from K = 3840 on only one would, and
-  // the smaller tile is 15 % faster there - tools/gemm_k_sweep.py)
+  const int64_t mid_tiles = ((tokens + 127) / 128) * ((outs + 127) / 128);
   const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds(G) <= 160 * 1024;
-  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : env ? atoi(env) : (big_tiles >= 1024 && big_fits_twice) ? 10 : 20;
+  // (the LDS-DMA kernel reads the bias four outputs at a time: a bias that is not 8-byte aligned goes to the other kernel)
+  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : env ? atoi(env) : mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
 #define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
   do {                                                                                                               \
     using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
@@ -176,8 +178,9 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
       return check_launch();                                                                                         \
     }                                                                                                                \
   } while (0)
+  if (cfg == 30) FPQ_GEMM_GLDS(2, 4);   // 64 x 128 tiles
   if (cfg == 10) FPQ_GEMM_GLDS(8, 4);
-  if (cfg == 10 || cfg == 20) FPQ_GEMM_GLDS(4, 4);   // (the larger tile's LDS image may not fit where the smaller one's does)
+  if (cfg == 10 || cfg == 20 || cfg == 30) FPQ_GEMM_GLDS(4, 4);   // (the larger tile's LDS image may not fit where the smaller one's does)
 #undef FPQ_GEMM_GLDS
   if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
   else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
@@ -200,7 +203,8 @@ int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_sca
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const char* env6 = getenv("FPQ_GEMM6_CFG");     // 0: 128 x 128 tiles, 1: 256 x 128 (default for tall problems)
-  const int cfg6 = env6 ? atoi(env6) : (tokens >= 4096 ? 1 : 0);
+  // 256 x 128 tiles from 4096 tokens on for the wide Linears, from 32768 on for outs < 4096 (tools/gemm_small_steps.py fp6)
+  const int cfg6 = env6 ? atoi(env6) : (tokens >= 4096 && (outs >= 4096 || tokens >= 32768) ? 1 : 0);
 #define FPQ_GO6(TA, TW, MT, NT)                                                                                     \
   do {                                                                                                               \
     using Cfg = GemmFp6Cfg<MT, NT>;                                                                                  \

@@ -1363,20 +1363,20 @@ def test_fp4_gemm(dev, T, O, K):
     assert gemm.linear_fp4(ac, asc, wc, wsc.half(), None).shape == (T, O)        # fp16 weight scales, no bias
 
 
-@pytest.mark.parametrize("T,O,K", ((300, 392, 1920), (4096, 8192, 256)))
+@pytest.mark.parametrize("T,O,K", ((300, 392, 1920), (16384, 8192, 128)))
 def test_fp4_gemm_tile_configurations_agree(dev, T, O, K, monkeypatch):
-    """Every tiling of the FP4 GEMM (FPQ_GEMM_CFG, read at each call): the two LDS-DMA tilings do the same arithmetic per
+    """Every tiling of the FP4 GEMM (FPQ_GEMM_CFG, read at each call): the three LDS-DMA tilings do the same arithmetic per
     element and must agree bit for bit - with bias, gate and residual, on ragged edges - and with the default choice
-    ((4096, 8192): 1024 tiles of 256 x 128, the size from which the larger tile is the default); the register-staged
-    tilings multiply the two scales first and stay within the rounding of one fp32 product.  A bias that is not 8-byte
-    aligned is served by the register-staged kernel."""
+    ((300, 392): 12 tiles of 128 x 128, the smallest tile is the default; (16384, 8192): 4096 tiles of 256 x 128, past
+    the size from which the larger tile is); the register-staged tilings multiply the two scales first and stay within
+    the rounding of one fp32 product.  A bias that is not 8-byte aligned is served by the register-staged kernel."""
     from fpqvar_amd import gemm
     g = torch.Generator().manual_seed(7 + T)
     x = (torch.randn(T, K, generator=g) * torch.exp(0.3 * torch.randn(T, K, generator=g))).half().to(dev)
     w = (torch.randn(O, K, generator=g) * 0.02).to(dev)
     bias_store = (torch.randn(O + 4, generator=g) * 0.1).half().to(dev)
     bias = bias_store[:O]
-    gate = torch.randn(6 if T == 300 else 8, 1, O, generator=g).half().to(dev)     # [B, 1, outs]: 50 / 512 rows per gate row
+    gate = torch.randn(6 if T == 300 else 8, 1, O, generator=g).half().to(dev)     # [B, 1, outs]: 50 / 2048 rows per gate row
     resid = torch.randn(T, O, generator=g).half().to(dev)
     ac, asc = gemm.quantize_mx(x)
     wc, wsc = gemm.quantize_mx(w)
@@ -1391,7 +1391,7 @@ def test_fp4_gemm_tile_configurations_agree(dev, T, O, K, monkeypatch):
         return plain, fused
 
     base = run("20")
-    for cfg in ("10", None):
+    for cfg in ("10", "30", None):
         got = run(cfg)
         assert_bits_equal(got[0], base[0], f"cfg {cfg} plain")
         assert_bits_equal(got[1], base[1], f"cfg {cfg} fused")
