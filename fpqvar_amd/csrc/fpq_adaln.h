@@ -860,12 +860,21 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
       }
     }
     FPQ_PHASE("ln_reduce_rstd");
+#ifdef FPQ_ADALN_ABLATE_STATS   // measurement only (wrong results): what the kernel would cost with the row statistics given
+    sum1 = 0.0f;
+    s2 = (float)ad.cols;
+    sum1b = 0.0f;
+    s2b = (float)ad.cols;
+#else
     wave_sum2_dpp(sum1, s2);
+#endif
     const float mean = sum1 * inv_c;
     float var = __builtin_fmaf(-mean, mean, s2 * inv_c);
     float mean_b = 0.0f, var_b = 1.0f;
     if constexpr (PAIR2) {
+#ifndef FPQ_ADALN_ABLATE_STATS
       wave_sum2_dpp(sum1b, s2b);
+#endif
       mean_b = sum1b * inv_c;
       var_b = __builtin_fmaf(-mean_b, mean_b, s2b * inv_c);
       if (!(mean * mean < 64.0f * var) || !(mean_b * mean_b < 64.0f * var_b)) {   // either row: both centred (rare)
