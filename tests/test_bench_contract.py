@@ -177,6 +177,21 @@ def test_bench_gpus2_launches_two_ranks_gloo(tmp_path):
     assert "cpu_baseline" not in res and "cpu_baseline" in res["omitted_at_n_gt_1"]           # N = 1 only, and the line says so
 
 
+def test_bench_gpus8_launches_eight_ranks_gloo(tmp_path):
+    """The driver's largest case, rehearsed on CPU: eight ranks, more ranks than the rehearsal's model has layers (some own
+    nothing), one line from rank 0."""
+    out = _rehearse(tmp_path, ["--gpus", "8", "--steps", "2", "--warmup", "1"], timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["config"]["parallelism"] == "shard8"
+    assert res["value"] > 0 and res["scaling"] == "weak"
+    wc = res["weight_calibration"]
+    assert "error" not in wc, wc
+    assert wc["n_gpus"] == 8 and wc["elements"] == 12 * 64 * 64 and wc["ms_with_all_gather"] > 0
+
+
 def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
     out = _rehearse(tmp_path, ["--gpus", "2", "--steps", "1", "--warmup", "0"],
                     {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

@@ -75,7 +75,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", (2, 3))
+@pytest.mark.parametrize("world", (2, 3, 8))   # 8: the node the driver scales to (one process per GPU there, gloo on the CPU here)
 def test_calibrate_all_gather_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
