@@ -1444,6 +1444,37 @@ def test_row_scaled_gemm_tile_configurations_agree(dev, kind, T, O, K, monkeypat
     assert bool((err <= tol).all()), float((err / tol).max())
 
 
+@pytest.mark.parametrize("kind", ("fp4", "fp6", "fp8"))
+def test_gemm_full_size_row_and_column_permutations(dev, kind):
+    """The matrix-core GEMMs at the bench shape [65536 x 1920] . [1920 -> 5760], through a property that needs no reference:
+    every output element depends on ONE activation row and ONE weight row, and the K-sum order inside a tile is fixed, so
+    permuting the activation rows (or the weight rows) permutes the output rows (columns) bit for bit - whatever tile,
+    wavefront and lane an element lands in.  Plus a float64 check on a 64 x 64 corner of the result."""
+    from fpqvar_amd import gemm
+    T, O, K = 65536, 5760, 1920
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = (torch.randn(T, K, device=dev, generator=g) * torch.exp(0.3 * torch.randn(T, 1, device=dev, generator=g))).half()
+    w = torch.randn(O, K, device=dev, generator=g) * 0.02
+    bias = (torch.randn(O, device=dev, generator=g) * 0.1).half()
+    quant, lin, deq = {"fp4": (gemm.quantize_mx, gemm.linear_fp4, gemm.dequantize_mx), "fp6": (gemm.quantize_fp6, gemm.linear_fp6, gemm.dequantize_fp6),
+                       "fp8": (gemm.quantize_fp8, gemm.linear_fp8, gemm.dequantize_fp8)}[kind]
+    (ac, asc), (wc, wsc) = quant(x), quant(w)
+    del x, w
+    y = lin(ac, asc, wc, wsc, bias)
+    pt = torch.randperm(T, device=dev, generator=g)
+    assert_bits_equal(lin(ac[pt].contiguous(), asc[pt].contiguous(), wc, wsc, bias), y[pt], f"{kind}: activation rows permuted")
+    po = torch.randperm(O, device=dev, generator=g)
+    assert_bits_equal(lin(ac, asc, wc[po].contiguous(), wsc[po].contiguous(), bias[po].contiguous()), y[:, po], f"{kind}: weight rows permuted")
+    rows = torch.tensor([0, 1, 127, 128, 255, 256, 4095, 32767, 32768, 65535] + list(range(1000, 1054)), device=dev)
+    cols = torch.tensor([0, 3, 4, 63, 64, 127, 128, 1919, 1920, 5759] + list(range(2000, 2054)), device=dev)
+    a64 = deq(ac[rows].contiguous(), asc[rows].contiguous()).double().view(len(rows), K)
+    w64 = deq(wc[cols].contiguous(), wsc[cols].contiguous()).double().view(len(cols), K)
+    ref = a64 @ w64.t() + bias[cols].double()
+    err = (y[rows][:, cols].double() - ref).abs()
+    tol = 2.0 ** -10 * ref.abs() + 1e-5 * (a64.abs() @ w64.abs().t()) + 1e-6
+    assert bool((err <= tol).all()), float((err / tol).max())
+
+
 def test_fp4_linear_module(dev, golden):
     """FP4Linear vs the reference-path QuantizedLinear (fake-quant + fp16 GEMM) on the golden toy layer."""
     from fpqvar_amd import gemm
