@@ -38,6 +38,9 @@ _SIGS = {
     "fpq_version": (_c.c_int, []),
     "fpq_strerror": (_c.c_char_p, [_c.c_int]),
     "fpq_build_tag": (_c.c_char_p, []),
+    "fpq_set_option": (_c.c_int, [_c.c_char_p, _c.c_int]),
+    "fpq_get_option": (_c.c_int, [_c.c_char_p, _c.POINTER(_c.c_int)]),
+    "fpq_option_name": (_c.c_char_p, [_c.c_int]),
     "fpq_table_values": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_float)]),
     "fpq_quant_nearest": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
                                       _c.c_void_p]),
@@ -105,6 +108,8 @@ _SIGS = {
                                     _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p]),
     "fpq_gemm_fp4_mx_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                        _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_gemm_fp4_gelu_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                           _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_gemm_fp8_rows_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                          _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_gemm_fp6_rows_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
@@ -159,6 +164,48 @@ def use_variant(path: str, expect_tag: Optional[str] = None) -> ctypes.CDLL:
 
 def build_tag() -> str:
     return lib().fpq_build_tag().decode()
+
+
+OPTION_DEFAULT = -2147483648   # FPQ_OPTION_DEFAULT
+
+
+def set_option(name: str, value: Optional[int]) -> None:
+    """fpq_set_option: an experiment switch of the library (tests and A/B tools; include/fpq.h).  None = the built-in choice.
+    Process-wide: the compiled binding and the ctypes layer share the one loaded libfpq_hip.so."""
+    check(lib().fpq_set_option(name.encode(), OPTION_DEFAULT if value is None else int(value)), f"fpq_set_option({name})")
+
+
+def get_option(name: str) -> Optional[int]:
+    """Current value of a switch, None while it is at the built-in choice."""
+    v = _c.c_int(0)
+    check(lib().fpq_get_option(name.encode(), _c.byref(v)), f"fpq_get_option({name})")
+    return None if v.value == OPTION_DEFAULT else v.value
+
+
+def option_names() -> list:
+    l, out, i = lib(), [], 0
+    while True:
+        n = l.fpq_option_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+class option:
+    """`with _lib.option("FPQ_NO_HW4", 1): ...` - a switch for the duration of a block, restored afterwards."""
+
+    def __init__(self, name: str, value: Optional[int]):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.before = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.before)
+        return False
 
 
 def check(status: int, what: str) -> None:

@@ -8,6 +8,51 @@
 
 #include "fpq.h"
 
+// ---------------------------------------------------------------------------------
+// Process-wide experiment switches (include/fpq.h, fpq_set_option).  ONE table of ints for both translation units
+// (defined in fpq_kernels.hip), filled from the environment once when the library is loaded and changed afterwards only
+// through fpq_set_option: the launch paths read an int, never the environment.
+// ---------------------------------------------------------------------------------
+#define FPQ_OPTION_LIST(X)                                                                                             \
+  X(FPQ_NO_HW4, 1)          /* E2M1: keep the bucket table instead of the FP4 conversion hardware */                   \
+  X(FPQ_NO_HW6, 1)          /* E2M3 / E3M2: keep the bucket table instead of the FP6 conversion hardware */            \
+  X(FPQ_NO_FAST32, 1)       /* fp32 rows: IEEE division + closed form instead of approximate-then-verify */            \
+  X(FPQ_ADALN_NO_PAIR2, 1)  /* adaLN producer at C = 1024: one row per tile */                                         \
+  X(FPQ_ROT_BUTTERFLY, 1)   /* the butterfly form of the 128-point transform instead of the matrix cores */            \
+  X(FPQ_ADALN_V1, 1)        /* first-generation adaLN kernel */                                                        \
+  X(FPQ_ADALN_NO_TIGHT, 1)                                                                                             \
+  X(FPQ_NO_WAVE_ROWS, 1)    /* long fp16 rows: one workgroup per row even when a wavefront would hold it */            \
+  X(FPQ_GEMM_CFG, 0)        /* FP4 GEMM tiling: 0..2 register-staged, 10 / 20 / 30 LDS-DMA 256x128 / 128x128 / 64x128 */ \
+  X(FPQ_GEMM6_CFG, 0)       /* FP6 GEMM tiling: 0 128x128, 1 256x128 */                                                 \
+  X(FPQ_GEMM8_CFG, 0)       /* FP8 GEMM tiling: 0 128x128, 1 256x128 */                                                 \
+  X(FPQ_ROT_WGS, 0)         /* rotate_quant: workgroups per generation */                                              \
+  X(FPQ_ADALN_ROWS, 0)      /* adaLN producer: rows per workgroup */                                                   \
+  X(FPQ_ADALN_TAIL, 0)      /* adaLN producer: rows at the end of the grid cut into finer tiers */                     \
+  X(FPQ_ADALN_GRID, 0)      /* first-generation adaLN kernel: grid cap */                                              \
+  X(FPQ_ADALN_LANES, 0)     /* adaLN producer: 64 (wavefront per row) or 256 (workgroup per row) */                    \
+  X(FPQ_BIGTAB_RPB, 0)                                                                                                 \
+  X(FPQ_BIGTAB_U, 0)                                                                                                   \
+  X(FPQ_BIGTAB_CAP, 0)
+enum FpqOptId {
+#define FPQ_OPT_ENUM(name, is_flag) OPT_##name,
+  FPQ_OPTION_LIST(FPQ_OPT_ENUM)
+#undef FPQ_OPT_ENUM
+  FPQ_OPT_COUNT
+};
+extern "C" __attribute__((visibility("hidden"))) int fpq_option_table[FPQ_OPT_COUNT];
+// a flag: set and not zero; a number: its value, or `dflt` while unset
+static inline int fpq_opt_raw(int id) { return __atomic_load_n(&fpq_option_table[id], __ATOMIC_RELAXED); }
+static inline bool fpq_flag(int id) { const int v = fpq_opt_raw(id); return v != FPQ_OPTION_DEFAULT && v != 0; }
+static inline bool fpq_opt_set(int id) { return fpq_opt_raw(id) != FPQ_OPTION_DEFAULT; }
+static inline int fpq_opt(int id, int dflt) { const int v = fpq_opt_raw(id); return v == FPQ_OPTION_DEFAULT ? dflt : v; }
+
+// Helpers of fpq_kernels.hip that fpq_gemm.hip's fused fc1 epilogue needs too (internal to the library, not exported):
+// the bucket table + arguments of a dual-format quantizer (copied into caller-provided Lut16Args / Lut16Tab objects, whose
+// layout the two translation units share through fpq_fast16.h), and the "any NaN => the whole result is zero" fix-up launch.
+extern "C" __attribute__((visibility("hidden"))) int fpq_internal_dual_lut(int neg_table, int pos_table, void* args_out, size_t args_bytes,
+                                                                           void* tab_out, size_t tab_bytes);
+extern "C" __attribute__((visibility("hidden"))) int fpq_internal_zero_if_flag(void* out, int64_t n_bytes, void* scratch, void* stream);
+
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -138,12 +138,11 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   // would fill less than half of the chip's 768 slots (the first scale steps of a generation: 8.4 against 11.4 us at 100 tokens;
   // tools/gemm_small_steps.py); the register-staged kernel when the LDS image does not fit (very long K).
   // FPQ_GEMM_CFG (experiments, tests): 0..2 register-staged tilings, 10 / 20 / 30 LDS-DMA tilings (256x128, 128x128, 64x128).
-  const char* env = getenv("FPQ_GEMM_CFG");
-  const int64_t big_tiles = ((tokens + 255) / 256) * ((outs + 127) / 128);
+    const int64_t big_tiles = ((tokens + 255) / 256) * ((outs + 127) / 128);
   const int64_t mid_tiles = ((tokens + 127) / 128) * ((outs + 127) / 128);
   const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds(G) <= 160 * 1024;
   // (the LDS-DMA kernel reads the bias four outputs at a time: a bias that is not 8-byte aligned goes to the other kernel)
-  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : env ? atoi(env) : mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
+  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : fpq_opt_set(OPT_FPQ_GEMM_CFG) ? fpq_opt(OPT_FPQ_GEMM_CFG, 0) : mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
 #define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
   do {                                                                                                               \
     using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
@@ -170,11 +169,11 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
       if (w_scale_dtype == FPQ_F16)                                                                                  \
         hipLaunchKernelGGL((gemm_fp4_glds_kernel<_Float16, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,      \
                            a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,                   \
-                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi, GemmNoFc1{});      \
       else                                                                                                           \
         hipLaunchKernelGGL((gemm_fp4_glds_kernel<float, MT, NT>), dim3((unsigned)n_wg), dim3(256), lds, st,         \
                            a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,                      \
-                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi);                   \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi, GemmNoFc1{});      \
       return check_launch();                                                                                         \
     }                                                                                                                \
   } while (0)
@@ -189,6 +188,67 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   return check_launch();
 }
 
+// fc1 with GELU and fc2's dual-format input quantizer in the GEMM's epilogue (fpq_gemm_fp4.h, GemmFc1)
+int fpq_gemm_fp4_gelu_dual(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                           int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
+                           int64_t k, void* nan_flag, fpq_stream_t stream) {
+  if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
+  if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  // outs % 128: an output tile is one quantization group wide
+  if (k % 128 != 0 || k > 128 * 64 || outs % 128 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if (tokens == 0 || outs == 0) return FPQ_OK;
+  if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out | (uintptr_t)gelu_out) & 15) != 0 || ((uintptr_t)bias & 7) != 0 ||
+      ((uintptr_t)nan_flag & 7) != 0)
+    return FPQ_ERR_ARG;
+  // the dual quantizer's table and arguments, built once by the quantizers' translation unit (immutable afterwards)
+  struct Dual { GemmFc1 xe; int rc; };
+  static const Dual dual = [] {
+    Dual d;
+    d.rc = fpq_internal_dual_lut(FPQ_E1M2_NEG, FPQ_E2M1_POS, &d.xe.a, sizeof(d.xe.a), &d.xe.tab, sizeof(d.xe.tab));
+    d.xe.h_out = nullptr;
+    d.xe.nan_flag = nullptr;
+    return d;
+  }();
+  if (dual.rc != FPQ_OK) return dual.rc;
+  GemmFc1 xe = dual.xe;
+  xe.h_out = (_Float16*)gelu_out;
+  xe.nan_flag = (uint32_t*)nan_flag;
+  const int G = (int)(k / 128);
+  hipStream_t st = (hipStream_t)stream;
+  GemmEpi epi{nullptr, nullptr, 1};
+  // tile choice as fpq_gemm_fp4_mx_ex (FPQ_GEMM_CFG 10 / 20 / 30 forces one of the three LDS-DMA tilings)
+  const int64_t big_tiles = ((tokens + 255) / 256) * (outs / 128), mid_tiles = ((tokens + 127) / 128) * (outs / 128);
+  const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds_fc1(G, xe.a.shift) <= 160 * 1024;
+  const int want = fpq_opt(OPT_FPQ_GEMM_CFG, 0);
+  const int cfg = (want == 10 || want == 20 || want == 30) ? want : mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
+#define FPQ_GEMM_FC1(MT, NT)                                                                                         \
+  do {                                                                                                               \
+    using Cfg = GemmGldsCfg<MT, NT>;                                                                                 \
+    const size_t lds = Cfg::lds_fc1(G, xe.a.shift);                                                                  \
+    if (lds <= 160 * 1024) {                                                                                         \
+      const int64_t n_col = outs / Cfg::BN, n_row = (tokens + Cfg::BM - 1) / Cfg::BM;                                \
+      const int64_t n_wg = 8 * ((n_col + 7) / 8) * n_row;                                                            \
+      if (n_wg > 0x7FFFFFFF) return FPQ_ERR_SHAPE;                                                                   \
+      if (w_scale_dtype == FPQ_F16)                                                                                  \
+        hipLaunchKernelGGL((gemm_fp4_glds_kernel<_Float16, MT, NT, GemmFc1>), dim3((unsigned)n_wg), dim3(256), lds, st, \
+                           a_codes, (const _Float16*)a_scales, w_codes, (const _Float16*)w_scales,                   \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi, xe);          \
+      else                                                                                                           \
+        hipLaunchKernelGGL((gemm_fp4_glds_kernel<float, MT, NT, GemmFc1>), dim3((unsigned)n_wg), dim3(256), lds, st, \
+                           a_codes, (const _Float16*)a_scales, w_codes, (const float*)w_scales,                      \
+                           (const _Float16*)bias, (_Float16*)out, (int)tokens, (int)outs, (int)k, epi, xe);          \
+      if (int rc = check_launch()) return rc;                                                                        \
+      return nan_flag ? fpq_internal_zero_if_flag(out, tokens * outs * 2, nan_flag, stream) : FPQ_OK;                \
+    }                                                                                                                \
+  } while (0)
+  if (cfg == 30) FPQ_GEMM_FC1(2, 4);
+  if (cfg == 10) FPQ_GEMM_FC1(8, 4);
+  FPQ_GEMM_FC1(4, 4);
+#undef FPQ_GEMM_FC1
+  return FPQ_ERR_SHAPE;   // K too long for the LDS-DMA kernel's scale tiles
+}
+
 int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
                          const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
                          int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
@@ -201,10 +261,13 @@ int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_sca
   if (tokens == 0 || outs == 0) return FPQ_OK;
   if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  // the LDS-DMA pieces address a tile by a 32-bit lane offset (row inside the tile x row bytes + chunk): the 256-row tile's
+  // last row must stay below 2^32 (k above ~22 M would wrap and read wrong rows silently)
+  if (255 * (k * 3 / 4) + 128 >= (1ll << 32)) return FPQ_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const char* env6 = getenv("FPQ_GEMM6_CFG");     // 0: 128 x 128 tiles, 1: 256 x 128 (default for tall problems)
+  // FPQ_GEMM6_CFG 0: 128 x 128 tiles, 1: 256 x 128 (default for tall problems)
   // 256 x 128 tiles from 4096 tokens on for the wide Linears, from 32768 on for outs < 4096 (tools/gemm_small_steps.py fp6)
-  const int cfg6 = env6 ? atoi(env6) : (tokens >= 4096 && (outs >= 4096 || tokens >= 32768) ? 1 : 0);
+  const int cfg6 = fpq_opt_set(OPT_FPQ_GEMM6_CFG) ? fpq_opt(OPT_FPQ_GEMM6_CFG, 0) : (tokens >= 4096 && (outs >= 4096 || tokens >= 32768) ? 1 : 0);
 #define FPQ_GO6(TA, TW, MT, NT)                                                                                     \
   do {                                                                                                               \
     using Cfg = GemmFp6Cfg<MT, NT>;                                                                                  \
@@ -241,9 +304,9 @@ int fpq_gemm_fp8_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_sca
   if (tokens == 0 || outs == 0) return FPQ_OK;
   if (k == 0 || !a_codes || !a_scales || !w_codes || !w_scales || !out) return FPQ_ERR_ARG;
   if ((((uintptr_t)a_codes | (uintptr_t)w_codes | (uintptr_t)out) & 15) != 0) return FPQ_ERR_ARG;
+  if (255 * k + 128 >= (1ll << 32)) return FPQ_ERR_SHAPE;   // 32-bit lane offsets inside a tile, as in fpq_gemm_fp6_rows_ex
   hipStream_t st = (hipStream_t)stream;
-  const char* env8 = getenv("FPQ_GEMM8_CFG");
-  const int cfg8 = env8 ? atoi(env8) : 0;
+  const int cfg8 = fpq_opt(OPT_FPQ_GEMM8_CFG, 0);
 #define FPQ_GO8(TA, TW, MT, NT)                                                                                     \
   do {                                                                                                               \
     using Cfg = GemmFp8Cfg<MT, NT>;                                                                                  \

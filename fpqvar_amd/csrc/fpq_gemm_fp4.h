@@ -1,5 +1,5 @@
 // fpq_gemm_fp4.h - F2: a REAL low-precision consumer for the quantized
-// activations and weights.  Included by fpq_kernels.hip inside its anonymous namespace.
+// activations and weights.  Included by fpq_gemm.hip inside its anonymous namespace (the operand-emitting quantizer: fpq_codes_mx.h).
 //
 // The reference fake-quantizes and then runs an fp16 GEMM on the de-quantized tensors
 // (tr/quant_utils.py:765-767: F.linear(act_quant(x), W_q)).  With per-group(128) FP4-E2M1 on both
@@ -296,15 +296,99 @@ FPQ_NOPK __device__ __forceinline__ void load_scale_tiles(const _Float16* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The fc1 tail (round 5): everything between the fc1 GEMM and fc2's GEMM in the reference's FFN
+//     h  = F.gelu(fc1(x), approximate="tanh")                              tr/basic_var.py:120      (fp16 tensor, fp32 arithmetic)
+//     q  = fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128)            tr/quant_utils.py:415-452, bound at :991
+// as the epilogue of gemm_fp4_glds_kernel: every tile is BN = 128 outputs wide and starts at a multiple of 128, i.e. it
+// holds WHOLE quantization groups - one per token row - so both scales of a group are tile-local.
+//   * y = half(acc + bias) exactly as the plain epilogue rounds it (the Linear output the reference's GELU sees);
+//   * h = half(gelu(float(y))): torch's formula in torch's operation order, 0.5 x (1 + tanh(beta (x + kappa x^3))), with
+//     the device library's tanh restated (__ocml_tanh_f32: a polynomial below 0.625, 1 - 2 / (exp(2|u|) + 1) above) - within
+//     one fp16 ulp of torch's on every fp16 input, checked exhaustively (tests/test_gpu_fc1_fused.py);
+//   * per token row the maxima of the negative and of the positive side over the lane's four outputs, the 16 lanes of the
+//     row (DPP) and the two wavefronts that share the group (LDS), one thread per row turns them into the two scales
+//     (row_scale16, dual_poison: the arithmetic of rows16_lut_subwave_kernel<DUAL>), and every lane quantizes its own
+//     values with quant_pair16_dual = one packed pair of quant_vec16<DUAL>: bit-equal to the stand-alone quantizer on h;
+//   * "any NaN in the tensor => the whole result is zero" (the reference's global clamp, tr/quant_utils.py:421-422) keeps
+//     its flag + fix-up launch (fpq_kernels.hip, zero_if_flag_kernel): a row that saw a NaN raises the flag.
+// LDS: the bucket table behind the scale tiles (staged in the prologue); the maxima exchange and the row scales in the
+// stage buffer the last K group does not use.
+struct GemmNoFc1 {};
+struct GemmFc1 {
+  _Float16* h_out;       // nullptr, or fp16 [T, O] receiving h (the tensor the quantizer saw)
+  uint32_t* nan_flag;    // nullptr, or the 8-byte scratch of fpq_quant_rows_dual
+  Lut16Args a;           // the (e1m2_neg, e2m1_pos) bucket table's arguments ...
+  Lut16Tab tab;          // ... and the table itself, by value (as the stand-alone quantizers take it)
+};
+
+// torch: aten/src/ATen/native/cuda/ActivationGeluKernel.cu, GeluCUDAKernelImpl, approximate == tanh (opmath = float):
+//   kBeta = M_SQRT2 * M_2_SQRTPI * 0.5, kKappa = 0.044715; x_cube = x * x * x; inner = kBeta * (x + kKappa * x_cube);
+//   0.5 * x * (1 + tanh(inner))
+// FPQ_GELU_FMA: the compiler that built torch contracts x + kKappa * x_cube into one fma (hipcc's default for HIP sources);
+// this library is built with contraction off, so the fma is spelled out.
+#ifndef FPQ_GELU_FMA
+#define FPQ_GELU_FMA 1
+#endif
+FPQ_NOPK __device__ __forceinline__ float tanh_devlib(float x) {   // __ocml_tanh_f32 (ROCm device library), restated
+  const float y = __builtin_fabsf(x);
+  float z;
+  if (y < 0.625f) {
+    const float y2 = x * x;
+    float p = __builtin_fmaf(y2, -0x1.758e7ap-8f, 0x1.521192p-6f);
+    p = __builtin_fmaf(y2, p, -0x1.b8389cp-5f);
+    p = __builtin_fmaf(y2, p, 0x1.110704p-3f);
+    p = __builtin_fmaf(y2, p, -0x1.555532p-2f);
+    z = __builtin_fmaf(y2, y * p, y);
+  } else {
+    const float t = __builtin_expf(2.0f * y);
+    z = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+  }
+  return __builtin_copysignf(z, x);
+}
+FPQ_NOPK __device__ __forceinline__ float gelu_tanh_like_torch(float x) {
+  const float kBeta = (float)(1.41421356237309504880 * 1.12837916709551257390 * 0.5), kKappa = 0.044715f;
+  const float x3 = x * x * x;
+#if FPQ_GELU_FMA
+  const float inner = kBeta * __builtin_fmaf(kKappa, x3, x);
+#else
+  const float inner = kBeta * (x + kKappa * x3);
+#endif
+  return 0.5f * x * (1.0f + tanh_devlib(inner));
+}
+
+// max over the 16 lanes of a DPP row of two packed unsigned 16-bit values (row_max_dpp<16> on pairs)
+FPQ_NOPK __device__ __forceinline__ uint32_t row16_pk_max_u16(uint32_t v) {
+  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+// one packed pair of quant_vec16<DUAL> (fpq_fast16.h): each half takes the reciprocal and the scale of its sign's side
+FPQ_NOPK __device__ __forceinline__ uint32_t quant_pair16_dual(uint32_t wk, const uint16_t* lut, int shift, float ih_n, uint32_t s2_n,
+                                                               float ih_p, uint32_t s2_p) {
+  const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)wk, 15, 1), m1 = (uint32_t)((int)wk >> 31);   // all ones: negative
+  const float h0 = u2f((fbits16(ih_n) & m0) | (fbits16(ih_p) & ~m0)), h1 = u2f((fbits16(ih_n) & m1) | (fbits16(ih_p) & ~m1));
+  const uint32_t mp = pk_ashr_i16(wk, 15);
+  const uint32_t sc = (s2_n & mp) | (s2_p & ~mp);
+  const uint32_t rb = div_pair16(wk, h0, 0.0f, h1, 0.0f);
+  const uint32_t u = pk_sub_u16(rb, pk_lshr_u16(rb, 15));   // negative patterns: magnitude - 1
+  return pk_mul_f16(lut_pair16(lut, u, shift), sc);
+}
+
 // target("no-packed-fp32-ops"): beside MFMAs a packed fp32 op costs as much as two scalar ones and blocks the issue
 // port twice as long (tools/probe/valu_mfma_overlap.hip); with the feature off the compiler emits scalar
 // v_mul_f32 / v_fma_f32 and schedules them - and the MFMA hazard wait states - itself.
-template <typename Tsw, int MT, int NT>
+// XE = GemmNoFc1: the plain Linear (+ gate / residual tail); XE = GemmFc1: the fc1 tail above.
+template <typename Tsw, int MT, int NT, typename XE = GemmNoFc1>
 __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4_glds_kernel(const uint8_t* __restrict__ A,
                                                               const _Float16* __restrict__ sa,
                                                               const uint8_t* __restrict__ W, const Tsw* __restrict__ sw,
                                                               const _Float16* __restrict__ bias,
-                                                              _Float16* out, int T, int O, int C, GemmEpi epi) {
+                                                              _Float16* out, int T, int O, int C, GemmEpi epi, XE xe) {
+  constexpr bool FC1 = !__is_same(XE, GemmNoFc1);
   constexpr int WR = 2, WC = 2, BM = 16 * MT * WR, BN = 16 * NT * WC, NTHR = 256;
   constexpr int ABLK = BM / 16, BBLK = BN / 16, NBLK = ABLK + BBLK, STAGE = NBLK * 1024;
   static_assert(NBLK % 4 == 0, "blocks are dealt round-robin to the four wavefronts");
@@ -367,6 +451,11 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   FPQ_GLDS_ISSUE(0, 0);
 
   load_scale_tiles<Tsw, BM, BN, NTHR>(sa, sw, lsa, lsw, t0, o0, T, O, G, tid);
+  uint16_t* lut = nullptr;
+  if constexpr (FC1) {   // the dual quantizer's bucket table, behind the scale tiles; visible after the first barrier of the main loop
+    lut = (uint16_t*)(lsw + G * BN);
+    lut16_stage(lut, xe.tab, xe.a.shift);
+  }
 
   // A wait the COMPILER sees (the builtin, not assembly): its scoreboard still carries the scale loads above, whose last
   // waits it counted without knowing of the stage-0 pieces in the same queue - left like that, it protects their
@@ -467,6 +556,63 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   v4f_t b4 = v4f_t{0, 0, 0, 0};
 #pragma unroll
   for (int n = 0; n < NT; ++n) b4[n] = (float)bias_h[n];
+  if constexpr (FC1) {
+    // (see the comment above GemmFc1)  Row r of the tile = wm * WROWS + m * 16 + 4 * (lane >> 4) + i.
+    uint32_t* xch = (uint32_t*)(smem + (G & 1) * STAGE);     // [2 (wn)][BM]: packed (max|h| over h < 0) | (max h over h > 0) << 16
+    u32x4* rsc = (u32x4*)(xch + 2 * BM);                     // [BM]: {1 / s_neg, 1 / s_pos, s_neg x 2, s_pos x 2}
+    static_assert(2 * BM * 4 + BM * 16 <= STAGE, "exchange + row scales fit the idle stage buffer");
+    uint32_t hw[MT][4][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      u32x4 mx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float g[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) g[n] = gelu_tanh_like_torch((float)(_Float16)(acc[m][n][i] + b4[n]));
+        hw[m][i][0] = f2h2(g[0], g[1]);
+        hw[m][i][1] = f2h2(g[2], g[3]);
+        // unsigned maximum = the most negative value (or a negative NaN), signed maximum = the largest positive one (or a
+        // positive NaN): dual_max_acc / dual_max_finish of fpq_fast16.h on the lane's two words
+        uint32_t mn, mp;
+        dual_max_finish(pk_max_u16(hw[m][i][0], hw[m][i][1]), pk_max_i16(hw[m][i][0], hw[m][i][1]), mn, mp);
+        mx[i] = row16_pk_max_u16(mn | (mp << 16));
+      }
+      if ((lane & 15) == 0) *(u32x4*)(xch + wn * BM + wm * WROWS + m * 16 + 4 * (lane >> 4)) = mx;
+      if (xe.h_out) {
+        const int t_first = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (t_first + i < T && o < O)
+            __builtin_nontemporal_store(u32x2{hw[m][i][0], hw[m][i][1]}, (u32x2*)(xe.h_out + (int64_t)(t_first + i) * O + oc));
+      }
+    }
+    FPQ_SYNC();
+    if (tid < BM) {   // one thread per token row: the group's two scales
+      const uint32_t p0 = xch[tid], p1 = xch[BM + tid];
+      const uint32_t l0 = p0 & 0xFFFFu, l1 = p1 & 0xFFFFu, h0 = p0 >> 16, h1 = p1 >> 16;
+      const uint32_t mn = l0 > l1 ? l0 : l1, mp = h0 > h1 ? h0 : h1;
+      if ((mn > 0x7C00u || mp > 0x7C00u) && xe.nan_flag && t0 + tid < T)   // a NaN in this group (the builtin: atomicOr() is a header function without this kernel's target attribute - it would become a call)
+        __hip_atomic_fetch_or(xe.nan_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      RowScale16 sn = row_scale16(mn, xe.a.fneg.gmax, xe.a.inv_gneg), sp = row_scale16(mp, xe.a.fpos.gmax, xe.a.inv_gpos);
+      dual_poison(sn, sp);
+      rsc[tid] = u32x4{fbits16(sn.inv), fbits16(sp.inv), sn.s16x2, sp.s16x2};
+    }
+    FPQ_SYNC();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int r_first = wm * WROWS + m * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 sc = rsc[r_first + i];
+        const uint32_t q0 = quant_pair16_dual(hw[m][i][0], lut, xe.a.shift, u2f(sc[0]), sc[2], u2f(sc[1]), sc[3]);
+        const uint32_t q1 = quant_pair16_dual(hw[m][i][1], lut, xe.a.shift, u2f(sc[0]), sc[2], u2f(sc[1]), sc[3]);
+        if (t0 + r_first + i < T && o < O)
+          __builtin_nontemporal_store(u32x2{q0, q1}, (u32x2*)(out + (int64_t)(t0 + r_first + i) * O + oc));
+      }
+    }
+    return;
+  }
   const bool gate_far = epi.gate && epi.rows_per_gate >= WROWS;
   int gq0 = 0, gr0 = 0, gq_last = 0;
   if (epi.gate) {
@@ -523,8 +669,9 @@ template <int MT, int NT>
 struct GemmGldsCfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
   static size_t lds(int G) {
-    return 2 * (size_t)(BM + BN) * 64 + (size_t)G * (BM + BN) * 4;   // two stages + the scale tiles (the epilogue uses no LDS)
+    return 2 * (size_t)(BM + BN) * 64 + (size_t)G * (BM + BN) * 4;   // two stages + the scale tiles (the plain epilogue uses no LDS)
   }
+  static size_t lds_fc1(int G, int shift) { return lds(G) + ((size_t)2 << (16 - shift)); }   // + the dual quantizer's bucket table
 };
 
 template <int MT, int NT, int WR, int WC>
@@ -536,23 +683,3 @@ struct GemmCfg {
     return main > epi ? main : epi;
   }
 };
-
-// per-group(128) E2M1 quantization of fp16 rows straight to hardware nibbles + fp16 scales: the fused
-// activation quantizer of fpq_fast16.h with the level table replaced by a code table
-__global__ __launch_bounds__(kBlock) void rows16_codes_mx_kernel(const u32x4* __restrict__ x, uint32_t* __restrict__ codes,
-                                                                uint16_t* __restrict__ scales, int64_t n_vec,
-                                                                Lut16Args a, Lut16Tab tab) {
-  __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
-  {
-    lut16_stage(lut, tab, a.shift);
-    __syncthreads();
-  }
-  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * kBlock) {
-    const u32x4 w = __builtin_nontemporal_load(x + v);
-    const uint32_t m = row_max_dpp<16>(vec_absmax16(w));
-    const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-    if ((threadIdx.x & 15) == 0) scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
-    const uint32_t packed = codes_vec16(w, lut, a.shift, s.inv, s.inv_lo);
-    codes[v] = packed;
-  }
-}

@@ -26,9 +26,33 @@
 //     for xn < 0.  tests/ prove it equal to the scan on every fp16 input and on fp32
 //     neighbourhoods of every midpoint; fpq_quant_nearest keeps the literal scan.
 #include "fpq_common.h"
-// experiment switches ("Experiment switches"): read from the environment once per process (FPQ_NO_FAST32
-// at every call: tests/test_gpu_configs.py flips it to compare the two paths in one process)
-#define FPQ_ENV(name) ([] { static const char* const v = getenv(name); return v; }())
+#include <string.h>
+
+// Experiment switches (fpq_common.h, FPQ_OPTION_LIST; include/fpq.h, fpq_set_option): the table both translation units
+// read.  The initialiser below is the ONLY place in the library that touches the environment.
+int fpq_option_table[FPQ_OPT_COUNT];
+namespace {
+struct FpqOptionDesc { const char* name; int is_flag; };
+const FpqOptionDesc kOptionDescs[FPQ_OPT_COUNT] = {
+#define FPQ_OPT_DESC(name, is_flag) {#name, is_flag},
+    FPQ_OPTION_LIST(FPQ_OPT_DESC)
+#undef FPQ_OPT_DESC
+};
+struct FpqOptionInit {
+  FpqOptionInit() {
+    for (int i = 0; i < FPQ_OPT_COUNT; ++i) {
+      const char* e = getenv(kOptionDescs[i].name);
+      fpq_option_table[i] = (!e || !*e) ? FPQ_OPTION_DEFAULT : kOptionDescs[i].is_flag ? (strcmp(e, "0") != 0) : atoi(e);
+    }
+  }
+} fpq_option_init;
+int option_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < FPQ_OPT_COUNT; ++i)
+    if (strcmp(name, kOptionDescs[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace
 
 namespace {
 
@@ -381,9 +405,9 @@ __global__ __launch_bounds__(kBlock) void rows_negrev_scalar_kernel(const T* __r
 #endif
 #include "fpq_fast32.h"
 #include "fpq_adaln.h"
-#include "fpq_gemm_fp4.h"   // the code-emitting quantizer kernels live beside their consumers;
-#include "fpq_gemm_fp8.h"   // the GEMM templates themselves are instantiated in fpq_gemm.hip
-#include "fpq_gemm_fp6.h"
+#include "fpq_codes_mx.h"    // the operand-emitting quantizers of the matrix-core GEMMs (the GEMM kernels themselves,
+#include "fpq_codes_fp8.h"   // fpq_gemm_fp4.h / fp8.h / fp6.h, are compiled in fpq_gemm.hip only: an edit there does not
+#include "fpq_codes_fp6.h"   // rebuild this translation unit)
 
 // ---------------------------------------------------------------------------------
 // L0: literal scan (quant/quant_kernel.cu:25-37), any table of k <= 256 floats.
@@ -1023,7 +1047,7 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
     }
   }
   if constexpr (!DUAL) {
-    if (lpr == 16 && neg_id == FPQ_E2M1 && pos_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4")) {
+    if (lpr == 16 && neg_id == FPQ_E2M1 && pos_id == FPQ_E2M1 && !fpq_flag(OPT_FPQ_NO_HW4)) {
       // no table to stage, so nothing to amortise over a tile: ONE vector per lane on the full grid, the best plain-copy
       // shape of this chip (profiles/r02_copy_persistent_probe.txt: 0.81 against 0.777 for 8 KiB tiles); same-process
       // A/B against U = 2: 77.0 - 77.5 vs 79.0 - 79.4 us in steady state (profiles/r03_headline_u1.txt)
@@ -1037,7 +1061,7 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   if constexpr (!DUAL) {
     // E2M3 / E3M2 per group of 128 and per row of 64 (the KV cache's head rows): levels from the FP6 conversion hardware, four
     // vectors per lane = the 32 values of one conversion, full grid (no table to amortise); FPQ_NO_HW6 keeps the table
-    if ((lpr == 16 || lpr == 8) && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !getenv("FPQ_NO_HW6")) {
+    if ((lpr == 16 || lpr == 8) && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !fpq_flag(OPT_FPQ_NO_HW6)) {
       const int64_t tiles4 = (n_vec + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4);
       const dim3 g4(grid_for(tiles4, 1 << 20));
 #define FPQ_HW6_GO(L, H)                                                                                                         \
@@ -1083,17 +1107,17 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
   const int64_t tiles = (n_vec + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
   const dim3 grid(grid_for(tiles, 1 << 20));
   // values out: the transform on the matrix cores (fpq_rotate_mfma.h), one 32-group tile per wavefront
-  static const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
+  const bool butterfly = FPQ_ROT_BUTTERFLY_BUILD || fpq_flag(OPT_FPQ_ROT_BUTTERFLY);
   if (!butterfly) {
     // Every workgroup the same number of passes over its tiles.  With a bucket table to stage per workgroup the grid is
     // two generations of the FPQ_ROT_WAVES workgroups a CU holds (3072: 84.2 us against 85.9 for one generation, round 2).
     // The table-free E2M1 forms have next to no prologue and want SHORT workgroups - the grid drains faster at its end:
     // values out, 3072 / 7680 / 12288 / 16384 workgroups: 83.2 / 82.2 / 82.1 / 80.3 us (one pass each at [65536 x 1920]);
     // codes out: 57.3 / 52.8 / 53.0 / 53.6 us (profiles/r03_rotate_grid.txt).  FPQ_ROT_WGS overrides.
-    const bool hw4 = table_id == FPQ_E2M1 && !getenv("FPQ_NO_HW4");   // E2M1 values or FP4 operands: levels / codes from the conversion hardware
+    const bool hw4 = table_id == FPQ_E2M1 && !fpq_flag(OPT_FPQ_NO_HW4);   // E2M1 values or FP4 operands: levels / codes from the conversion hardware
     const int64_t per_wg = (int64_t)(kBlock / 64) * kRqTileVec;
     const int64_t wg_tiles = (n_vec + per_wg - 1) / per_wg;
-    static const int64_t resident_env = [] { const char* e = FPQ_ENV("FPQ_ROT_WGS"); return e ? atoll(e) : 0ll; }();
+    const int64_t resident_env = fpq_opt(OPT_FPQ_ROT_WGS, 0);
     // (with a smoothing vector every workgroup stages it - 7.5 KiB at C = 1920 - so a few passes each: 7680 / 2560)
     const int64_t resident = resident_env > 0 ? resident_env : !hw4 ? 2 * 256ll * FPQ_ROT_WAVES
                              : smooth ? (code_scales ? 2560 : 7680) : code_scales ? 8192 : 16384;
@@ -1143,12 +1167,12 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   {
     // second generation (fpq_adaln.h): fp16 or fp32 rows of up to 2560 channels, one batch entry per workgroup
     constexpr bool X32 = sizeof(Tin) == 4;
-    if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !FPQ_ENV("FPQ_ADALN_V1")) {
+    if (lanes_per_row == 64 && r.vec_per_row <= 64 * 5 && !fpq_flag(OPT_FPQ_ADALN_V1)) {
       if (h.args.shift < 6) return FPQ_ERR_TABLE;   // symmetric tables only (<= 2 x 512 buckets)
       const int64_t L = ad.rows_per_batch;
       const int64_t n_batches = (rows + L - 1) / L;
-      static const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || FPQ_ENV("FPQ_ROT_BUTTERFLY") != nullptr;
-      const char* rows_env = FPQ_ENV("FPQ_ADALN_ROWS");
+      const bool adaln_butterfly = FPQ_ROT_BUTTERFLY_BUILD || fpq_flag(OPT_FPQ_ROT_BUTTERFLY);
+      const bool rows_env = fpq_opt_set(OPT_FPQ_ADALN_ROWS);
       // Large launches: chunks of 16 rows (4 per wavefront) amortise the staging of the modulation; small launches (the
       // early scale steps of a generation: 100 .. 3600 rows) are latency-bound and want every CU busy: one row per wavefront
       // (profiles/r02_small_steps.json; round 4, cold inputs, 4 / 8 / 12 / 16 rows per workgroup over the ten steps of d30 and
@@ -1162,16 +1186,16 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       // prologue's instructions per row count: 73.3 -> 70.5 us for codes, 89.7 -> 87.1 for E4M3 bytes, 96.2 -> 93.4 for
       // per-token E2M3 values; profiles/r03_adaln_partition.txt)
       const bool issue_bound = !X32 && (code_scales != nullptr || token_mode != 0 || table_id != FPQ_E2M1);
-      int rows_per_wg = rows_env ? atoi(rows_env) : (rows >= 8192 ? (adaln_butterfly && rows >= 32768 ? 16 : issue_bound && rows >= 32768 ? 12 : 8) : 4);
+      int rows_per_wg = rows_env ? fpq_opt(OPT_FPQ_ADALN_ROWS, 0) : (rows >= 8192 ? (adaln_butterfly && rows >= 32768 ? 16 : issue_bound && rows >= 32768 ? 12 : 8) : 4);
       if (rows_per_wg < 1) rows_per_wg = 1;
       // rows of exactly 8 groups (C = 1024): two rows per tile (fpq_adaln.h, PAIR2) - workgroups of an even number of rows
       const bool pair2 = !adaln_butterfly && !X32 && r.vec_per_row == 128 && token_mode == 0 && !h_out && !y_out &&
-                         !getenv("FPQ_ADALN_NO_PAIR2");
+                         !fpq_flag(OPT_FPQ_ADALN_NO_PAIR2);
       if (pair2) rows_per_wg = rows_env ? ((rows_per_wg + 1) & ~1) : (rows >= 8192 ? 16 : 8);
       const int64_t per_batch = (L + rows_per_wg - 1) / rows_per_wg;
       if (n_batches * per_batch > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
       AdalnTiers tiers = {};
-      static const int tail_rows = FPQ_ENV("FPQ_ADALN_TAIL") ? atoi(FPQ_ENV("FPQ_ADALN_TAIL")) : 0;
+      const int tail_rows = fpq_opt(OPT_FPQ_ADALN_TAIL, 0);
       int64_t nb2 = 0, nb1 = 0;
       if (!adaln_butterfly && tail_rows > 0 && rows_per_wg > 4) {
         nb2 = (tail_rows + L - 1) / L;                                   // batch entries cut into chunks of 4 rows
@@ -1198,10 +1222,10 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
       const dim3 g3((unsigned)n_wg3);
       const size_t lds2 = 0;   // table, modulation planes and images live in static LDS
       // E2M1 values per group: levels from the FP4 conversion hardware, no table (fpq_adaln.h)
-      const bool hw4 = table_id == FPQ_E2M1 && !token_mode && !getenv("FPQ_NO_HW4");
-      static const bool tight_ok = FPQ_ADALN_TIGHT && !FPQ_ENV("FPQ_ADALN_NO_TIGHT");
+      const bool hw4 = table_id == FPQ_E2M1 && !token_mode && !fpq_flag(OPT_FPQ_NO_HW4);
+      const bool tight_ok = FPQ_ADALN_TIGHT && !fpq_flag(OPT_FPQ_ADALN_NO_TIGHT);
       // E2M3 / E3M2 values (per group, or per token: token_mode 1): levels from the FP6 conversion hardware, no table
-      const int hw6 = (token_mode <= 1 && !code_scales && !getenv("FPQ_NO_HW6")) ? (table_id == FPQ_E2M3 ? 1 : table_id == FPQ_E3M2 ? 2 : 0) : 0;
+      const int hw6 = (token_mode <= 1 && !code_scales && !fpq_flag(OPT_FPQ_NO_HW6)) ? (table_id == FPQ_E2M3 ? 1 : table_id == FPQ_E3M2 ? 2 : 0) : 0;
 #define FPQ_ADALN3(M, CODES, EMIT, TOKEN, HW4, TIGHT)                                                                  \
   hipLaunchKernelGGL((adaln_mfma_kernel<Tmod, M, CODES, EMIT, TOKEN, X32, HW4, TIGHT>), g3, dim3(kBlock), lds2, st,    \
                      (const u32x4*)x, (u32x4*)out, (u32x4*)h_out, (u32x4*)y_out, rows, ad, r, h.args, tab, tiers)
@@ -1284,8 +1308,7 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
   }
   const int64_t rows_per_wg = kBlock / lanes_per_row;
   int64_t g64 = (rows + rows_per_wg - 1) / rows_per_wg;
-  const char* cap_env = FPQ_ENV("FPQ_ADALN_GRID");
-  const int64_t cap = cap_env ? atoll(cap_env) : 8192;   // every workgroup stages the table once, then walks rows
+  const int64_t cap = fpq_opt(OPT_FPQ_ADALN_GRID, 8192);   // every workgroup stages the table once, then walks rows
   if (g64 > cap) g64 = cap;
   const dim3 g((unsigned)g64);
   const int maxc = (int)((r.vec_per_row + lanes_per_row - 1) / lanes_per_row);
@@ -1352,7 +1375,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   args.nan_flag = nan_flag;
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t vec_per_row = cols / 8;
-  if (vec_per_row <= 64 * 5 && !FPQ_ENV("FPQ_NO_WAVE_ROWS")) {
+  if (vec_per_row <= 64 * 5 && !fpq_flag(OPT_FPQ_NO_WAVE_ROWS)) {
     // one wavefront per row: 4 rows per workgroup pass, enough workgroups to keep every CU busy while the
     // table staging stays amortised
     const int mc = (int)((vec_per_row + 63) / 64);
@@ -1364,7 +1387,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
     // rows of four or five vectors per lane on E2M3 / E3M2 (per-token FP6 at C = 1920, 2048, 2304): levels from the FP6
     // conversion hardware, no table (fpq_fast16.h, fp6_levels_hw32); FPQ_NO_HW6 (read at every call) keeps the table
     if constexpr (!DUAL) {
-      if ((mc == 4 || mc == 5) && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !getenv("FPQ_NO_HW6")) {
+      if ((mc == 4 || mc == 5) && neg_id == pos_id && (neg_id == FPQ_E2M3 || neg_id == FPQ_E3M2) && !fpq_flag(OPT_FPQ_NO_HW6)) {
         int64_t g6 = (rows + 3) / 4;
         if (g6 > (1 << 20)) g6 = 1 << 20;   // nothing to amortise: one pass of four rows per workgroup
 #define FPQ_WAVE6(M, H) hipLaunchKernelGGL((rows16_lut_wave_kernel<false, M, true, H>), dim3((unsigned)g6), dim3(kBlock), lds, st, \
@@ -1391,8 +1414,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
   int64_t rpb = (rows + target_wgs - 1) / target_wgs;
   if (rpb < 1) rpb = 1;
   if (h.tab_valid && (1 << (16 - h.args.shift)) >= 1024) {   // 2 x 512 (E2M3: [16384 x 7680] 86.3 -> 83.4 us) or 2 x 1024 buckets to stage: two rows per workgroup
-    const char* e = FPQ_ENV("FPQ_BIGTAB_RPB");
-    rpb = e ? atoll(e) : 2;
+    rpb = fpq_opt(OPT_FPQ_BIGTAB_RPB, 2);
     if (rpb < 1) rpb = 1;
   }
   const int64_t grid = (rows + rpb - 1) / rpb;
@@ -1415,7 +1437,7 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
 // ---- fp32 rows of 128 (weights): fpq_fast32.h -------------------------------------------------
 inline bool fast32_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int table_id) {
   return in_dtype == FPQ_F32 && cols == 128 && kTables[table_id].symmetric && (((uintptr_t)x | (uintptr_t)out) & 15) == 0 &&
-         !getenv("FPQ_NO_FAST32");
+         !fpq_flag(OPT_FPQ_NO_FAST32);
 }
 
 // one tensor (segs == nullptr, `one` by value) or a device-resident segment table (grid.y = segment)
@@ -1449,7 +1471,7 @@ inline int launch_codes32(const CodesSeg32* segs, int n_segs, const CodesSeg32& 
 // long fp32 rows (per-channel weights): one wavefront or one workgroup per row (fpq_fast32.h)
 inline bool rows32_eligible(const void* x, const void* out, int64_t cols, int in_dtype, int table_id) {
   return in_dtype == FPQ_F32 && cols % 8 == 0 && cols >= 512 && cols / 4 <= 256 * 10 && kTables[table_id].symmetric &&
-         (((uintptr_t)x | (uintptr_t)out) & 15) == 0 && !getenv("FPQ_NO_FAST32");
+         (((uintptr_t)x | (uintptr_t)out) & 15) == 0 && !fpq_flag(OPT_FPQ_NO_FAST32);
 }
 
 template <typename Tout>
@@ -1538,6 +1560,34 @@ int fpq_version(void) { return FPQ_VERSION; }
 #define FPQ_BUILD_TAG "stock"
 #endif
 const char* fpq_build_tag(void) { return FPQ_BUILD_TAG; }
+
+int fpq_internal_dual_lut(int neg_table, int pos_table, void* args_out, size_t args_bytes, void* tab_out, size_t tab_bytes) {
+  if (neg_table < 0 || neg_table >= FPQ_NUM_TABLES || pos_table < 0 || pos_table >= FPQ_NUM_TABLES) return FPQ_ERR_TABLE;
+  const Lut16Host& h = lut16_host(neg_table, pos_table);
+  if (!h.tab_valid || args_bytes != sizeof(Lut16Args) || tab_bytes != sizeof(Lut16Tab)) return FPQ_ERR_TABLE;
+  memcpy(args_out, &h.args, sizeof(Lut16Args));
+  memcpy(tab_out, &h.tab, sizeof(Lut16Tab));
+  return FPQ_OK;
+}
+
+int fpq_internal_zero_if_flag(void* out, int64_t n_bytes, void* scratch, void* stream) {
+  hipLaunchKernelGGL(zero_if_flag_kernel, dim3(kFixupBlocks), dim3(kBlock), 0, (hipStream_t)stream, (uint8_t*)out, n_bytes, (uint32_t*)scratch);
+  return check_launch();
+}
+
+int fpq_set_option(const char* name, int value) {
+  const int i = option_index(name);
+  if (i < 0) return FPQ_ERR_ARG;
+  __atomic_store_n(&fpq_option_table[i], value, __ATOMIC_RELAXED);
+  return FPQ_OK;
+}
+int fpq_get_option(const char* name, int* value_out) {
+  const int i = option_index(name);
+  if (i < 0 || !value_out) return FPQ_ERR_ARG;
+  *value_out = fpq_opt_raw(i);
+  return FPQ_OK;
+}
+const char* fpq_option_name(int index) { return (index >= 0 && index < FPQ_OPT_COUNT) ? kOptionDescs[index].name : nullptr; }
 
 const char* fpq_strerror(int status) {
   switch (status) {
@@ -1815,10 +1865,8 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
     if ((1 << (16 - lut16_host(neg_table, pos_table).args.shift)) <= 1024)
       rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag);
     else {
-      const char* eu = FPQ_ENV("FPQ_BIGTAB_U");
-      const char* ec = FPQ_ENV("FPQ_BIGTAB_CAP");
-      const int cap = ec ? atoi(ec) : 16384;   // measured on [65536 x 7680]: 4096 -> 366 us, 16384 -> 348 us, full grid -> 367 us
-      if (eu && atoi(eu) == 8) rc = launch_fast16<true, 8>(x, out, rows, cols, neg_table, pos_table, st, cap, flag);
+      const int cap = fpq_opt(OPT_FPQ_BIGTAB_CAP, 16384);   // measured on [65536 x 7680]: 4096 -> 366 us, 16384 -> 348 us, full grid -> 367 us
+      if (fpq_opt(OPT_FPQ_BIGTAB_U, 4) == 8) rc = launch_fast16<true, 8>(x, out, rows, cols, neg_table, pos_table, st, cap, flag);
       else rc = launch_fast16<true, 4>(x, out, rows, cols, neg_table, pos_table, st, cap, flag);
     }
   } else if (!clip_absmax && fast16_block_eligible(x, out, cols, in_dtype, out_dtype)) {
@@ -1920,8 +1968,7 @@ static int adaln_rotate_quant_impl(const void* x, void* out, void* h_out, void* 
   // One wavefront per row while the row fits 5 vectors per lane (C <= 2560: no barrier in the row
   // loop; measured 0.180 ms vs 0.199 ms per [65500 x 1920] on MI355X), one workgroup per row beyond.
   // FPQ_ADALN_LANES / FPQ_ADALN_GRID override the choice for experiments.
-  const char* env = FPQ_ENV("FPQ_ADALN_LANES");
-  const int lanes = (env && !token_mode) ? atoi(env) : (cols / 8 <= 64 * 5 ? 64 : 256);
+  const int lanes = (fpq_opt_set(OPT_FPQ_ADALN_LANES) && !token_mode) ? fpq_opt(OPT_FPQ_ADALN_LANES, 64) : (cols / 8 <= 64 * 5 ? 64 : 256);
   const int lpr = (lanes == 64) ? 64 : 256;
   if (token_mode && lpr != 64) return FPQ_ERR_SHAPE;   // the per-token form keeps a row inside one wavefront: C <= 2560
   hipStream_t st = (hipStream_t)stream;
@@ -2170,7 +2217,7 @@ int fpq_quant_rows_codes(const void* x, uint8_t* codes, void* scales, int64_t ro
   hipStream_t st = (hipStream_t)stream;
   Fmt f = make_fmt(table_id);
   if (in_dtype == FPQ_F32 && cols == 128 && (((uintptr_t)x | (uintptr_t)codes) & 15) == 0 && (((uintptr_t)scales) & 3) == 0 &&
-      !getenv("FPQ_NO_FAST32")) {   // fp32 weights: the approximate-then-verify path (fpq_fast32.h, groups32_codes_kernel)
+      !fpq_flag(OPT_FPQ_NO_FAST32)) {   // fp32 weights: the approximate-then-verify path (fpq_fast32.h, groups32_codes_kernel)
     const CodesSeg32 one = {x, codes, scales, rows};
     return launch_codes32(nullptr, 1, one, rows, table_id, pack_nibbles != 0, st);
   }
@@ -2248,7 +2295,7 @@ int fpq_quant_rows_codes_segments(const fpq_codes_segment_t* segments_device, in
   if (n_segments == 0 || max_rows == 0) return FPQ_OK;
   if (!segments_device || (((uintptr_t)segments_device) & 7) != 0) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (in_dtype == FPQ_F32 && !getenv("FPQ_NO_FAST32")) {   // (segments are 16-byte aligned by contract, include/fpq.h)
+  if (in_dtype == FPQ_F32 && !fpq_flag(OPT_FPQ_NO_FAST32)) {   // (segments are 16-byte aligned by contract, include/fpq.h)
     static_assert(sizeof(CodesSeg32) == sizeof(CodesSeg), "one segment layout");
     return launch_codes32((const CodesSeg32*)segments_device, n_segments, CodesSeg32{nullptr, nullptr, nullptr, 0}, max_rows, table_id,
                           pack_nibbles != 0, st);

@@ -378,25 +378,29 @@ at::Tensor linear_fp4(const at::Tensor& a_codes, const at::Tensor& a_scales, con
   check_operand("linear_fp4(weight)", w_codes, w_scales, outs, k / 2, outs * (k / 128), dev);
   fpq_gemm_epilogue_t ep{nullptr, nullptr, 1};
   at::Tensor g, r, b;
+  at::Tensor out = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
+  if (tokens == 0 || outs == 0) return out;   // as the C ABI: valid, nothing to enqueue (and no reshape({-1, 0}) below)
+  // the epilogue reads gate / residual / bias in 8- and 16-byte pieces: a contiguous view at an odd storage offset is cloned
+  // here (the C ABI rejects the pointer; a misaligned bias would otherwise route to the slower register-staged kernel)
+  auto aligned = [](const at::Tensor& t) { return (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0 ? t : t.clone(); };
   if (gate.has_value()) {
     g = gate->reshape({-1, outs});
     TORCH_CHECK(g.scalar_type() == at::kHalf && g.size(0) > 0 && tokens % g.size(0) == 0 && g.device() == dev,
                 "linear_fp4: gate must be float16 [B, outs] with tokens % B == 0");
-    g = g.contiguous();
+    g = aligned(g.contiguous());
     ep.gate = g.data_ptr();
     ep.rows_per_gate = std::max<int64_t>(tokens / g.size(0), 1);
   }
   if (residual.has_value()) {
     r = residual->reshape({-1, outs});
     TORCH_CHECK(r.scalar_type() == at::kHalf && r.size(0) == tokens && r.device() == dev, "linear_fp4: residual must be float16 with ", tokens, " rows of ", outs);
-    r = r.contiguous();
+    r = aligned(r.contiguous());
     ep.residual = r.data_ptr();
   }
   if (bias.has_value()) {
     TORCH_CHECK(bias->numel() == outs && bias->device() == dev, "linear_fp4: bias must hold one value per output on the operands' device");
-    b = bias->detach().to(at::kHalf).reshape({-1}).contiguous();
+    b = aligned(bias->detach().to(at::kHalf).reshape({-1}).contiguous());
   }
-  at::Tensor out = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
   check(fpq_gemm_fp4_mx_ex((const uint8_t*)a_codes.data_ptr(), a_scales.data_ptr(), (const uint8_t*)w_codes.data_ptr(), w_scales.data_ptr(),
                            dtype_id(w_scales.scalar_type(), "linear_fp4"), b.defined() ? b.data_ptr() : nullptr, out.data_ptr(), tokens, outs, k,

@@ -132,6 +132,42 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     return out
 
 
+def linear_fp4_gelu_dual(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
+                         bias: Optional[torch.Tensor] = None, return_gelu: bool = False):
+    """fc1 of the AdaLN block's FFN up to fc2's GEMM in ONE launch (+ the dual quantizer's tiny NaN fix-up launch):
+    `fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(F.gelu(linear_fp4(a, w, bias), approximate="tanh"), 4, 128)`
+    (tr/basic_var.py:120-121, tr/quant_utils.py:415-452,991) as the epilogue of the FP4 GEMM (fpq_gemm_fp4_gelu_dual):
+    fp16 [tokens, outs], outs % 128 == 0.  return_gelu: also the GELU values the quantizer saw - the quantization is
+    bit-exact on THOSE, they sit within one fp16 ulp of torch's GELU of the Linear output."""
+    require_gpu(a_codes, "linear_fp4_gelu_dual")
+    if a_codes.dim() != 2 or w_codes.dim() != 2:
+        raise RuntimeError("linear_fp4_gelu_dual: codes must be [rows, K / 2]")
+    tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
+    if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16 or k % 128 != 0 or outs % 128 != 0:
+        raise RuntimeError("linear_fp4_gelu_dual: operand shapes / activation scale dtype mismatch (outs must be a multiple of 128)")
+    dev = a_codes.device
+    _check_operand("linear_fp4_gelu_dual(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), dev)
+    _check_operand("linear_fp4_gelu_dual(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), dev)
+    out = torch.empty((tokens, outs), dtype=torch.float16, device=dev)
+    h = torch.empty((tokens, outs), dtype=torch.float16, device=dev) if return_gelu else None
+    b = None
+    if bias is not None:
+        if bias.numel() != outs or bias.device != dev:
+            raise RuntimeError("linear_fp4_gelu_dual: bias must hold one value per output on the operands' device")
+        b = bias.detach().to(torch.float16).reshape(-1).contiguous()
+        if b.data_ptr() % 16:
+            b = b.clone()
+    if tokens and outs:
+        from .ops import _nan_scratch
+        with device_guard(dev):
+            flag = _nan_scratch(dev)
+            check(lib().fpq_gemm_fp4_gelu_dual(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
+                                               dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
+                                               None if h is None else h.data_ptr(), tokens, outs, k, flag.data_ptr(),
+                                               stream_ptr(dev)), "fpq_gemm_fp4_gelu_dual")
+    return (out, h) if return_gelu else out
+
+
 class FP4Linear(_ScaledOperandModule):
     """Drop-in for QuantizedLinear in the W4A4 per-group `fp_e2` configuration that runs on the FP4
     matrix cores instead of simulating FP4 in fp16: weights are stored as hardware E2M1 codes + one

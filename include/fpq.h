@@ -6,7 +6,9 @@
  *   - every pointer is a DEVICE pointer unless the name says `host`;
  *   - nothing allocates, nothing synchronises the host, everything is enqueued on
  *     `stream` (a hipStream_t passed as void*; NULL = the null stream);
- *   - re-entrant and thread-safe: no mutable global state;
+ *   - re-entrant and thread-safe: no mutable global state on any launch path.  The ONE piece of process-wide state is
+ *     the table of experiment switches below (fpq_set_option): filled from the environment once, when the library is
+ *     loaded, and read as plain ints afterwards - no entry point calls getenv();
  *   - returns FPQ_OK (0) or a negative FPQ_ERR_* code; on error nothing is enqueued;
  *   - rows == 0 / n == 0 is valid and enqueues nothing;
  *   - inputs are never written.
@@ -22,9 +24,10 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 123 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
+#define FPQ_VERSION 124 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
                            0.1.3: + fpq_quant_rows_codes_segments, fpq_dequant_rows_codes_segments (round 3);
-                           123: + fpq_build_tag (round 4) */
+                           123: + fpq_build_tag (round 4);
+                           124: + fpq_set_option, fpq_get_option, fpq_option_name, fpq_gemm_fp4_gelu_dual (round 5) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -62,6 +65,18 @@ const char* fpq_strerror(int status);
 /* Which build this is: "stock" for the shipped library, the name given to tools/build_variant.sh for a diagnostic
  * build (-DFPQ_BUILD_TAG).  The A/B tools assert on it so that a timing is never attributed to the wrong library. */
 const char* fpq_build_tag(void);
+
+/* Experiment switches - tests and the A/B tools only; a deployment never touches them.  Every switch is an int named
+ * like the environment variable that initialises it ("FPQ_NO_HW4", "FPQ_GEMM_CFG", ...; fpq_option_name enumerates
+ * them).  The environment is read ONCE, by the library's initialiser (a variable that is set and not empty: flags take
+ * 1 unless the text is "0", numbers take atoi of the text); later changes of the environment are not seen.
+ * fpq_set_option changes a switch for every later call in the process (value FPQ_OPTION_DEFAULT = back to the built-in
+ * choice); it is a relaxed atomic store - call it between launches, not concurrently with them, if the outcome matters.
+ * Both return FPQ_ERR_ARG for an unknown name. */
+#define FPQ_OPTION_DEFAULT (-2147483647 - 1)
+int fpq_set_option(const char* name, int value);
+int fpq_get_option(const char* name, int* value_out);
+const char* fpq_option_name(int index); /* NULL past the last one */
 
 /* Host-side copy of a built-in table exactly as the reference spells it
  * (ascending, duplicate zeros kept).  Returns the entry count, or FPQ_ERR_TABLE.
@@ -384,6 +399,19 @@ int fpq_gate_residual(const void* y, const void* gate, const void* residual, voi
 int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
                        int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
                        const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
+/* fc1 of the AdaLN block's FFN with everything up to fc2's GEMM in its epilogue (tr/basic_var.py:120-121; fc2's input
+ * quantizer is bound at tr/quant_utils.py:991 and defined at :415-452):
+ *     y   = half(dequant(a) @ dequant(w).T + bias)                         the Linear output of fpq_gemm_fp4_mx, bit for bit
+ *     h   = half(gelu_tanh(float(y)))                                      F.gelu(y, approximate="tanh") on the fp16 tensor
+ *     out = fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(h, 4, 128)           groups of 128 consecutive outputs, strength 1.0
+ * out: fp16 [tokens, outs], outs % 128 == 0.  gelu_out: NULL, or fp16 [tokens, outs] receiving h.  nan_flag: as in
+ * fpq_quant_rows_dual (8 bytes of zeroed persistent scratch: "a NaN anywhere in h => the whole result is zero", one tiny
+ * second launch; NULL skips the rule).  Parity: out == fpq_quant_rows_dual(h) bit for bit on the h produced here; h within
+ * one fp16 ulp of torch's GELU of y on every fp16 input (torch's formula in torch's operation order, the device library's
+ * tanh restated).  Replaces three launches and 10 B of HBM traffic per element behind the GEMM. */
+int fpq_gemm_fp4_gelu_dual(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                           int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
+                           int64_t k, void* nan_flag, fpq_stream_t stream);
 int fpq_gemm_fp8_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
                          const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
                          int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);

@@ -50,3 +50,20 @@ def assert_bits_equal(got: torch.Tensor, want: torch.Tensor, what: str = ""):
         raise AssertionError(
             f"{what}: {int(bad.sum())} of {bad.numel()} elements differ; first at flat index {k}: "
             f"got {g.reshape(-1)[k].item()!r} want {w.reshape(-1)[k].item()!r}")
+
+
+@pytest.fixture
+def lib_options():
+    """`lib_options(name, value)` sets an experiment switch of libfpq_hip.so (fpq_set_option, include/fpq.h) and the
+    fixture puts every touched switch back when the test ends.  value None = the library's built-in choice."""
+    from fpqvar_amd import _lib
+    saved = {}
+
+    def set_option(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+
+    yield set_option
+    for name, value in saved.items():
+        _lib.set_option(name, value)

@@ -104,3 +104,56 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.lib()
     monkeypatch.undo()
     assert _lib.lib().fpq_version() == FPQ_VERSION
+
+
+def test_option_table_is_the_only_reader_of_the_environment(lib):
+    """include/fpq.h: no entry point calls getenv().  (a) In the sources, getenv appears in ONE place, the initialiser of
+    the option table; (b) in the shipped library, the only code that calls getenv@plt is that initialiser (the static
+    constructor of fpq_kernels.hip) - checked in the disassembly of the host code."""
+    import subprocess
+    csrc = os.path.join(ROOT, "fpqvar_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                code = line.split("//")[0]
+                if "getenv" in code:
+                    hits.append((f, i))
+    assert len(hits) == 1 and hits[0][0] == "fpq_kernels.hip", hits
+    so = os.path.join(ROOT, "fpqvar_amd", "libfpq_hip.so")
+    dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", so], capture_output=True, text=True, check=True).stdout
+    callers, cur = set(), None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = m.group(1)
+        elif "<getenv@plt>" in line and cur != "getenv@plt":
+            callers.add(cur)
+    assert callers, "expected the option initialiser to call getenv"
+    assert all(("GLOBAL__sub_I" in c or "FpqOptionInit" in c or c.startswith(".plt")) for c in callers), callers
+
+
+def test_options_roundtrip_and_env_is_read_once(lib, monkeypatch):
+    from fpqvar_amd import _lib
+    names = _lib.option_names()
+    assert "FPQ_NO_HW4" in names and "FPQ_GEMM_CFG" in names and len(names) == len(set(names)) >= 19
+    assert lib.fpq_option_name(len(names)) is None and lib.fpq_option_name(-1) is None
+    for n in names:
+        before = _lib.get_option(n)
+        with _lib.option(n, 7):
+            assert _lib.get_option(n) == 7
+        assert _lib.get_option(n) == before
+    assert lib.fpq_set_option(b"FPQ_NO_SUCH_SWITCH", 1) == -1 and lib.fpq_set_option(None, 1) == -1
+    assert lib.fpq_get_option(b"FPQ_NO_HW4", None) == -1
+    # the environment was read when the library was loaded; a later change is not seen
+    before = _lib.get_option("FPQ_NO_HW6")
+    monkeypatch.setenv("FPQ_NO_HW6", "1" if not before else "0")
+    assert _lib.get_option("FPQ_NO_HW6") == before
+    # ... and a fresh process does see it, with the documented parsing (flags: 1 unless "0"; numbers: atoi; empty = unset)
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); from fpqvar_amd import _lib; "
+            "print(_lib.get_option('FPQ_NO_HW4'), _lib.get_option('FPQ_NO_HW6'), _lib.get_option('FPQ_GEMM_CFG'), "
+            "_lib.get_option('FPQ_NO_FAST32'), _lib.get_option('FPQ_ADALN_ROWS'))" % ROOT)
+    env = dict(os.environ, FPQ_NO_HW4="yes", FPQ_NO_HW6="0", FPQ_GEMM_CFG="20", FPQ_NO_FAST32="", FPQ_ADALN_ROWS="12")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "0", "20", "None", "12"], out

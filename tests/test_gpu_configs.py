@@ -3,6 +3,7 @@ Needs a real MI355X: run with ``-m gpu``.  Bit-exact (all NaNs equal, +0 / -0 di
 import pytest
 import torch
 
+from fpqvar_amd import _lib
 from oracle import fpq_oracle as orc
 from tests.conftest import assert_bits_equal, from_bits
 
@@ -163,7 +164,7 @@ def test_fast32_groups_vs_oracle(dev, table, out_dtype):
 @pytest.mark.parametrize("table", SYM)
 def test_fast32_codes_vs_generic_emitter_and_oracle(dev, table, pack):
     """fp32 groups -> codes + fp32 scales through the approximate-then-verify path (groups32_codes_kernel, round 4) against
-    the generic emitter (FPQ_NO_FAST32=1, read per call: IEEE division + closed form) on the boundary-saturated groups and
+    the generic emitter (library switch FPQ_NO_FAST32: IEEE division + closed form) on the boundary-saturated groups and
     the edge rows of test_fast32_groups_vs_oracle, and decoded against the oracle's values."""
     import os
     from fpqvar_amd import ops
@@ -192,11 +193,8 @@ def test_fast32_codes_vs_generic_emitter_and_oracle(dev, table, pack):
     for rows in (x.shape[0], 1, 31, 33):
         xr = x[:rows].contiguous()
         codes, scales = ops.quant_rows_codes(xr, table, 128, pack)
-        os.environ["FPQ_NO_FAST32"] = "1"
-        try:
+        with _lib.option("FPQ_NO_FAST32", 1):
             codes_g, scales_g = ops.quant_rows_codes(xr, table, 128, pack)
-        finally:
-            del os.environ["FPQ_NO_FAST32"]
         assert torch.equal(codes, codes_g), f"{table} pack={pack} rows={rows}: codes differ from the generic emitter"
         assert_bits_equal(scales, scales_g, f"{table} pack={pack} rows={rows}: scales")
         deq = ops.dequant_rows_codes(codes, scales, table, 128, torch.float32, pack)
@@ -210,11 +208,8 @@ def test_fast32_codes_equal_generic_on_64m_weights(dev):
     for kind in ("weights", "uniform"):
         x = torch.randn(1 << 26, device=dev, generator=g) * 0.02 if kind == "weights" else (torch.rand(1 << 26, device=dev, generator=g) * 2 - 1)
         codes, scales = ops.quant_rows_codes(x.view(-1, 128), "e2m1", 128, True)
-        os.environ["FPQ_NO_FAST32"] = "1"
-        try:
+        with _lib.option("FPQ_NO_FAST32", 1):
             codes_g, scales_g = ops.quant_rows_codes(x.view(-1, 128), "e2m1", 128, True)
-        finally:
-            del os.environ["FPQ_NO_FAST32"]
         assert torch.equal(codes, codes_g) and torch.equal(scales.view(torch.int32), scales_g.view(torch.int32)), kind
 
 
@@ -229,11 +224,8 @@ def test_fast32_equals_ieee_path_on_64m_weights(dev):
             x = torch.randn(1 << 26, device=dev, generator=g) * 0.02 if kind == "weights" else \
                 (torch.rand(1 << 26, device=dev, generator=g) * 2 - 1)
             fast = ops.quant_rows(x, table, 128, torch.float16)
-            os.environ["FPQ_NO_FAST32"] = "1"
-            try:
+            with _lib.option("FPQ_NO_FAST32", 1):
                 slow = ops.quant_rows(x, table, 128, torch.float16)
-            finally:
-                del os.environ["FPQ_NO_FAST32"]
             assert bool((fast.view(torch.int16) == slow.view(torch.int16)).all()), f"{table} {kind}"
             rows = slice(0, 64 * 128)
             assert_bits_equal(fast[rows], orc.per_group_kernel_sem(x[rows].cpu(), table, 128).half(), f"{table} {kind} vs oracle")

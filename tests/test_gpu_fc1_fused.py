@@ -1,0 +1,156 @@
+"""The fc1 tail fused into the FP4 GEMM (fpq_gemm_fp4_gelu_dual): GELU(tanh) and fc2's dual E1M2-/E2M1+
+per-group quantizer as the GEMM's epilogue (tr/basic_var.py:120-121, tr/quant_utils.py:415-452,991).
+Contract, as for the fused producers: the QUANTIZATION is bit-exact on the GELU values the kernel
+emits on request - against the oracle's dual quantizer and against the stand-alone HIP quantizer; the GELU values sit
+within one fp16 ulp of torch's F.gelu(y, approximate="tanh") of the Linear output y, on EVERY fp16 input (the domain is
+finite: all 65536 patterns are pushed through the epilogue); y itself is fpq_gemm_fp4_mx's output bit for bit."""
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from fpqvar_amd import _lib
+from oracle import fpq_oracle as orc
+from tests.conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch.device("cuda:0")
+
+
+def ordered(h: torch.Tensor) -> torch.Tensor:
+    """fp16 bit patterns as integers that grow with the value (-0 and +0 coincide): ulp distances are differences."""
+    b = h.view(torch.int16).to(torch.int32) & 0xFFFF
+    return torch.where(b >= 0x8000, 0x8000 - b, b)
+
+
+def ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """|a - b| in fp16 ulps; NaN against NaN counts 0, NaN against a number 2^16."""
+    na, nb = torch.isnan(a), torch.isnan(b)
+    d = (ordered(a) - ordered(b)).abs()
+    d = torch.where(na & nb, torch.zeros_like(d), d)
+    return torch.where(na ^ nb, torch.full_like(d, 1 << 16), d)
+
+
+def operands(dev, T, K, O, seed):
+    from fpqvar_amd import gemm
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(T, K, generator=g) * torch.exp(0.3 * torch.randn(T, K, generator=g))).half().to(dev)
+    w = (torch.randn(O, K, generator=g) * 0.05).to(dev)
+    bias = (torch.randn(O, generator=g) * 0.3).half().to(dev)
+    return gemm.quantize_mx(x), gemm.quantize_mx(w), bias
+
+
+@pytest.mark.parametrize("T,K,O", [(300, 256, 384), (1, 128, 128), (1000, 1920, 512), (70, 2304, 1152)])
+def test_fused_fc1_equals_gemm_gelu_quantizer(dev, T, K, O, lib_options):
+    """Every LDS-DMA tiling (64 / 128 / 256 rows x 128 outputs), ragged token counts: the emitted GELU values against torch's
+    GELU of the plain GEMM's output (<= 1 fp16 ulp), the quantized result against the stand-alone HIP quantizer on the emitted
+    values (bit-exact) and against the oracle's (bit-exact), and the one-tensor form against the two-tensor form."""
+    from fpqvar_amd import gemm, ops
+    a, w, bias = operands(dev, T, K, O, 11)
+    for cfg in (None, 30, 20, 10):
+        lib_options("FPQ_GEMM_CFG", cfg)
+        for b in (bias, None):
+            y = gemm.linear_fp4(*a, *w, b)
+            q, h = gemm.linear_fp4_gelu_dual(*a, *w, b, return_gelu=True)
+            ref_h = Fn.gelu(y, approximate="tanh")
+            d = ulp_diff(h, ref_h)
+            assert int(d.max()) <= 1, (cfg, T, K, O, int(d.max()), int((d > 0).sum()))
+            assert float((d > 0).float().mean()) < 0.01, "GELU: more than 1 % of the values differ from torch's"
+            assert_bits_equal(q, ops.quant_rows_dual(h, "e1m2_neg", "e2m1_pos", 128, 1.0), f"cfg {cfg}: fused vs stand-alone quantizer on the emitted GELU values")
+            assert_bits_equal(q.cpu(), orc.dual_per_group_kernel_sem(h.cpu(), "e1m2_neg", "e2m1_pos", 128, 1.0), f"cfg {cfg}: fused vs oracle")
+            assert_bits_equal(gemm.linear_fp4_gelu_dual(*a, *w, b), q, f"cfg {cfg}: without the GELU output")
+    # float32 weight scales (the reference quantizes weights in fp32) give the same result as their fp16 rounding would not: just run
+    wc, ws = w
+    q32 = gemm.linear_fp4_gelu_dual(*a, wc, ws.float() if ws.dtype == torch.float16 else ws.half().float(), bias)
+    assert q32.shape == (T, O) and q32.dtype == torch.float16
+
+
+def test_fused_fc1_gelu_on_every_fp16_input(dev):
+    """All 65536 fp16 patterns as the Linear output: zero activations (every product is 0) and the pattern as the bias of
+    its own output column.  The GELU the epilogue computes against torch's on this GPU: never more than one fp16 ulp apart,
+    NaN exactly where torch has NaN (NaN inputs and -inf: 0.5 * -inf * 0)."""
+    from fpqvar_amd import gemm
+    K, O = 128, 65536
+    every = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.float16).to(dev)
+    a = (torch.zeros(4, K // 2, dtype=torch.uint8, device=dev), torch.ones(4, 1, dtype=torch.float16, device=dev))
+    w = (torch.zeros(O, K // 2, dtype=torch.uint8, device=dev), torch.ones(O, 1, dtype=torch.float32, device=dev))
+    y = gemm.linear_fp4(*a, *w, every)
+    assert_bits_equal(y[0], torch.where(every == 0, torch.zeros_like(every), every), "the Linear output is the bias (0 + -0 = +0)")
+    q, h = gemm.linear_fp4_gelu_dual(*a, *w, every, return_gelu=True)
+    ref = Fn.gelu(y, approximate="tanh")
+    d = ulp_diff(h, ref)
+    worst = int(d.max())
+    n_diff = int((d[0] > 0).sum())
+    assert worst <= 1, (worst, every[d[0] > 1][:8].tolist(), h[0][d[0] > 1][:8].tolist(), ref[0][d[0] > 1][:8].tolist())
+    assert n_diff <= 64, f"{n_diff} of 65536 inputs differ from torch's GELU by one ulp (expected: a handful at fp16 rounding boundaries)"
+    assert torch.equal(torch.isnan(h), torch.isnan(ref))
+    # a NaN anywhere in h: the reference's global clamp makes the whole result zero (tr/quant_utils.py:421-422)
+    assert bool(torch.isnan(h).any()) and not bool(q.any()), "NaN rule: every output must be +0"
+    assert q.view(torch.int16).abs().max().item() == 0
+
+
+def test_fused_fc1_nan_rule_and_scratch(dev):
+    """One NaN in the GELU tensor (a NaN bias): every output zero, the 8-byte scratch zero again afterwards - eager and as
+    a replayed hipGraph; without a NaN the same buffers give the ordinary result again."""
+    from fpqvar_amd import gemm, ops
+    a, w, bias = operands(dev, 200, 256, 256, 5)
+    clean = gemm.linear_fp4_gelu_dual(*a, *w, bias)
+    assert bool(clean.any())
+    bad = bias.clone()
+    bad[77] = float("nan")
+    z = gemm.linear_fp4_gelu_dual(*a, *w, bad)
+    assert not bool(z.view(torch.int16).any())
+    scratch = ops._nan_scratch(dev)
+    torch.cuda.synchronize()
+    assert not bool(scratch.any()), "the NaN scratch must be zero again after the fix-up launch"
+    assert_bits_equal(gemm.linear_fp4_gelu_dual(*a, *w, bias), clean, "after a NaN call")
+    # graph replay: the NaN case twice, then the clean case, on static buffers
+    sb = bad.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gemm.linear_fp4_gelu_dual(*a, *w, sb)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            out = gemm.linear_fp4_gelu_dual(*a, *w, sb)
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(2):
+        gr.replay()
+        torch.cuda.synchronize()
+        assert not bool(out.view(torch.int16).any())
+    sb.copy_(bias)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert_bits_equal(out, clean, "graph replay without the NaN")
+
+
+def test_fused_fc1_at_the_model_shape(dev):
+    """VAR-d30's fc1 at a late scale step (16900 tokens x 1920 -> 7680): the default tiling of that size, checked through the
+    stand-alone quantizer on the emitted values, oracle-checked row slices from both ends, and torch's GELU."""
+    from fpqvar_amd import gemm, ops
+    a, w, bias = operands(dev, 16900, 1920, 7680, 3)
+    q, h = gemm.linear_fp4_gelu_dual(*a, *w, bias, return_gelu=True)
+    y = gemm.linear_fp4(*a, *w, bias)
+    assert int(ulp_diff(h, Fn.gelu(y, approximate="tanh")).max()) <= 1
+    assert_bits_equal(q, ops.quant_rows_dual(h, "e1m2_neg", "e2m1_pos", 128, 1.0), "fused vs stand-alone quantizer")
+    for lo in (0, 16900 - 16):
+        assert_bits_equal(q[lo:lo + 16].cpu(), orc.dual_per_group_kernel_sem(h[lo:lo + 16].cpu(), "e1m2_neg", "e2m1_pos", 128, 1.0), f"rows {lo}..")
+
+
+def test_fused_fc1_argument_checks(dev):
+    from fpqvar_amd import gemm
+    a, w, bias = operands(dev, 8, 128, 128, 1)
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp4_gelu_dual(a[0], a[1], w[0][:120], w[1][:120])        # outs % 128 != 0
+    with pytest.raises(RuntimeError):
+        gemm.linear_fp4_gelu_dual(a[0][:, :-8], a[1], *w)                     # truncated operand
+    assert gemm.linear_fp4_gelu_dual(a[0][:0], a[1][:0], *w).shape == (0, 128)
+    lib = _lib.lib()
+    assert lib.fpq_gemm_fp4_gelu_dual(None, None, None, None, 1, None, None, None, 4, 100, 128, None, None) == -3   # shape before pointers
+    assert lib.fpq_gemm_fp4_gelu_dual(None, None, None, None, 1, None, None, None, 4, 128, 128, None, None) == -1
+    assert lib.fpq_gemm_fp4_gelu_dual(None, None, None, None, 7, None, None, None, 4, 128, 128, None, None) == -2
+    assert lib.fpq_gemm_fp4_gelu_dual(None, None, None, None, 1, None, None, None, 0, 128, 128, None, None) == 0

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from fpqvar_amd import _lib
 from oracle import fpq_oracle as orc
 from tests.conftest import assert_bits_equal, from_bits
 
@@ -347,7 +348,7 @@ def test_exhaustive_fp16_scale_pairs(dev, qu):
 
 @pytest.mark.parametrize("table", ("e2m1", "e2m1/table", "e1m2", "e3m0", "e2m3", "e2m3/table", "e3m2", "e3m2/table", "e1m2_neg+e2m1_pos",
                                    "int_neg+e2m3_pos"))
-def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, monkeypatch):
+def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, lib_options):
     """EVERY (group maximum, element) pair of finite fp16 values - 1.0e9 per table, both signs - through the fast
     fp16 kernel (one-multiply division, level from the bucket table or - "e2m1", "e2m3", "e3m2": the defaults in groups of
     128 - from the FP4 / FP6 conversion hardware, packed fp16 multiply) and through the generic kernel (IEEE fp32
@@ -359,8 +360,8 @@ def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, monkeypatch):
     Dual formats: the group holds +max and -max, so both sides' scales sweep every magnitude too."""
     from fpqvar_amd import ops
     if table.endswith("/table"):                   # the bucket-table forms behind the conversion-hardware defaults (round 3: E2M1;
-        monkeypatch.setenv("FPQ_NO_HW4", "1")      # round 4: E2M3 / E3M2); both variables are read by the library at every call
-        monkeypatch.setenv("FPQ_NO_HW6", "1")
+        lib_options("FPQ_NO_HW4", 1)   # round 4: E2M3 / E3M2); switches of the library (fpq_set_option), restored by the fixture
+        lib_options("FPQ_NO_HW6", 1)
         table = table.split("/")[0]
     dual = "+" in table
     lead = 2 if dual else 1
@@ -418,11 +419,11 @@ def test_every_fp16_pair_fast_path_vs_ieee_path(dev, table, monkeypatch):
 
 @pytest.mark.parametrize("cols", (1920, 2304))
 @pytest.mark.parametrize("table", ("e2m3", "e3m2"))
-def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, cols, monkeypatch):
+def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, cols):
     """The per-token FP6 quantizer on rows of 1920 (W6A6 activations) takes its levels from the FP6 conversion hardware since
     round 4 (rows16_lut_wave_kernel<HW6>, fp6_levels_hw32: float(xn) + 2^-17 in front of a round-to-nearest-even conversion).
-    EVERY (row maximum, element) pair of finite fp16 values through it, through the table form (FPQ_NO_HW6=1, read at
-    every call) and through the generic kernel (IEEE division + closed form, selected by asking for a float32 result).
+    EVERY (row maximum, element) pair of finite fp16 values through it, through the table form (library switch FPQ_NO_HW6 around
+    the call) and through the generic kernel (IEEE division + closed form, selected by asking for a float32 result).
     cols = 2304 (d36): a lane's fifth vector goes through a second conversion with 8 live values."""
     from fpqvar_amd import ops
     per = cols - 1
@@ -443,8 +444,7 @@ def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, cols, monk
         ieee = ops.quant_rows(x, table, cols, torch.float32).half()
         bad = fast.view(torch.int16) != ieee.view(torch.int16)
         assert not bool(bad.any()), (table, lo, x[bad][:4].tolist(), fast[bad][:4].tolist(), ieee[bad][:4].tolist())
-        with monkeypatch.context() as m:
-            m.setenv("FPQ_NO_HW6", "1")
+        with _lib.option("FPQ_NO_HW6", 1):
             tab = ops.quant_rows(x, table, cols, torch.float16)
         assert torch.equal(fast.view(torch.int16), tab.view(torch.int16)), (table, lo, "hardware levels vs table form")
         total += int(ok.sum())
@@ -465,7 +465,7 @@ def test_every_fp16_pair_per_token_hw_levels_vs_ieee_path(dev, table, cols, monk
 
 
 @pytest.mark.parametrize("cols", (1920, 128, 64))
-def test_fp6_hardware_levels_full_size_properties(dev, cols, monkeypatch):
+def test_fp6_hardware_levels_full_size_properties(dev, cols):
     """The metric-sized tensor [65536 x 1920] through the FP6 conversion-hardware forms (per token, per group of 128, KV rows of
     64): equal to the table forms element for element, idempotent (a quantized tensor quantizes to itself - the KV path
     relies on it, tr/basic_var.py:186-209), every output a level times its row's scale (checked on oracle slices)."""
@@ -474,8 +474,7 @@ def test_fp6_hardware_levels_full_size_properties(dev, cols, monkeypatch):
     x = (torch.randn(65536, 1920, device=dev, generator=g) * torch.exp(0.3 * torch.randn(65536, 1920, device=dev, generator=g))).half()
     for table in ("e2m3", "e3m2"):
         q = ops.quant_rows(x, table, cols, torch.float16)
-        with monkeypatch.context() as m:
-            m.setenv("FPQ_NO_HW6", "1")
+        with _lib.option("FPQ_NO_HW6", 1):
             qt = ops.quant_rows(x, table, cols, torch.float16)
         assert torch.equal(q.view(torch.int16), qt.view(torch.int16)), f"{table} cols={cols}: hardware levels vs table form"
         assert torch.equal(ops.quant_rows(q, table, cols, torch.float16).view(torch.int16), q.view(torch.int16)), f"{table} cols={cols}: not idempotent"
@@ -870,9 +869,9 @@ def test_rotate_butterfly_switch(dev, tmp_path):
 @pytest.mark.parametrize("C", (1920, 2304))
 @pytest.mark.parametrize("x_dtype", (torch.float16, torch.float32))
 @pytest.mark.parametrize("table", ("e2m3", "e3m2"))
-def test_adaln_fp6_hardware_levels_equal_the_table_form(dev, table, x_dtype, C, monkeypatch):
+def test_adaln_fp6_hardware_levels_equal_the_table_form(dev, table, x_dtype, C):
     """The adaLN producer's E2M3 / E3M2 value outputs (per group and per token, rows of 13 .. 16 groups) take their levels
-    from the FP6 conversion hardware since round 4; FPQ_NO_HW6=1 (read at every call) keeps the bucket table: bit-equal,
+    from the FP6 conversion hardware since round 4; the library switch FPQ_NO_HW6 keeps the bucket table: bit-equal,
     including rows with non-finite values, all-zero rows and ragged batch entries; and the quantization is the oracle's on
     the rotated rows the kernel emits."""
     from fpqvar_amd import rotation as rot
@@ -890,8 +889,7 @@ def test_adaln_fp6_hardware_levels_equal_the_table_form(dev, table, x_dtype, C, 
 
     def both(fn):
         a = fn()
-        with monkeypatch.context() as m:
-            m.setenv("FPQ_NO_HW6", "1")
+        with _lib.option("FPQ_NO_HW6", 1):
             b = fn()
         return a, b
     a, b = both(lambda: rot.adaln_rotate_quant(xd, sc, sh, table, smooth=sm))
@@ -983,7 +981,7 @@ def test_producers_at_full_size_equal_their_slices(dev, x_dtype):
 
 
 @pytest.mark.parametrize("mod_dtype", (torch.float16, torch.float32))
-def test_adaln_two_rows_per_tile_at_c1024(dev, mod_dtype, monkeypatch):
+def test_adaln_two_rows_per_tile_at_c1024(dev, mod_dtype, lib_options):
     """C = 1024 (VAR-d16): two consecutive rows of a batch entry share one matrix-core tile (PAIR2).  Bit for bit against
     the one-row-per-tile kernel - the emitting form always is one, FPQ_ADALN_NO_PAIR2 forces it - for batch entries of
     odd and even length (a lone last row), one-row entries, the BASELINE-like shape, values and FP4 operands, with and
@@ -1006,12 +1004,12 @@ def test_adaln_two_rows_per_tile_at_c1024(dev, mod_dtype, monkeypatch):
             assert_bits_equal(got, out_e, f"B={B} L={L}: paired vs emitting (one row per tile)")
             assert_bits_equal(got, orc.per_group_kernel_sem(y_e.cpu().reshape(-1, C), "e2m1", 128).view_as(got), f"B={B} L={L}: oracle on rotated rows")
             assert_bits_equal(gemm.dequantize_mx(codes.view(B * L, -1), scales.view(B * L, -1)).half().view_as(got), got, f"B={B} L={L}: operands")
-            monkeypatch.setenv("FPQ_ADALN_NO_PAIR2", "1")
+            lib_options("FPQ_ADALN_NO_PAIR2", 1)
             assert_bits_equal(rot.adaln_rotate_quant(x, sc, sh, "e2m1", smooth=sm), got, f"B={B} L={L}: unpaired values")
             assert_bits_equal(rot.adaln_rotate_quant(x, sc, sh, "e2m3", smooth=sm), tab, f"B={B} L={L}: unpaired, table form")
             c0, s0 = rot.adaln_rotate_quant_mx(x, sc, sh, smooth=sm)
             assert torch.equal(c0, codes) and torch.equal(s0.view(torch.int16), scales.view(torch.int16)), f"B={B} L={L}: unpaired operands"
-            monkeypatch.delenv("FPQ_ADALN_NO_PAIR2")
+            lib_options("FPQ_ADALN_NO_PAIR2", None)
 
 
 @pytest.mark.parametrize("in_dtype", (torch.float16, torch.float32))
@@ -1364,8 +1362,8 @@ def test_fp4_gemm(dev, T, O, K):
 
 
 @pytest.mark.parametrize("T,O,K", ((300, 392, 1920), (16384, 8192, 128)))
-def test_fp4_gemm_tile_configurations_agree(dev, T, O, K, monkeypatch):
-    """Every tiling of the FP4 GEMM (FPQ_GEMM_CFG, read at each call): the three LDS-DMA tilings do the same arithmetic per
+def test_fp4_gemm_tile_configurations_agree(dev, T, O, K, lib_options):
+    """Every tiling of the FP4 GEMM (library switch FPQ_GEMM_CFG): the three LDS-DMA tilings do the same arithmetic per
     element and must agree bit for bit - with bias, gate and residual, on ragged edges - and with the default choice
     ((300, 392): 12 tiles of 128 x 128, the smallest tile is the default; (16384, 8192): 4096 tiles of 256 x 128, past
     the size from which the larger tile is); the register-staged tilings multiply the two scales first and stay within
@@ -1382,10 +1380,7 @@ def test_fp4_gemm_tile_configurations_agree(dev, T, O, K, monkeypatch):
     wc, wsc = gemm.quantize_mx(w)
 
     def run(cfg, b=bias):
-        if cfg is None:
-            monkeypatch.delenv("FPQ_GEMM_CFG", raising=False)
-        else:
-            monkeypatch.setenv("FPQ_GEMM_CFG", cfg)
+        lib_options("FPQ_GEMM_CFG", None if cfg is None else int(cfg))
         plain = gemm.linear_fp4(ac, asc, wc, wsc, b)
         fused = gemm.linear_fp4(ac, asc, wc, wsc, b, gate=gate, residual=resid)
         return plain, fused
@@ -1407,7 +1402,7 @@ def test_fp4_gemm_tile_configurations_agree(dev, T, O, K, monkeypatch):
 
 @pytest.mark.parametrize("kind", ("fp6", "fp8"))
 @pytest.mark.parametrize("T,O,K", ((300, 392, 1920), (4100, 520, 256)))
-def test_row_scaled_gemm_tile_configurations_agree(dev, kind, T, O, K, monkeypatch):
+def test_row_scaled_gemm_tile_configurations_agree(dev, kind, T, O, K, lib_options):
     """The two tilings of the FP6 / FP8 row-scaled GEMMs (FPQ_GEMM6_CFG / FPQ_GEMM8_CFG: 128 x 128 and 256 x 128) sum a tile's
     K in the same order and share the epilogue: bit-equal outputs, plain and with bias + gate + residual, on ragged edges;
     4100 tokens is past the size from which the larger FP6 tile is the default.  And against float64 on the decoded operands."""
@@ -1424,10 +1419,7 @@ def test_row_scaled_gemm_tile_configurations_agree(dev, kind, T, O, K, monkeypat
     a, wq = quant(x), quant(w)
 
     def run(cfg):
-        if cfg is None:
-            monkeypatch.delenv(env, raising=False)
-        else:
-            monkeypatch.setenv(env, cfg)
+        lib_options(env, None if cfg is None else int(cfg))
         return lin(*a, *wq, bias), lin(*a, *wq, bias, gate, resid)
 
     base = run("0")

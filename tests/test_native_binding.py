@@ -170,6 +170,17 @@ def test_native_q_path_equals_ctypes_path(monkeypatch):
     same(*both(lambda: gemm.linear_fp4(*a, *w, bias, gate, res)), "linear_fp4 + epilogue")
     with pytest.raises(RuntimeError):
         gemm.linear_fp4(a[0][:, :-64], a[1], *w)
+    # edge cases of the compiled binding: bias / gate / residual views at an odd storage offset (2 bytes past a
+    # 16-byte boundary) give the aligned result bit for bit; zero tokens / zero outputs are valid and enqueue nothing
+    want = _native.linear_fp4(*a, *w, bias, gate, res)
+    off = lambda t: torch.cat([t.reshape(-1)[:1], t.reshape(-1)])[1:].view(t.shape)     # same values, data_ptr + 2
+    assert off(bias).data_ptr() % 16 == 2
+    same(_native.linear_fp4(*a, *w, off(bias), off(gate), off(res)), want, "linear_fp4 with misaligned bias / gate / residual")
+    same(_native.linear_fp4(*a, *w, off(bias)), _native.linear_fp4(*a, *w, bias), "linear_fp4 with a misaligned bias alone")
+    empty_a = (a[0][:0], a[1][:0])
+    assert _native.linear_fp4(*empty_a, *w, bias, gate[:0], res[:0]).shape == (0, 256)
+    empty_w = (w[0][:0], w[1][:0])
+    assert _native.linear_fp4(*a, *empty_w).shape == (a[0].shape[0], 0)
     # the KV-cache step
     from fpqvar_amd import kv_cache as kvc
     outs = []

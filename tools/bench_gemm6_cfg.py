@@ -1,13 +1,13 @@
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
-from fpqvar_amd import gemm
+from fpqvar_amd import _lib, gemm
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 T, K, O = 65536, 1920, 5760
 x = torch.randn(T, K, device=dev).half(); w = torch.randn(O, K, device=dev) * 0.02
 ac, asc = gemm.quantize_fp6(x); wc, wsc = gemm.quantize_fp6(w)
 ref = None
 for cfg in ("0", "1", "2"):
-    os.environ["FPQ_GEMM6_CFG"] = cfg
+    _lib.set_option("FPQ_GEMM6_CFG", int(cfg))
     y = gemm.linear_fp6(ac, asc, wc, wsc)
     ref = y if ref is None else ref
     for _ in range(10): gemm.linear_fp6(ac, asc, wc, wsc)

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""FP4 GEMM kernel only, mat_qkv shape, per tile configuration (FPQ_GEMM_CFG read at every call)."""
+"""FP4 GEMM kernel only, mat_qkv shape, per tile configuration (the library switch FPQ_GEMM_CFG, set through fpq_set_option)."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from fpqvar_amd import gemm  # noqa: E402
+from fpqvar_amd import _lib, gemm  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -17,7 +17,7 @@ ac, asc = gemm.quantize_mx(x)
 wc, wsc = gemm.quantize_mx(w)
 ref = None
 for cfg in (sys.argv[1:] or ["0", "3", "4", "5"]):
-    os.environ["FPQ_GEMM_CFG"] = cfg
+    _lib.set_option("FPQ_GEMM_CFG", int(cfg))
     y = gemm.linear_fp4(ac, asc, wc, wsc)
     if ref is None:
         ref = y

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """FP4 GEMM at the token counts of the ten scale steps (VAR-d30: 2 x 50 x pn^2 rows; the three Linears fed by per-group FP4
-activations), per tile configuration (FPQ_GEMM_CFG / FPQ_GEMM6_CFG / FPQ_GEMM8_CFG, read at every call).
+activations), per tile configuration (the library switches FPQ_GEMM_CFG / FPQ_GEMM6_CFG / FPQ_GEMM8_CFG, set through fpq_set_option).
 usage: gemm_small_steps.py [fp4|fp6|fp8] [cfg ...]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from fpqvar_amd import gemm
+from fpqvar_amd import _lib, gemm
 
 kind = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("fp4", "fp6", "fp8") else "fp4"
 cfgs = [a for a in sys.argv[1:] if a not in ("fp4", "fp6", "fp8")] or {"fp4": ["default", "20", "30"], "fp6": ["default", "0", "1"], "fp8": ["default", "0", "1"]}[kind]
@@ -25,10 +25,7 @@ for O in (5760, 1920, 7680):
         ac, asc = quant(x)
         row = []
         for c in cfgs:
-            if c == "default":
-                os.environ.pop(env, None)
-            else:
-                os.environ[env] = c
+            _lib.set_option(env, None if c == "default" else int(c))
             for _ in range(5):
                 linear(ac, asc, wc, wsc)
             torch.cuda.synchronize()
