@@ -641,7 +641,7 @@ def generation_steps(dev, model="d30", rows_dtype="fp32", mode="rotating", repla
     # What a dependent launch costs before it moves a byte, in THIS protocol (same graph machinery, cold caches): the smallest
     # launch of the path - one group of 128 - fifty times in one graph.  The bound below prices every launch of a block-step at
     # this floor plus its bytes at the chip's 1:1 stream ceiling (a 16-byte copy: 6.29 TB/s, MI355X_MICROARCH.md), so that
-    # the "five dependent launches bound the step at 0.66" of DESIGN.md is a number the driver's run reproduces.
+    # the "five dependent launches bound the step at 0.66" of DESIGN.md section 4c is a number the driver's run reproduces.
     floor_us = None
     try:
         tiny = torch.zeros(1 << 16, dtype=torch.float16, device=dev)

@@ -303,11 +303,11 @@ FPQ_NOPK __device__ __forceinline__ void load_scale_tiles(const _Float16* __rest
 // as the epilogue of gemm_fp4_glds_kernel: every tile is BN = 128 outputs wide and starts at a multiple of 128, i.e. it
 // holds WHOLE quantization groups - one per token row - so both scales of a group are tile-local.
 //   * y = half(acc + bias) exactly as the plain epilogue rounds it (the Linear output the reference's GELU sees);
-//   * h = half(gelu(float(y))): torch's formula in torch's operation order, 0.5 x (1 + tanh(beta (x + kappa x^3))), with
-//     the device library's tanh restated (__ocml_tanh_f32: a polynomial below 0.625, 1 - 2 / (exp(2|u|) + 1) above) - within
-//     one fp16 ulp of torch's on every fp16 input, checked exhaustively (tests/test_gpu_fc1_fused.py);
+//   * h = half(gelu(float(y))), gelu_tanh_fast below: within one fp16 ulp of torch's F.gelu(y, approximate="tanh") on every
+//     fp16 input, checked exhaustively (tests/test_gpu_fc1_fused.py; torch's formula in torch's operation order with the
+//     device library's tanh restated, gelu_tanh_like_torch, is bit-equal to torch and three times the instructions);
 //   * per token row the maxima of the negative and of the positive side over the lane's four outputs, the 16 lanes of the
-//     row (DPP) and the two wavefronts that share the group (LDS), one thread per row turns them into the two scales
+//     row (a DPP reduce-scatter) and the two wavefronts that share the group (LDS), one thread per row turns them into the two scales
 //     (row_scale16, dual_poison: the arithmetic of rows16_lut_subwave_kernel<DUAL>), and every lane quantizes its own
 //     values with quant_pair16_dual = one packed pair of quant_vec16<DUAL>: bit-equal to the stand-alone quantizer on h;
 //   * "any NaN in the tensor => the whole result is zero" (the reference's global clamp, tr/quant_utils.py:421-422) keeps
@@ -357,13 +357,39 @@ FPQ_NOPK __device__ __forceinline__ float gelu_tanh_like_torch(float x) {
   return 0.5f * x * (1.0f + tanh_devlib(inner));
 }
 
-// max over the 16 lanes of a DPP row of two packed unsigned 16-bit values (row_max_dpp<16> on pairs)
-FPQ_NOPK __device__ __forceinline__ uint32_t row16_pk_max_u16(uint32_t v) {
-  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
-  v = pk_max_u16(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
-  return v;
+// The form the epilogue runs (9 vector instructions instead of ~30): gelu(x) = x w, w = (1 + tanh(u)) / 2 = 1 / (1 + 2^m),
+// m = -2 log2(e) u = x (c0 + c1 x^2); `(w - 0.5) + 0.5` snaps w to the grid torch's own 1 + tanh(u) lives on (its tanh is an
+// fp32 number just below 1 for the deep negatives, where 1 + tanh cancels: without the snap the more exact w is up to 2 fp16
+// ulps away from what torch returns on 7 inputs in [-5.2, -4.7]).  tools/probe/gelu_probe.hip runs eight candidate forms over
+// all 65536 fp16 inputs against torch on the GPU (profiles/r05_gelu_probe.txt): the torch-order form above is bit-equal
+// to torch on every input; this one differs on 5 inputs, by one ulp each, NaN exactly where torch has NaN (NaN, -inf).
+FPQ_NOPK __device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float kBeta = (float)(1.41421356237309504880 * 1.12837916709551257390 * 0.5), kKappa = 0.044715f;
+  const float c0 = -2.8853900817779268f * kBeta, c1 = c0 * kKappa;   // float arithmetic, as in the probe
+  const float m = x * __builtin_fmaf(x * x, c1, c0);
+  const float w = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m));
+  return x * ((w - 0.5f) + 0.5f);
+}
+#ifdef FPQ_FC1_GELU_TORCH_ORDER   // A/B builds: the bit-equal form
+#define FPQ_FC1_GELU gelu_tanh_like_torch
+#else
+#define FPQ_FC1_GELU gelu_tanh_fast
+#endif
+
+// One step of the maxima's reduce-scatter over the 16 lanes of a DPP row: rows r and r + N / 2 are paired, a lane keeps the
+// one its bit selects and hands the other to its partner (DPP control CTRL), taking the partner's in return: N rows in, N / 2
+// out, each now the maximum over twice as many lanes.  N == 1: plain exchange-and-max.  Packed pairs, unsigned compare.
+template <int N, int CTRL>
+FPQ_NOPK __device__ __forceinline__ void pk_max_scatter_step(uint32_t* key, bool bit) {
+  if constexpr (N == 1) {
+    key[0] = pk_max_u16(key[0], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key[0], CTRL, 0xF, 0xF, true));
+  } else {
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) {
+      const uint32_t keep = bit ? key[r + N / 2] : key[r], send = bit ? key[r] : key[r + N / 2];
+      key[r] = pk_max_u16(keep, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, CTRL, 0xF, 0xF, true));
+    }
+  }
 }
 
 // one packed pair of quant_vec16<DUAL> (fpq_fast16.h): each half takes the reciprocal and the scale of its sign's side
@@ -562,23 +588,24 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
     u32x4* rsc = (u32x4*)(xch + 2 * BM);                     // [BM]: {1 / s_neg, 1 / s_pos, s_neg x 2, s_pos x 2}
     static_assert(2 * BM * 4 + BM * 16 <= STAGE, "exchange + row scales fit the idle stage buffer");
     uint32_t hw[MT][4][2];
+    // The two maxima of a row as ONE packed key, both halves compared unsigned: low half = the unsigned maximum of the fp16
+    // patterns (the most negative value, or a negative NaN), high half = their signed maximum with the sign bit flipped (the
+    // largest positive value, or a positive NaN) - dual_max_acc of fpq_fast16.h, finished by the row's thread further down.
+    constexpr int NR = 4 * MT;
+    uint32_t key[NR];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      u32x4 mx;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float g[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) g[n] = gelu_tanh_like_torch((float)(_Float16)(acc[m][n][i] + b4[n]));
-        hw[m][i][0] = f2h2(g[0], g[1]);
-        hw[m][i][1] = f2h2(g[2], g[3]);
-        // unsigned maximum = the most negative value (or a negative NaN), signed maximum = the largest positive one (or a
-        // positive NaN): dual_max_acc / dual_max_finish of fpq_fast16.h on the lane's two words
-        uint32_t mn, mp;
-        dual_max_finish(pk_max_u16(hw[m][i][0], hw[m][i][1]), pk_max_i16(hw[m][i][0], hw[m][i][1]), mn, mp);
-        mx[i] = row16_pk_max_u16(mn | (mp << 16));
+        for (int n = 0; n < NT; ++n) g[n] = FPQ_FC1_GELU((float)(_Float16)(acc[m][n][i] + b4[n]));
+        const uint32_t w0 = f2h2(g[0], g[1]), w1 = f2h2(g[2], g[3]);
+        hw[m][i][0] = w0;
+        hw[m][i][1] = w1;
+        const uint32_t un = pk_max_u16(w0, w1), sg = pk_max_i16(w0, w1) ^ 0x80008000u;
+        key[4 * m + i] = pk_max_u16(__builtin_amdgcn_perm(sg, un, 0x05040100u), __builtin_amdgcn_perm(sg, un, 0x07060302u));
       }
-      if ((lane & 15) == 0) *(u32x4*)(xch + wn * BM + wm * WROWS + m * 16 + 4 * (lane >> 4)) = mx;
       if (xe.h_out) {
         const int t_first = t0 + wm * WROWS + m * 16 + 4 * (lane >> 4);
 #pragma unroll
@@ -587,11 +614,28 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
             __builtin_nontemporal_store(u32x2{hw[m][i][0], hw[m][i][1]}, (u32x2*)(xe.h_out + (int64_t)(t_first + i) * O + oc));
       }
     }
+    {
+      // maxima over the 16 lanes that share a row: a reduce-scatter (the NR rows of a lane are halved four times, each step
+      // one DPP exchange per surviving row: 30 exchanges for 32 rows, where reducing every row over all lanes takes 128) -
+      // afterwards lane j of a DPP row holds the finished keys of NR / 16 rows (one row per lane pair for NR = 8), row index
+      // = the lane's bits, highest first, then the position in `key`
+      const int j = lane & 15;
+      pk_max_scatter_step<NR, 0x128>(key, (j & 8) != 0);                               // row_ror:8       partner j ^ 8
+      pk_max_scatter_step<(NR >= 2 ? NR / 2 : 1), 0x141>(key, (j & 4) != 0);           // row_half_mirror partner 7 - (j & 7)
+      pk_max_scatter_step<(NR >= 4 ? NR / 4 : 1), 0x4E>(key, (j & 2) != 0);            // quad_perm [2,3,0,1]
+      pk_max_scatter_step<(NR >= 8 ? NR / 8 : 1), 0xB1>(key, (j & 1) != 0);            // quad_perm [1,0,3,2]
+      constexpr int NF = NR >= 16 ? NR / 16 : 1;                                       // finished rows per lane
+      constexpr int HALVINGS = NR >= 16 ? 4 : 3;                                       // NR = 8: the last step is a plain exchange
+      const int rho0 = (HALVINGS == 4 ? j : (j >> 1)) * NF;                            // row m * 4 + i of key[0]
+      uint32_t* dst = xch + wn * BM + wm * WROWS + (rho0 >> 2) * 16 + 4 * (lane >> 4) + (rho0 & 3);
+      if constexpr (NF == 2) *(u32x2*)dst = u32x2{key[0], key[1]};                     // rows i, i + 1 of one tile row block
+      else dst[0] = key[0];
+    }
     FPQ_SYNC();
     if (tid < BM) {   // one thread per token row: the group's two scales
-      const uint32_t p0 = xch[tid], p1 = xch[BM + tid];
-      const uint32_t l0 = p0 & 0xFFFFu, l1 = p1 & 0xFFFFu, h0 = p0 >> 16, h1 = p1 >> 16;
-      const uint32_t mn = l0 > l1 ? l0 : l1, mp = h0 > h1 ? h0 : h1;
+      const uint32_t k = pk_max_u16(xch[tid], xch[BM + tid]);                          // the two wavefronts that share the group
+      const uint32_t un = k & 0xFFFFu, sgv = (k >> 16) ^ 0x8000u;
+      const uint32_t mn = (un & 0x8000u) ? (un & 0x7FFFu) : 0u, mp = (sgv & 0x8000u) ? 0u : sgv;   // dual_max_finish
       if ((mn > 0x7C00u || mp > 0x7C00u) && xe.nan_flag && t0 + tid < T)   // a NaN in this group (the builtin: atomicOr() is a header function without this kernel's target attribute - it would become a call)
         __hip_atomic_fetch_or(xe.nan_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       RowScale16 sn = row_scale16(mn, xe.a.fneg.gmax, xe.a.inv_gneg), sp = row_scale16(mp, xe.a.fpos.gmax, xe.a.inv_gpos);

@@ -13,6 +13,14 @@
 #pragma once
 
 FPQ_NOPK __device__ __forceinline__ int fp6_rot(int r) { return (r >> 3) & 1; }
+// The fragment reads MUST stay ds_read_b64 (two 32-lane groups, 64 banks: the layout above is conflict-free for exactly that
+// instruction).  Left as plain loads, the compiler pairs the reads of tile rows 1536 bytes apart into ds_read2st64_b64 - two
+// accesses served in 16-lane groups over 32 banks (MI355X_MICROARCH.md, LDS) - which conflict: rounds 1 - 4 ran with six of
+// them per K step, SQ_LDS_BANK_CONFLICT = 48 cycles per step = 1.5 per MFMA (profiles/r04_pmc_gemm6.txt; the FP4 / FP8 GEMMs
+// read 16 bytes with ds_read_b128, which has no paired form).  A volatile access is not merged.
+// (spelled with the LDS address space: a volatile access through a generic pointer becomes a flat load)
+typedef const volatile __attribute__((address_space(3))) u32x2* fpq_lds_v64_ptr;
+#define FPQ_LDS_READ64(ptr) (*(fpq_lds_v64_ptr)(const __attribute__((address_space(3))) void*)(ptr))
 
 template <typename Tsa, typename Tsw, int MT, int NT>
 __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const uint8_t* __restrict__ A,
@@ -103,13 +111,13 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const uint8_t* p = st + b_base + n * 1536;
-      const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
+      const u32x2 q0 = FPQ_LDS_READ64(p + foff[0]), q1 = FPQ_LDS_READ64(p + foff[1]), q2 = FPQ_LDS_READ64(p + foff[2]);
       bf[n] = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const uint8_t* p = st + a_base + m * 1536;
-      const u32x2 q0 = *(const u32x2*)(p + foff[0]), q1 = *(const u32x2*)(p + foff[1]), q2 = *(const u32x2*)(p + foff[2]);
+      const u32x2 q0 = FPQ_LDS_READ64(p + foff[0]), q1 = FPQ_LDS_READ64(p + foff[1]), q2 = FPQ_LDS_READ64(p + foff[2]);
       const v8i_t af = v8i_t{(int)q0[0], (int)q0[1], (int)q1[0], (int)q1[1], (int)q2[0], (int)q2[1], 0, 0};
 #pragma unroll
       for (int n = 0; n < NT; ++n) {

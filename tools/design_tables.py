@@ -133,7 +133,7 @@ def steps():
 
 def write():
     """Splice both blocks into DESIGN.md (between their first line and the paragraph that follows them)."""
-    path = os.path.join(ROOT, "DESIGN.md")
+    path = os.path.join(ROOT, "profiles", "NOTES_r04.md")   # the round-4 notebook (DESIGN.md until round 5)
     s = open(path).read()
     a = s.index("| kernel at its BASELINE shape |")
     b = s.index("| kernel | used for (SURVEY §8a row)")
@@ -142,7 +142,7 @@ def write():
     b = s.index("**Why 0.70 is not there")
     s = s[:a] + "\n".join(steps()) + "\n" + s[b:]
     open(path, "w").write(s)
-    print("DESIGN.md: round-4 figures table and section 4c step tables rewritten from profiles/")
+    print("profiles/NOTES_r04.md: round-4 figures table and section 4c step tables rewritten from profiles/")
 
 
 if __name__ == "__main__":

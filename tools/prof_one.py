@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE kernel a few times (for rocprofv3 --pmc passes).
-usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|token6|group6|sym|calib|channel|gemm|gemm6|gemm8}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
+usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|token6|group6|sym|calib|channel|gemm|gemm6|gemm8|fc1}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -52,6 +52,14 @@ elif which == "gemm":
     ac, asc = gemm.quantize_mx(x)
     wc, wsc = gemm.quantize_mx(w)
     fn = lambda: gemm.linear_fp4(ac, asc, wc, wsc)
+elif which == "fc1":   # fc1 with GELU and fc2's dual quantizer in the GEMM's epilogue (fpq_gemm_fp4_gelu_dual), VAR-d30's shape
+    from fpqvar_amd import gemm
+    x = torch.randn(65536, C, device=dev).half()
+    w = torch.randn(7680, C, device=dev) * 0.02
+    bias = (torch.randn(7680, device=dev) * 0.1).half()
+    ac, asc = gemm.quantize_mx(x)
+    wc, wsc = gemm.quantize_mx(w)
+    fn = lambda: gemm.linear_fp4_gelu_dual(ac, asc, wc, wsc, bias)
 elif which in ("gemm6", "gemm8"):   # the row-scaled GEMMs of the W6A6 configuration (6-bit packed / E4M3 bytes)
     from fpqvar_amd import gemm
     x = torch.randn(65536, C, device=dev).half()
