@@ -205,6 +205,24 @@ class FP4Linear(_ScaledOperandModule):
         return linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual)
 
 
+class FP4LinearGeluDual(FP4Linear):
+    """fc1 of an AdaLN block's FFN in the W4A4 per-group configuration with the FFN's GELU(tanh) AND fc2's dual-format input
+    quantizer (`fp_e1m2_neg_e2m1_pos`, tr/quant_utils.py:415-452,991) in the GEMM's epilogue: `forward(x)` returns what
+    `fc2.act_quant(act(fc1(x)))` returns in the reference's FFN.forward (tr/basic_var.py:120-121) - the module that follows
+    must neither apply the activation nor quantize again (`quant_linear.quantize_VAR(..., real_fp4=True, fuse_ffn=True)` swaps
+    the FFN's `act` for an identity and switches fc2's input quantizer off)."""
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features))
+        return linear_fp4_gelu_dual(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)
+
+    @torch.no_grad()
+    def forward_operands(self, a_codes: torch.Tensor, a_scales: torch.Tensor) -> torch.Tensor:
+        return linear_fp4_gelu_dual(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)
+
+
 # ---- per-token activations x per-channel weights (W6A6): one scale per row, FP8-coded levels ---------------------
 _FP8_TABLES = {"fp6_e2m3": "e2m3", "fp6_e3m2": "e3m2", "fp_e2": "e2m1", "fp_e1": "e1m2", "fp_e3": "e3m0",
                "e2m3": "e2m3", "e3m2": "e3m2", "e2m1": "e2m1", "e1m2": "e1m2", "e3m0": "e3m0"}

@@ -149,7 +149,7 @@ class QuantizedLinear_fc2(QuantizedLinear):
 def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=False, w_bit=8, a_bit=8, kv_bit=8,
                  act_quant_sym=None, fc2_act_log2_quant=None, quant_kv=None, activation_fp_quant=False,
                  weight_fp_quant=False, act_fp_type=None, weight_fp_type=None, fc2_fp_type=None, real_fp4=False,
-                 real_fp6=False):
+                 real_fp6=False, fuse_ffn=False):
     """tr/quant_utils.py:1095-1167.  The reference matches its own FFN / SelfAttention
     classes; here a module with Linear children ``fc1``+``fc2`` is an FFN and one with
     ``mat_qkv``+``proj`` is a self-attention block.  As in the reference,
@@ -158,7 +158,12 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
 
     ``real_fp4`` (additive, default off = the reference's behaviour): in the W4A4 per-group ``fp_e2`` configuration
     fc1 / mat_qkv / proj become ``gemm.FP4Linear`` - same quantization decisions, product on the FP4 matrix cores
-    instead of an fp16 GEMM on de-quantized tensors (fc2 keeps its dual-format fake quantization)."""
+    instead of an fp16 GEMM on de-quantized tensors (fc2 keeps its dual-format fake quantization).
+
+    ``fuse_ffn`` (additive, with ``real_fp4`` and ``fc2_fp_type == "fp_e1m2_neg_e2m1_pos"``): an FFN whose ``act`` is
+    GELU(tanh) gets ``gemm.FP4LinearGeluDual`` as fc1 - the GELU and fc2's dual-format input quantizer run in the fc1 GEMM's
+    epilogue - an identity as ``act`` and an fc2 that multiplies the already quantized input; the FFN's own
+    ``forward`` (``fc2(act(fc1(x)))``, tr/basic_var.py:120-121) stays as it is and computes the same thing in two launches fewer."""
     fp4_ok = (real_fp4 and weight_quant == "per_group" and act_quant == "per_group" and w_bit == 4 and a_bit == 4
               and activation_fp_quant and weight_fp_quant and act_fp_type == "fp_e2" and weight_fp_type == "fp_e2")
     if real_fp4 and not fp4_ok:
@@ -188,9 +193,22 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
         fc1, fc2 = getattr(m, "fc1", None), getattr(m, "fc2", None)
         qkv, proj = getattr(m, "mat_qkv", None), getattr(m, "proj", None)
         if isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear):
-            m.fc1 = plain(fc1, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+            act = getattr(m, "act", None)
+            fuse = (fuse_ffn and fp4_ok and fc2_fp_type == "fp_e1m2_neg_e2m1_pos" and isinstance(act, nn.GELU)
+                    and getattr(act, "approximate", "none") == "tanh" and fc1.in_features % 128 == 0 and fc1.out_features % 128 == 0)
+            if fuse_ffn and not fuse:
+                raise ValueError("fuse_ffn needs real_fp4, fc2_fp_type='fp_e1m2_neg_e2m1_pos', an FFN with act = GELU(approximate='tanh') "
+                                 "and widths that are multiples of 128")
             m.fc2 = QuantizedLinear_fc2.from_float(fc2, act_quant_sym=False, fc2_act_log2_quant=fc2_act_log2_quant,
                                                    act_fp_type=fc2_fp_type, **common)
+            if fuse:
+                from .gemm import FP4LinearGeluDual
+                m.fc1 = FP4LinearGeluDual.from_float(fc1)
+                m.act = nn.Identity()
+                m.fc2.act_quant = lambda t: t                      # its input arrives quantized from fc1's epilogue
+                m.fc2.act_quant_name = "in fc1's epilogue"
+            else:
+                m.fc1 = plain(fc1, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
         elif isinstance(qkv, nn.Linear) and isinstance(proj, nn.Linear):
             m.mat_qkv = plain(qkv, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
             m.proj = plain(proj, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)

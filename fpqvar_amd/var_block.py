@@ -19,6 +19,7 @@ Three ways to run everything around the attention core:
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, List, Optional, Sequence
 
@@ -36,6 +37,42 @@ WHAT = {
     "d36-512": "VAR-d36 512x512, 10 images with CFG (evaluate_fp_quant_transform_rotate_512x512.py:54,62,192-214)",
 }
 PATHS = ("R", "F", "Q")
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+class tuned_torch_gemms:
+    """`with tuned_torch_gemms():` - torch's OWN GEMMs (fc2 on every path; every Linear and the rotation of paths F / R) pick
+    their kernel from selections recorded once on an MI355X for the shapes of the two models (torch's TunableOp: the fastest of
+    the hipBLASLt / rocBLAS solutions per shape; `fpqvar_amd/tunableop_gfx950.csv`, made by running tools/bench_model.py under
+    PYTORCH_TUNABLEOP_TUNING=1).  Nothing is tuned at run time; a file whose validators (torch / hipBLASLt / rocBLAS versions,
+    gfx950) do not match the box is ignored by torch, which then selects as it does by default."""
+
+    def __init__(self, path: str = TUNED_GEMMS):
+        self.path = path
+
+    def __enter__(self):
+        import torch.cuda.tunable as tn
+        self.before = (tn.is_enabled(), tn.tuning_is_enabled())
+        self.active = os.path.exists(self.path)
+        if self.active:
+            # torch works on a private copy: it may rewrite its results file when the process ends, and the recorded file is source
+            import shutil
+            import tempfile
+            self.copy = os.path.join(tempfile.gettempdir(), f"fpq_tunableop_{os.getpid()}.csv")
+            shutil.copyfile(self.path, self.copy)
+            tn.enable(True)
+            tn.tuning_enable(False)
+            tn.set_filename(self.copy, False)
+            self.active = bool(tn.read_file(self.copy))
+            if not self.active:
+                tn.enable(self.before[0])
+        return self
+
+    def __exit__(self, *exc):
+        import torch.cuda.tunable as tn
+        tn.enable(self.before[0])
+        tn.tuning_enable(self.before[1])
+        return False
 
 
 def _ref_sym(x, grid, group=None, out_dtype=None):
@@ -260,15 +297,23 @@ class GenerationBatch:
 
 
 def generation_record(models: Sequence[str] = ("d30-256", "d36-512"), paths: Sequence[str] = PATHS, config: str = "w4a4",
-                      reps: int = 3, device=None, seed: int = 0, depth: Optional[int] = None) -> List[dict]:
-    """bench.py's `generation` entries (this rank's replica): one record per (model, path)."""
+                      reps: int = 3, device=None, seed: int = 0, depth: Optional[int] = None, tuned_gemms: bool = True) -> List[dict]:
+    """bench.py's `generation` entries (this rank's replica): one record per (model, path).  tuned_gemms: torch's own GEMMs
+    - the same ones on every path - run with the recorded TunableOp selections (tuned_torch_gemms), and the record says so."""
     out = []
     for model in models:
         gb = GenerationBatch(model, config, depth=depth, device=device, seed=seed)
         for path in paths:
             rec = {"model": model, "path": path, "config": config, "images_per_batch": gb.B // 2, "what": WHAT[model]}
             try:
-                rec.update(gb.time_path(path, reps))
+                if tuned_gemms:
+                    with tuned_torch_gemms() as tg:
+                        rec.update(gb.time_path(path, reps))
+                    rec["torch_gemms"] = ("TunableOp selections recorded for these shapes (fpqvar_amd/tunableop_gfx950.csv), no tuning at run time"
+                                          if tg.active else "torch's default selection (the recorded TunableOp file did not validate on this box)")
+                else:
+                    rec.update(gb.time_path(path, reps))
+                    rec["torch_gemms"] = "torch's default selection"
             except Exception as e:   # one failing path must not hide the others
                 rec["error"] = repr(e)[:200]
                 torch.cuda.empty_cache()

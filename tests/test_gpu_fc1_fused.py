@@ -154,3 +154,46 @@ def test_fused_fc1_argument_checks(dev):
     assert lib.fpq_gemm_fp4_gelu_dual(None, None, None, None, 1, None, None, None, 4, 128, 128, None, None) == -1
     assert lib.fpq_gemm_fp4_gelu_dual(None, None, None, None, 7, None, None, None, 4, 128, 128, None, None) == -2
     assert lib.fpq_gemm_fp4_gelu_dual(None, None, None, None, 1, None, None, None, 0, 128, 128, None, None) == 0
+
+
+def test_quantize_var_fuses_the_ffn(dev):
+    """quantize_VAR(..., real_fp4=True, fuse_ffn=True): the reference-shaped FFN.forward - fc2(act(fc1(x))), tr/basic_var.py:120-121 -
+    runs unchanged on the swapped modules and computes what the unfused real_fp4 model computes: fc2's input equals the dual
+    quantizer of torch's GELU of the FP4Linear output wherever the two GELUs agree (they differ on 5 of 65536 inputs by one
+    ulp, and a one-ulp step can move a group's scale: >= 99.9 % of the elements bit-equal), the FFN output within GEMM tolerance."""
+    import copy
+    from fpqvar_amd import gemm, quant_linear as ql
+
+    class FFN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.act, self.fc2 = torch.nn.Linear(256, 1024), torch.nn.GELU(approximate="tanh"), torch.nn.Linear(1024, 256)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(4)
+            self.ffn = FFN()
+
+    cfg = dict(weight_quant="per_group", act_quant="per_group", w_bit=4, a_bit=4, act_quant_sym=True, activation_fp_quant=True,
+               weight_fp_quant=True, act_fp_type="fp_e2", weight_fp_type="fp_e2", fc2_fp_type="fp_e1m2_neg_e2m1_pos")
+    base = Toy().to(dev)
+    plain = ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, **cfg).half()
+    fused = ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, fuse_ffn=True, **cfg).half()
+    assert isinstance(fused.ffn.fc1, gemm.FP4LinearGeluDual) and isinstance(fused.ffn.act, torch.nn.Identity)
+    assert type(fused.ffn.fc2).__name__ == "QuantizedLinear_fc2" and "epilogue" in repr(fused.ffn.fc2)
+    x = torch.randn(3, 50, 256, device=dev).half()
+    hq = fused.ffn.fc1(x)
+    want = plain.ffn.fc2.act_quant(plain.ffn.act(plain.ffn.fc1(x)))
+    assert hq.shape == want.shape == (3, 50, 1024)
+    same = (hq.view(torch.int16) == want.view(torch.int16)).float().mean()
+    assert float(same) >= 0.999, float(same)
+    ya, yb = plain.ffn(x).float(), fused.ffn(x).float()
+    assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
+    with pytest.raises(ValueError):
+        ql.quantize_VAR(copy.deepcopy(base), fuse_ffn=True, **cfg)                        # needs real_fp4
+    with pytest.raises(ValueError):
+        ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, fuse_ffn=True, **{**cfg, "fc2_fp_type": "fp_e2"})

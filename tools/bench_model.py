@@ -26,6 +26,7 @@ def main():
                     help="w4a4: run.sh line 4 (per-group fp_e2, fc2 dual FP4); w6a6: run.sh line 10 (per-token / per-channel fp6_e2m3, fc2 dual FP6)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--unfused-fc1", action="store_true", help="Q path: GEMM, GELU and the dual quantizer as three launches")
+    ap.add_argument("--tuned-gemms", action="store_true", help="torch's own GEMMs with the recorded TunableOp selections (var_block.tuned_torch_gemms)")
     args = ap.parse_args()
     torch.manual_seed(0)
     gb = var_block.GenerationBatch(args.model, args.config, depth=args.depth, batch_rows=args.batch, device="cuda:0",
@@ -33,6 +34,21 @@ def main():
     res = {"workload": gb.describe(), "depth": gb.depth, "batch_rows": gb.B, "fc1_epilogue_fused": gb.fused_fc1,
            "library": _lib.build_tag()}
     paths = args.paths.split(",")
+    import contextlib
+    ctx = var_block.tuned_torch_gemms() if args.tuned_gemms else contextlib.nullcontext()
+    with ctx as tg:
+        res["torch_gemms_tuned"] = bool(args.tuned_gemms and tg.active)
+        time_paths(args, gb, paths, res)
+    if "R" in paths:
+        for pth in ("F", "Q"):
+            if pth in paths:
+                res[f"speedup_{pth}_vs_R"] = round(res["R_ms_per_batch"] / res[f"{pth}_ms_per_batch"], 2)
+    for pth in paths:
+        res[f"images_per_s_{pth}"] = round((gb.B // 2) / (res[f"{pth}_ms_per_batch"] / 1e3), 1)
+    print(json.dumps(res))
+
+
+def time_paths(args, gb, paths, res):
     for path in paths:
         gb.run_eager(path)                                   # warm-up (allocator, kernel load)
         res[f"{path}_ms_per_batch"] = round(min(gb.run_eager(path) for _ in range(args.reps)), 1)
@@ -47,13 +63,6 @@ def main():
         except Exception as e:      # extra information only
             res[f"{path}_ms_per_batch_hipgraph"] = f"error: {str(e)[:120]}"
         torch.cuda.empty_cache()
-    if "R" in paths:
-        for pth in ("F", "Q"):
-            if pth in paths:
-                res[f"speedup_{pth}_vs_R"] = round(res["R_ms_per_batch"] / res[f"{pth}_ms_per_batch"], 2)
-    for pth in paths:
-        res[f"images_per_s_{pth}"] = round((gb.B // 2) / (res[f"{pth}_ms_per_batch"] / 1e3), 1)
-    print(json.dumps(res))
 
 
 if __name__ == "__main__":
