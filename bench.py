@@ -366,6 +366,11 @@ def other_kernels(dev):
         hbm("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680",
             timed(lambda: ops.quant_rows_dual(nxt(hs), "e1m2_neg", "e2m1_pos", GROUP, 1.0)), hs[0].numel() * 4)
 
+    def gelu_dual():
+        # fc2.act_quant(act(y)) in one pass over the fc1 output (tr/basic_var.py:120-121, tr/quant_utils.py:991): 2 B read + 2 B written
+        ys = [(torch.randn(ROWS, 4 * COLS, device=dev, generator=g) * 1.5).half() for _ in range(2)]
+        hbm("gelu_dual_fc2_one_pass_fp16_65536x7680", timed(lambda: ops.gelu_quant_rows_dual(nxt(ys))), ys[0].numel() * 4)
+
     def dual_fp6():
         hs = fc2_inputs()
         n = hs[0].numel()
@@ -513,7 +518,7 @@ def other_kernels(dev):
         hbm("config5_dual_fc2_e1m2neg_e2m1pos_fp16_44800x9216",
             timed(lambda: ops.quant_rows_dual(nxt(h5), "e1m2_neg", "e2m1_pos", GROUP, 1.0)), h5[0].numel() * 4)
 
-    groups = [("baseline_configs_1_2_4_5", configs), ("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4), ("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6),
+    groups = [("baseline_configs_1_2_4_5", configs), ("dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680", dual_fp4), ("gelu_dual_fc2_one_pass_fp16_65536x7680", gelu_dual), ("dual_fc2_intneg_e2m3pos_fp16_65536x7680", dual_fp6),
               ("activations_fp16_65536x1920", act16), ("operand_emitting_producers_65536x1920", operands),
               ("weights_fp32_32768x1920", weights), ("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", consumers)]
     only = os.environ.get("FPQ_BENCH_GROUPS")   # profiling aid: a comma-separated subset of the group functions' names
@@ -964,7 +969,7 @@ def own_all(shapes, own, dev):
 def pmc_traffic():
     """HBM bytes per launch of the headline kernel.  NOT measured by this process (rocprofv3 counters cannot be read
     from inside the run): the figure of the committed rocprofv3 --pmc passes of this same command, with its source."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:

@@ -59,6 +59,8 @@ _SIGS = {
                                           _c.c_void_p]),
     "fpq_quant_rows_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_float, _c.c_void_p, _c.c_void_p]),
+    "fpq_gelu_quant_rows_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                             _c.c_void_p, _c.c_void_p]),
     "fpq_quant_rows_codes_fp8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
                                              _c.c_int, _c.c_void_p]),
     "fpq_gemm_fp8_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,

@@ -43,6 +43,7 @@ struct Lut16Args {
   uint32_t* nan_flag;  // dual format only: nullptr, or device word OR-ed with 1 when an input is NaN
   const void* clip_absmax;   // dual format per group only (CLIP kernels): device scalar max|x| in x's dtype, or nullptr
   float clip_strength;       // the reference's global clamp to +-strength * max|x| (tr/quant_utils.py:421-422)
+  void* gelu_out;            // GELU kernels only: nullptr, or fp16 [rows, cols] receiving the GELU values the quantizer saw
 };
 
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
@@ -509,6 +510,59 @@ inline void lut16_build_host(uint16_t* lut, const Lut16Args& a) {
 }
 
 // ---------------------------------------------------------------------------------
+// GELU(tanh) of an fp16 tensor as torch computes it (fp32 arithmetic, one rounding to fp16): the FFN's activation between
+// fc1 and fc2's input quantizer (tr/basic_var.py:120), fused into the fc1 GEMM's epilogue (fpq_gemm_fp4.h, GemmFc1) and into
+// the stand-alone dual quantizer (rows16_lut_subwave_kernel<..., GELU>).
+// torch: aten/src/ATen/native/cuda/ActivationGeluKernel.cu, GeluCUDAKernelImpl, approximate == tanh (opmath = float):
+//   kBeta = M_SQRT2 * M_2_SQRTPI * 0.5, kKappa = 0.044715; x_cube = x * x * x; inner = kBeta * (x + kKappa * x_cube);
+//   0.5 * x * (1 + tanh(inner))
+// FPQ_GELU_FMA: the compiler that built torch contracts x + kKappa * x_cube into one fma (hipcc's default for HIP sources);
+// this library is built with contraction off, so the fma is spelled out.
+#ifndef FPQ_GELU_FMA
+#define FPQ_GELU_FMA 1
+#endif
+__device__ __forceinline__ float tanh_devlib(float x) {   // __ocml_tanh_f32 (ROCm device library), restated
+  const float y = __builtin_fabsf(x);
+  float z;
+  if (y < 0.625f) {
+    const float y2 = x * x;
+    float p = __builtin_fmaf(y2, -0x1.758e7ap-8f, 0x1.521192p-6f);
+    p = __builtin_fmaf(y2, p, -0x1.b8389cp-5f);
+    p = __builtin_fmaf(y2, p, 0x1.110704p-3f);
+    p = __builtin_fmaf(y2, p, -0x1.555532p-2f);
+    z = __builtin_fmaf(y2, y * p, y);
+  } else {
+    const float t = __builtin_expf(2.0f * y);
+    z = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+  }
+  return __builtin_copysignf(z, x);
+}
+__device__ __forceinline__ float gelu_tanh_like_torch(float x) {
+  const float kBeta = (float)(1.41421356237309504880 * 1.12837916709551257390 * 0.5), kKappa = 0.044715f;
+  const float x3 = x * x * x;
+#if FPQ_GELU_FMA
+  const float inner = kBeta * __builtin_fmaf(kKappa, x3, x);
+#else
+  const float inner = kBeta * (x + kKappa * x3);
+#endif
+  return 0.5f * x * (1.0f + tanh_devlib(inner));
+}
+
+// The form the epilogue runs (9 vector instructions instead of ~30): gelu(x) = x w, w = (1 + tanh(u)) / 2 = 1 / (1 + 2^m),
+// m = -2 log2(e) u = x (c0 + c1 x^2); `(w - 0.5) + 0.5` snaps w to the grid torch's own 1 + tanh(u) lives on (its tanh is an
+// fp32 number just below 1 for the deep negatives, where 1 + tanh cancels: without the snap the more exact w is up to 2 fp16
+// ulps away from what torch returns on 7 inputs in [-5.2, -4.7]).  tools/probe/gelu_probe.hip runs eight candidate forms over
+// all 65536 fp16 inputs against torch on the GPU (profiles/r05_gelu_probe.txt): the torch-order form above is bit-equal
+// to torch on every input; this one differs on 5 inputs, by one ulp each, NaN exactly where torch has NaN (NaN, -inf).
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float kBeta = (float)(1.41421356237309504880 * 1.12837916709551257390 * 0.5), kKappa = 0.044715f;
+  const float c0 = -2.8853900817779268f * kBeta, c1 = c0 * kKappa;   // float arithmetic, as in the probe
+  const float m = x * __builtin_fmaf(x * x, c1, c0);
+  const float w = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m));
+  return x * ((w - 0.5f) + 0.5f);
+}
+
+// ---------------------------------------------------------------------------------
 // rows of 1..64 lanes x 16 bytes inside one wavefront (per-group 128, KV c=64, ...).
 // A workgroup owns TILE = 256*U consecutive vectors (U*4 KiB, contiguous in HBM);
 // workgroups are dispatched in address order, so the chip sweeps the tensor front
@@ -521,7 +575,11 @@ inline void lut16_build_host(uint16_t* lut, const Lut16Args& a) {
 // is still seen) and clamped afterwards (clamping is monotonic).
 // HW6 (1: E2M3, 2: E3M2; U = 4: a lane's four vectors are the 32 values of one FP6 conversion, each with the scale of its own
 // row): levels from the FP6 conversion hardware (fp6_levels_hw32) - no table, no LDS, no barrier.
-template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true, bool HW4 = false, bool CLIP = false, int HW6 = 0>
+// GELU (dual format per group; round 5): x is the fc1 OUTPUT - every element goes through GELU(tanh) (gelu_tanh_fast above: fp32, one
+// rounding to fp16, within one fp16 ulp of torch's on every input) before the quantizer sees it: `fc2.act_quant(act(y))` of the
+// reference's FFN (tr/basic_var.py:120-121, tr/quant_utils.py:991) in one pass over y instead of two.
+template <int LPR, bool DUAL, int U, bool TAB_ARG, bool NTL = true, bool NTS = true, bool HW4 = false, bool CLIP = false, int HW6 = 0,
+          bool GELU = false>
 __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4* __restrict__ x,
                                                                    u32x4* __restrict__ out, int64_t n_vec,
                                                                    Lut16Args a, Lut16Tab tab) {
@@ -550,6 +608,15 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_subwave_kernel(const u32x4*
       int64_t v = v0 + u * kBlock;
       live[u] = v < n_vec;
       raw[u] = live[u] ? (NTL ? __builtin_nontemporal_load(x + v) : x[v]) : u32x4{0, 0, 0, 0};
+    }
+    if constexpr (GELU) {
+      static_assert(DUAL && !CLIP && HW6 == 0, "the fused activation belongs to fc2's dual-format input quantizer");
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) raw[u][k] = f2h2(gelu_tanh_fast(h2f(raw[u][k] & 0xFFFFu)), gelu_tanh_fast(h2f(raw[u][k] >> 16)));
+        if (a.gelu_out && live[u]) __builtin_nontemporal_store(raw[u], (u32x4*)a.gelu_out + v0 + u * kBlock);
+      }
     }
     if constexpr (HW6 != 0) {
       uint32_t q6[16], lv6[16], sc6[4];

@@ -322,54 +322,7 @@ struct GemmFc1 {
   Lut16Tab tab;          // ... and the table itself, by value (as the stand-alone quantizers take it)
 };
 
-// torch: aten/src/ATen/native/cuda/ActivationGeluKernel.cu, GeluCUDAKernelImpl, approximate == tanh (opmath = float):
-//   kBeta = M_SQRT2 * M_2_SQRTPI * 0.5, kKappa = 0.044715; x_cube = x * x * x; inner = kBeta * (x + kKappa * x_cube);
-//   0.5 * x * (1 + tanh(inner))
-// FPQ_GELU_FMA: the compiler that built torch contracts x + kKappa * x_cube into one fma (hipcc's default for HIP sources);
-// this library is built with contraction off, so the fma is spelled out.
-#ifndef FPQ_GELU_FMA
-#define FPQ_GELU_FMA 1
-#endif
-FPQ_NOPK __device__ __forceinline__ float tanh_devlib(float x) {   // __ocml_tanh_f32 (ROCm device library), restated
-  const float y = __builtin_fabsf(x);
-  float z;
-  if (y < 0.625f) {
-    const float y2 = x * x;
-    float p = __builtin_fmaf(y2, -0x1.758e7ap-8f, 0x1.521192p-6f);
-    p = __builtin_fmaf(y2, p, -0x1.b8389cp-5f);
-    p = __builtin_fmaf(y2, p, 0x1.110704p-3f);
-    p = __builtin_fmaf(y2, p, -0x1.555532p-2f);
-    z = __builtin_fmaf(y2, y * p, y);
-  } else {
-    const float t = __builtin_expf(2.0f * y);
-    z = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
-  }
-  return __builtin_copysignf(z, x);
-}
-FPQ_NOPK __device__ __forceinline__ float gelu_tanh_like_torch(float x) {
-  const float kBeta = (float)(1.41421356237309504880 * 1.12837916709551257390 * 0.5), kKappa = 0.044715f;
-  const float x3 = x * x * x;
-#if FPQ_GELU_FMA
-  const float inner = kBeta * __builtin_fmaf(kKappa, x3, x);
-#else
-  const float inner = kBeta * (x + kKappa * x3);
-#endif
-  return 0.5f * x * (1.0f + tanh_devlib(inner));
-}
-
-// The form the epilogue runs (9 vector instructions instead of ~30): gelu(x) = x w, w = (1 + tanh(u)) / 2 = 1 / (1 + 2^m),
-// m = -2 log2(e) u = x (c0 + c1 x^2); `(w - 0.5) + 0.5` snaps w to the grid torch's own 1 + tanh(u) lives on (its tanh is an
-// fp32 number just below 1 for the deep negatives, where 1 + tanh cancels: without the snap the more exact w is up to 2 fp16
-// ulps away from what torch returns on 7 inputs in [-5.2, -4.7]).  tools/probe/gelu_probe.hip runs eight candidate forms over
-// all 65536 fp16 inputs against torch on the GPU (profiles/r05_gelu_probe.txt): the torch-order form above is bit-equal
-// to torch on every input; this one differs on 5 inputs, by one ulp each, NaN exactly where torch has NaN (NaN, -inf).
-FPQ_NOPK __device__ __forceinline__ float gelu_tanh_fast(float x) {
-  const float kBeta = (float)(1.41421356237309504880 * 1.12837916709551257390 * 0.5), kKappa = 0.044715f;
-  const float c0 = -2.8853900817779268f * kBeta, c1 = c0 * kKappa;   // float arithmetic, as in the probe
-  const float m = x * __builtin_fmaf(x * x, c1, c0);
-  const float w = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m));
-  return x * ((w - 0.5f) + 0.5f);
-}
+// (the GELU itself - gelu_tanh_fast, gelu_tanh_like_torch - lives in fpq_fast16.h: the stand-alone fused quantizer uses it too)
 #ifdef FPQ_FC1_GELU_TORCH_ORDER   // A/B builds: the bit-equal form
 #define FPQ_FC1_GELU gelu_tanh_like_torch
 #else

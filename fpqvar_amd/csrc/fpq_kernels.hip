@@ -998,6 +998,7 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
         h.args.nan_flag = nullptr;
         h.args.clip_absmax = nullptr;
         h.args.clip_strength = 1.0f;
+        h.args.gelu_out = nullptr;
         for (int i = 0; i < kLutLdsEntries; ++i) h.full[i] = 0;
         lut16_build_host(h.full, h.args);
         h.tab_valid = lut16_compress(h.full, h.args.shift, &h.tab);
@@ -1019,12 +1020,13 @@ inline const Lut16Host& lut16_host(int neg_id, int pos_id) {
 template <bool DUAL, int U = FPQ_FAST16_U, bool NTL = true, bool NTS = true>
 int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id, hipStream_t st,
                   int grid_cap = 1 << 20, uint32_t* nan_flag = nullptr, const void* clip_absmax = nullptr,
-                  float clip_strength = 1.0f) {
+                  float clip_strength = 1.0f, bool gelu = false, void* gelu_out = nullptr) {
   const Lut16Host& h = lut16_host(neg_id, pos_id);
   Lut16Args args = h.args;
   args.nan_flag = nan_flag;
   args.clip_absmax = clip_absmax;
   args.clip_strength = clip_strength;
+  args.gelu_out = gelu_out;
   const int64_t n_vec = rows * (cols / 8);
   const int lpr = (int)(cols / 8);
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
@@ -1041,6 +1043,11 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
   // the headline shape - E2M1, groups of 128 - takes its levels from the FP4 conversion hardware (fpq_fast16.h); FPQ_NO_HW4
   // (read at every call: the exhaustive test sweeps both forms in one process) keeps the bucket table
   if constexpr (DUAL) {
+    if (gelu) {          // groups of 128, small tables (fpq_gelu_quant_rows_dual checks): GELU in front of the quantizer, one pass
+      if (lpr != 16 || clip_absmax) return FPQ_ERR_SHAPE;
+      return go(rows16_lut_subwave_kernel<16, true, U, true, NTL, NTS, false, false, 0, true>,
+                rows16_lut_subwave_kernel<16, true, U, false, NTL, NTS, false, false, 0, true>);
+    }
     if (clip_absmax) {   // groups of 128 only (fpq_quant_rows_dual checks): the clamping form of the same kernel
       if (lpr != 16) return FPQ_ERR_SHAPE;
       return go(rows16_lut_subwave_kernel<16, true, U, true, NTL, NTS, false, true>, rows16_lut_subwave_kernel<16, true, U, false, NTL, NTS, false, true>);
@@ -1883,6 +1890,23 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
   if (rc != FPQ_OK || !flag) return rc;
   const int64_t n_bytes = rows * cols * (out_dtype == FPQ_F16 ? 2 : 4);
   hipLaunchKernelGGL(zero_if_flag_kernel, dim3(kFixupBlocks), dim3(kBlock), 0, st, (uint8_t*)out, n_bytes, flag);
+  return check_launch();
+}
+
+int fpq_gelu_quant_rows_dual(const void* x, void* out, void* gelu_out, int64_t rows, int64_t cols, int neg_table, int pos_table,
+                             void* nan_flag, fpq_stream_t stream) {
+  if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
+  if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_E2M1_NEG) return FPQ_ERR_TABLE;     // the FP4 dual pairs (small bucket tables)
+  if (pos_table != FPQ_E2M1_POS) return FPQ_ERR_TABLE;
+  if (cols != 128) return FPQ_ERR_SHAPE;
+  if (rows == 0) return FPQ_OK;
+  if (!x || !out) return FPQ_ERR_ARG;
+  if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gelu_out) & 15) != 0 || ((uintptr_t)nan_flag & 7) != 0) return FPQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, (uint32_t*)nan_flag, nullptr, 1.0f, true, gelu_out))
+    return rc;
+  if (!nan_flag) return FPQ_OK;
+  hipLaunchKernelGGL(zero_if_flag_kernel, dim3(kFixupBlocks), dim3(kBlock), 0, st, (uint8_t*)out, rows * cols * 2, (uint32_t*)nan_flag);
   return check_launch();
 }
 

@@ -408,6 +408,60 @@ at::Tensor linear_fp4(const at::Tensor& a_codes, const at::Tensor& a_scales, con
   return out;
 }
 
+// fc1 with the FFN's GELU and fc2's dual-format input quantizer in the GEMM's epilogue (tr/basic_var.py:120-121,
+// tr/quant_utils.py:415-452,991): gemm.linear_fp4_gelu_dual.  Returns (out, gelu values or an undefined tensor).
+std::tuple<at::Tensor, c10::optional<at::Tensor>> linear_fp4_gelu_dual(const at::Tensor& a_codes, const at::Tensor& a_scales, const at::Tensor& w_codes,
+                                                                        const at::Tensor& w_scales, const c10::optional<at::Tensor>& bias,
+                                                                        bool return_gelu) {
+  require_gpu(a_codes, "linear_fp4_gelu_dual");
+  TORCH_CHECK(a_codes.dim() == 2 && w_codes.dim() == 2, "linear_fp4_gelu_dual: codes must be [rows, K / 2]");
+  const int64_t tokens = a_codes.size(0), outs = w_codes.size(0), k = a_codes.size(1) * 2;
+  TORCH_CHECK(w_codes.size(1) * 2 == k && a_scales.scalar_type() == at::kHalf && k % 128 == 0 && outs % 128 == 0,
+              "linear_fp4_gelu_dual: operand shapes / activation scale dtype mismatch (outs must be a multiple of 128)");
+  const at::Device dev = a_codes.device();
+  check_operand("linear_fp4_gelu_dual(activation)", a_codes, a_scales, tokens, k / 2, tokens * (k / 128), dev);
+  check_operand("linear_fp4_gelu_dual(weight)", w_codes, w_scales, outs, k / 2, outs * (k / 128), dev);
+  at::Tensor out = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
+  c10::optional<at::Tensor> h;
+  if (return_gelu) h = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
+  if (tokens == 0 || outs == 0) return {out, h};
+  at::Tensor b;
+  if (bias.has_value()) {
+    TORCH_CHECK(bias->numel() == outs && bias->device() == dev, "linear_fp4_gelu_dual: bias must hold one value per output on the operands' device");
+    b = bias->detach().to(at::kHalf).reshape({-1}).contiguous();
+    if ((reinterpret_cast<uintptr_t>(b.data_ptr()) & 15) != 0) b = b.clone();
+  }
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
+  const fpq_stream_t st = current_stream(a_codes);
+  at::Tensor scratch = nan_scratch(a_codes, st);
+  const int status = fpq_gemm_fp4_gelu_dual((const uint8_t*)a_codes.data_ptr(), a_scales.data_ptr(), (const uint8_t*)w_codes.data_ptr(), w_scales.data_ptr(),
+                                            dtype_id(w_scales.scalar_type(), "linear_fp4_gelu_dual"), b.defined() ? b.data_ptr() : nullptr, out.data_ptr(),
+                                            h.has_value() ? h->data_ptr() : nullptr, tokens, outs, k, scratch.data_ptr(), st);
+  if (status != 0) (void)hipMemsetAsync(scratch.data_ptr(), 0, 8, (hipStream_t)st);
+  check(status, "fpq_gemm_fp4_gelu_dual");
+  return {out, h};
+}
+
+// `fc2.act_quant(act(y))` in one pass over the fp16 fc1 output y: ops.gelu_quant_rows_dual
+std::tuple<at::Tensor, c10::optional<at::Tensor>> gelu_quant_rows_dual(const at::Tensor& y, int64_t neg_id, int64_t pos_id, bool return_gelu) {
+  require_gpu(y, "gelu_quant_rows_dual");
+  TORCH_CHECK(y.scalar_type() == at::kHalf && y.dim() >= 1 && y.size(-1) % 128 == 0,
+              "gelu_quant_rows_dual: y must be float16 with a last dimension that is a multiple of 128");
+  const at::Tensor yc = y.is_contiguous() ? y : y.contiguous();
+  at::Tensor out = at::empty(y.sizes(), y.options());
+  c10::optional<at::Tensor> h;
+  if (return_gelu) h = at::empty(y.sizes(), y.options());
+  if (yc.numel() == 0) return {out, h};
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(y.device());
+  const fpq_stream_t st = current_stream(y);
+  at::Tensor scratch = nan_scratch(y, st);
+  const int status = fpq_gelu_quant_rows_dual(yc.data_ptr(), out.data_ptr(), h.has_value() ? h->data_ptr() : nullptr, yc.numel() / 128, 128, (int)neg_id,
+                                              (int)pos_id, scratch.data_ptr(), st);
+  if (status != 0) (void)hipMemsetAsync(scratch.data_ptr(), 0, 8, (hipStream_t)st);
+  check(status, "fpq_gelu_quant_rows_dual");
+  return {out, h};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -443,6 +497,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("new_start"), py::arg("group"), py::arg("table_id"));
   m.def("linear_fp4", &linear_fp4, py::arg("a_codes"), py::arg("a_scales"), py::arg("w_codes"), py::arg("w_scales"),
         py::arg("bias") = py::none(), py::arg("gate") = py::none(), py::arg("residual") = py::none());
+  m.def("linear_fp4_gelu_dual", &linear_fp4_gelu_dual, py::arg("a_codes"), py::arg("a_scales"), py::arg("w_codes"), py::arg("w_scales"),
+        py::arg("bias") = py::none(), py::arg("return_gelu") = false);
+  m.def("gelu_quant_rows_dual", &gelu_quant_rows_dual, py::arg("y"), py::arg("neg_table_id"), py::arg("pos_table_id"), py::arg("return_gelu") = false);
   m.def("fp6_quant_per_token_contig", &fp6_quant_per_token_contig, py::arg("x"), py::arg("n_bits"), py::arg("table_id"));
   m.def("fp6_quant_int_neg_e2m3_pos_per_token_contig", &fp6_quant_int_neg_e2m3_pos_per_token_contig, py::arg("x"), py::arg("n_bits"));
 }

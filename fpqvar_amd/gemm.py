@@ -139,6 +139,9 @@ def linear_fp4_gelu_dual(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes:
     (tr/basic_var.py:120-121, tr/quant_utils.py:415-452,991) as the epilogue of the FP4 GEMM (fpq_gemm_fp4_gelu_dual):
     fp16 [tokens, outs], outs % 128 == 0.  return_gelu: also the GELU values the quantizer saw - the quantization is
     bit-exact on THOSE, they sit within one fp16 ulp of torch's GELU of the Linear output."""
+    if _native is not None:   # same checks, same C call, the binding's own NaN scratch
+        out, h = _native.linear_fp4_gelu_dual(a_codes, a_scales, w_codes, w_scales, bias, return_gelu)
+        return (out, h) if return_gelu else out
     require_gpu(a_codes, "linear_fp4_gelu_dual")
     if a_codes.dim() != 2 or w_codes.dim() != 2:
         raise RuntimeError("linear_fp4_gelu_dual: codes must be [rows, K / 2]")

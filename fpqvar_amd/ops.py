@@ -271,6 +271,31 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
     return out
 
 
+def gelu_quant_rows_dual(y: torch.Tensor, neg_table: str = "e1m2_neg", pos_table: str = "e2m1_pos", return_gelu: bool = False):
+    """`quant_rows_dual(F.gelu(y, approximate="tanh"), neg, pos, 128, 1.0)` in ONE pass over y (fpq_gelu_quant_rows_dual): the
+    reference's `fc2.act_quant(act(fc1_output))` (tr/basic_var.py:120-121, tr/quant_utils.py:991) for an fp16 fc1 output whose
+    last dimension is a multiple of 128.  return_gelu: also the GELU values the quantizer saw (quantization bit-exact on those;
+    within one fp16 ulp of torch's GELU on every fp16 input)."""
+    if _native is not None:
+        out, h = _native.gelu_quant_rows_dual(y, TABLE_IDS[neg_table], TABLE_IDS[pos_table], return_gelu)
+        return (out, h) if return_gelu else out
+    require_gpu(y, "gelu_quant_rows_dual")
+    if y.dtype != torch.float16 or y.shape[-1] % 128 != 0:
+        raise RuntimeError(f"gelu_quant_rows_dual: y must be float16 with a last dimension that is a multiple of 128, got {y.dtype} {tuple(y.shape)}")
+    yc = _contig(y)
+    out = torch.empty(y.shape, dtype=torch.float16, device=y.device)
+    h = torch.empty(y.shape, dtype=torch.float16, device=y.device) if return_gelu else None
+    if yc.numel():
+        with device_guard(y.device):
+            flag_ptr = _nan_scratch(y.device).data_ptr()
+            status = lib().fpq_gelu_quant_rows_dual(yc.data_ptr(), out.data_ptr(), None if h is None else h.data_ptr(), yc.numel() // 128, 128,
+                                                    TABLE_IDS[neg_table], TABLE_IDS[pos_table], flag_ptr, stream_ptr(y.device))
+            if status != 0:
+                _NAN_SCRATCH.clear()
+            check(status, "fpq_gelu_quant_rows_dual")
+    return (out, h) if return_gelu else out
+
+
 _NAN_SCRATCH = {}
 _NAN_SCRATCH_CAPTURED = []
 

@@ -135,6 +135,15 @@ if _native is not None:
     fp_quant_e1m2_neg_e2m1_pos_per_group_cuda = _native.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda
 
 
+def gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, n_bits, group_size=128):
+    """`fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(F.gelu(y, approximate="tanh"), n_bits, 128)` - what the reference's FFN feeds fc2's
+    GEMM (tr/basic_var.py:120-121: `self.fc2(self.act(self.fc1(x)))`, the quantizer bound at tr/quant_utils.py:991) - in one pass
+    over the fc1 output y instead of two (additive, build-defined name: Level 1b of INTEGRATION.md; the GELU is within one fp16
+    ulp of torch's on every input, the quantization exact on it)."""
+    assert n_bits == 4 and group_size == 128
+    return ops.gelu_quant_rows_dual(y, "e1m2_neg", "e2m1_pos")
+
+
 def quantize_to_nearest_grid(x, quant_grid):
     """tr/quant_utils.py:209-230 in one launch (no [N, K] distance tensor): quant_grid[argmin |x - quant_grid|]."""
     return ops.quant_nearest_argmin(x, quant_grid)

@@ -11,8 +11,8 @@ Three ways to run everything around the attention core:
      quant_cuda.quant (tr/quant_utils.py:313-330,415-452,503-517), the dense fp16 GEMM with the block-diagonal Q
      (tr/basic_var.py:263,266), fp16 Linears on de-quantized tensors (tr/quant_utils.py:767), the whole KV cache
      re-quantized at every step (tr/basic_var.py:186-209)
-  F  one launch per quantizer, the fused LayerNorm / modulate / smooth / rotate / quant producer, incremental KV cache;
-     the Linears stay fp16 GEMMs on fake-quantized values (what the reference's numerics are)
+  F  one launch per quantizer, the fused LayerNorm / modulate / smooth / rotate / quant producer, incremental KV cache, GELU
+     fused in front of fc2's input quantizer; the Linears stay fp16 GEMMs on fake-quantized values (the reference's numerics)
   Q  F with mat_qkv / proj / fc1 on the FP4 (W6A6: FP6) matrix cores - the producers emit the GEMM operands, proj applies
      the block's gate and residual in its epilogue, fc1 applies GELU and fc2's dual-format input quantizer in its epilogue
      (gemm.linear_fp4_gelu_dual; W4A4 only) - and attention by fpq_attention_blhc straight off the cache views
@@ -117,6 +117,7 @@ class GenerationBatch:
         self.max_len = sum(p * p for p in self.patch_nums)
         self.W6 = config == "w6a6"
         self.fused_fc1 = fused_fc1 and not self.W6 and hasattr(gemm, "linear_fp4_gelu_dual")
+        self.fused_gelu_quant = fused_fc1 and not self.W6      # path F: GELU + fc2's input quantizer in one pass over the fc1 output
         C, HID, B = self.C, self.HID, self.B
         g = torch.Generator(device=dev).manual_seed(seed)
         self.gen = g
@@ -230,7 +231,9 @@ class GenerationBatch:
             else:
                 x = self.q_proj(a.view(B * L, C), g1, x).view(B, L, C)
             if path == "F":
-                hq = self.f_fc2(Fn.gelu(Fn.linear(self.f_producer(x, sc2, sh2, self.s_fc1), self.wq["fc1"]), approximate="tanh"))
+                y = Fn.linear(self.f_producer(x, sc2, sh2, self.s_fc1), self.wq["fc1"])
+                hq = qu.gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, 4, 128) if self.fused_gelu_quant else \
+                    self.f_fc2(Fn.gelu(y, approximate="tanh"))
             elif self.fused_fc1:
                 hq = self.q_fc1_gelu_dual(x, sc2, sh2).view(B, L, HID)
             else:

@@ -27,7 +27,7 @@ extern "C" {
 #define FPQ_VERSION 124 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
                            0.1.3: + fpq_quant_rows_codes_segments, fpq_dequant_rows_codes_segments (round 3);
                            123: + fpq_build_tag (round 4);
-                           124: + fpq_set_option, fpq_get_option, fpq_option_name, fpq_gemm_fp4_gelu_dual (round 5) */
+                           124: + fpq_set_option, fpq_get_option, fpq_option_name, fpq_gemm_fp4_gelu_dual, fpq_gelu_quant_rows_dual (round 5) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -190,6 +190,14 @@ int fpq_quant_rows_argmin(const void* x, float* out, int64_t rows, int64_t cols,
 int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, int neg_table,
                         int pos_table, int in_dtype, int out_dtype, const void* clip_absmax,
                         float clip_strength, void* nan_flag, fpq_stream_t stream);
+
+/* `fc2.act_quant(act(y))` of the reference's FFN in ONE pass over y (tr/basic_var.py:120-121: act = GELU(approximate="tanh");
+ * tr/quant_utils.py:991: fc2's input quantizer): out = fpq_quant_rows_dual(half(gelu_tanh(float(y)))) for fp16 rows of 128 (groups),
+ * clipping strength 1.0, neg_table in {E1M2_NEG, E2M1_NEG}, pos_table = E2M1_POS.  gelu_out: NULL, or fp16 [rows, 128] receiving
+ * the GELU values the quantizer saw (the quantization is bit-exact on those; they sit within one fp16 ulp of torch's GELU on
+ * every fp16 input).  nan_flag as in fpq_quant_rows_dual.  The same fused tail inside the fc1 GEMM: fpq_gemm_fp4_gelu_dual. */
+int fpq_gelu_quant_rows_dual(const void* y, void* out, void* gelu_out, int64_t rows, int64_t cols, int neg_table, int pos_table,
+                             void* nan_flag, fpq_stream_t stream);
 
 /* The pure-torch twin of the FP4 dual format, fp_quant_e1m2_neg_e2m1_pos_per_group (tr/quant_utils.py:381-412;
  * what models_fp_quant_rotate's QuantizedLinear_fc2 binds, rot/quant_utils.py:779): same split and scales as

@@ -197,3 +197,44 @@ def test_quantize_var_fuses_the_ffn(dev):
         ql.quantize_VAR(copy.deepcopy(base), fuse_ffn=True, **cfg)                        # needs real_fp4
     with pytest.raises(ValueError):
         ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, fuse_ffn=True, **{**cfg, "fc2_fp_type": "fp_e2"})
+
+
+@pytest.mark.parametrize("shape", [(300, 7680), (1, 128), (5, 37, 1024), (16900, 7680)])
+def test_gelu_quant_rows_dual_one_pass(dev, shape):
+    """The stand-alone form (fpq_gelu_quant_rows_dual: `fc2.act_quant(act(y))` in one pass over the fc1 output y, for the drop-in
+    path whose fc1 stays a torch GEMM): the emitted GELU values within one fp16 ulp of torch's, the quantization bit-exact on
+    them against the plain dual quantizer and the oracle, and equal to what the fc1 GEMM's epilogue computes for the same y."""
+    from fpqvar_amd import ops, quant_utils as qu
+    g = torch.Generator().manual_seed(sum(shape))
+    y = (torch.randn(*shape, generator=g) * 1.5).half().to(dev)
+    q, h = ops.gelu_quant_rows_dual(y, return_gelu=True)
+    assert q.shape == h.shape == y.shape and q.dtype == torch.float16
+    d = ulp_diff(h, Fn.gelu(y, approximate="tanh"))
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01
+    assert_bits_equal(q, ops.quant_rows_dual(h, "e1m2_neg", "e2m1_pos", 128, 1.0), "fused vs the plain dual quantizer on the emitted GELU values")
+    if y.numel() <= 1 << 22:
+        assert_bits_equal(q.cpu(), orc.dual_per_group_kernel_sem(h.cpu().reshape(-1, 128), "e1m2_neg", "e2m1_pos", 128, 1.0).view(shape), "fused vs oracle")
+    assert_bits_equal(qu.gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, 4, 128), q, "quant_utils name, no GELU output")
+
+
+def test_gelu_quant_rows_dual_every_fp16_input_and_nan_rule(dev):
+    """All 65536 fp16 patterns through the stand-alone fused kernel: the same GELU as the GEMM epilogue (<= 1 ulp from torch, NaN
+    where torch has NaN), and the NaN rule (the result is zero everywhere, the scratch zero again)."""
+    from fpqvar_amd import ops
+    every = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.float16).to(dev)
+    q, h = ops.gelu_quant_rows_dual(every, return_gelu=True)
+    ref = Fn.gelu(every, approximate="tanh")
+    d = ulp_diff(h, ref)
+    assert int(d.max()) <= 1 and int((d > 0).sum()) <= 64 and torch.equal(torch.isnan(h), torch.isnan(ref))
+    assert not bool(q.view(torch.int16).any())
+    torch.cuda.synchronize()
+    assert not bool(ops._nan_scratch(dev).any())
+    finite = every[(every.abs() < 100) & ~torch.isnan(every)]
+    finite = finite[: finite.numel() // 128 * 128]
+    qf, hf = ops.gelu_quant_rows_dual(finite, return_gelu=True)
+    assert bool(qf.any())
+    assert_bits_equal(qf, ops.quant_rows_dual(hf, "e1m2_neg", "e2m1_pos", 128, 1.0), "finite inputs")
+    with pytest.raises(RuntimeError):
+        ops.gelu_quant_rows_dual(every.float())
+    with pytest.raises(RuntimeError):
+        ops.gelu_quant_rows_dual(every[:100])

@@ -170,6 +170,12 @@ def test_native_q_path_equals_ctypes_path(monkeypatch):
     same(*both(lambda: gemm.linear_fp4(*a, *w, bias, gate, res)), "linear_fp4 + epilogue")
     with pytest.raises(RuntimeError):
         gemm.linear_fp4(a[0][:, :-64], a[1], *w)
+    # the fused fc1 tail and its stand-alone twin (round 5)
+    same(*both(lambda: gemm.linear_fp4_gelu_dual(*a, *w, bias, return_gelu=True)), "linear_fp4_gelu_dual")
+    same(*both(lambda: gemm.linear_fp4_gelu_dual(*a, *w)), "linear_fp4_gelu_dual without bias / GELU output")
+    yq = (torch.randn(B, L, 256, generator=g) * 1.5).half().to(dev)
+    same(*both(lambda: ops.gelu_quant_rows_dual(yq, return_gelu=True)), "gelu_quant_rows_dual")
+    same(*both(lambda: ops.gelu_quant_rows_dual(yq)), "gelu_quant_rows_dual without the GELU output")
     # edge cases of the compiled binding: bias / gate / residual views at an odd storage offset (2 bytes past a
     # 16-byte boundary) give the aligned result bit for bit; zero tokens / zero outputs are valid and enqueue nothing
     want = _native.linear_fp4(*a, *w, bias, gate, res)

@@ -16,7 +16,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 # the kernels of the hot path: quantizers, producers, KV step, code emitters
-HOT = re.compile(r"rows16_lut|groups32|rows32|rotate_quant_mfma|adaln_mfma|adaln_rq16|kv16_step|rows16_codes|codes128|decode128")
+HOT = re.compile(r"rows16_lut|groups32|rows32|rotate_quant_mfma|adaln_mfma|adaln_rq16|kv16_step|rows16_codes|codes128|decode128|gemm_fp4_glds|gemm_fp6_rows|gemm_fp8_rows")
 
 
 def _tool(name):
@@ -89,3 +89,15 @@ def test_occupancy_relevant_register_budgets(tmp_path):
     # <fp16 input, EMIT any, SMOOTH = 0, ...>
     for n, r in find(lambda n: re.search(r"rotate_quant_mfma_kernelIDF16_Lb[01]ELb0E", n)):
         assert int(r["vgpr_count"]) <= 80, (n, r["vgpr_count"])
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libfpq_hip.so not built")
+def test_fc1_tail_register_budgets(tmp_path):
+    """The fc1 GEMM with GELU + dual quantizer in its epilogue (round 5) keeps the plain GEMM's occupancy: 256 x 128 tiles two
+    workgroups per CU (<= 256 registers per lane), 128 x 128 and 64 x 128 tiles three (<= 168), no scratch."""
+    recs = kernel_metadata(tmp_path)
+    fc1 = [(n, r) for n, r in recs if "gemm_fp4_glds_kernel" in n and "GemmFc1" in n]
+    assert len(fc1) == 6, [n for n, _ in fc1]                      # {fp16, fp32 weight scales} x {64, 128, 256 rows}
+    for n, r in fc1:
+        limit = 256 if "Li8ELi4E" in n else 168
+        assert int(r["vgpr_count"]) + int(r.get("agpr_count", 0)) <= limit and int(r.get("private_segment_fixed_size", 0)) == 0, (n, r["vgpr_count"])

@@ -1,13 +1,14 @@
 #!/bin/bash
-# Round-4 evidence, every file headed by WHAT was measured: the commit (FPQ_GIT_HEAD, set by the caller: the GPU box has no
+# A round's evidence (FPQ_ROUND, default r05), every file headed by WHAT was measured: the commit (FPQ_GIT_HEAD, set by the caller: the GPU box has no
 # .git) and the SHA-256 of the library that ran.  Counters in separate --pmc passes (never mixed with tracing) for the kernels
 # DESIGN.md quotes, and the rocprofv3 --kernel-trace --stats summary + FETCH / WRITE passes of the bench.py command itself.
-#   tools/collect_profiles.sh pmc [cases]  -> gpurun_out/prof_r04/pmc_<case>.txt          (one GPU call)
-#   tools/collect_profiles.sh bench        -> gpurun_out/prof_r04/bench_*.{json,csv,txt}  (another)
-#   tools/collect_profiles.sh steps        -> gpurun_out/prof_r04/steps_*.json            (the ten scale steps of d30 / d36-512)
-# The summaries are copied to profiles/r04_* after reading them.
+#   tools/collect_profiles.sh pmc [cases]  -> gpurun_out/prof_<round>/pmc_<case>.txt          (one GPU call)
+#   tools/collect_profiles.sh bench        -> gpurun_out/prof_<round>/bench_*.{json,csv,txt}  (another)
+#   tools/collect_profiles.sh steps        -> gpurun_out/prof_<round>/steps_*.json            (the ten scale steps of d30 / d36-512)
+# python tools/install_profiles.py copies them to profiles/<round>_* .
 set -e
-out=$PWD/gpurun_out/prof_r04
+round=${FPQ_ROUND:-r05}
+out=$PWD/gpurun_out/prof_$round
 mkdir -p $out
 export TMPDIR=/tmp
 sha=$(sha256sum fpqvar_amd/libfpq_hip.so | cut -c1-64)
@@ -35,14 +36,14 @@ else
   # the bench command itself: the line, the same command under --kernel-trace --stats, and the two traffic passes
   python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.log
   echo "bench ok"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_kt -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_kt.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_kt -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --skip generation,format_search,steps > $out/bench_under_rocprof.json 2> $out/bench_kt.log
   find $out/bench_kt -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats_full.csv \;
-  { echo "$stampline"; echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (this library's kernels only)"
+  { echo "$stampline"; echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --skip generation,format_search,steps (this library's kernels only)"
     grep -E "^\"Name\"|^\"_ZN12_GLOBAL__N_|^\"void \(anonymous namespace\)::" $out/bench_kernel_stats_full.csv | sed -E 's/^"(_ZN12_GLOBAL__N_[0-9]*[a-z_0-9]*)[^"]*"/"\1"/; s/^"void \(anonymous namespace\)::([a-z_0-9]*<[^>]*>)[^"]*"/"\1"/'; } > $out/bench_kernel_stats.csv
   rm -rf $out/bench_kt $out/bench_kernel_stats_full.csv
   echo "bench kernel trace ok"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/bench_f -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/bench_f.log
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/bench_w -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/bench_w.log
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/bench_f -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --skip generation,format_search,steps,other_kernels > /dev/null 2> $out/bench_f.log
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/bench_w -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --skip generation,format_search,steps,other_kernels > /dev/null 2> $out/bench_w.log
   { echo "$stampline"; python3 tools/pmc_summary.py $out/bench_f rows16_lut_subwave; python3 tools/pmc_summary.py $out/bench_f groups32; } > $out/bench_fetch.txt
   { echo "$stampline"; python3 tools/pmc_summary.py $out/bench_w rows16_lut_subwave; python3 tools/pmc_summary.py $out/bench_w groups32; } > $out/bench_write.txt
   rm -rf $out/bench_f $out/bench_w

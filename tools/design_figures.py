@@ -9,6 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROWS = [   # (label, bytes per element, other_kernels key)
     ("dual E1M2⁻/E2M1⁺ g=128 `[65536×7680]` (two launches; fc2's input, A5)", "4", "dual_fc2_e1m2neg_e2m1pos_fp16_65536x7680"),
+    ("GELU(tanh) + the same quantizer in ONE pass over the fc1 output (round 5; two launches)", "4", "gelu_dual_fc2_one_pass_fp16_65536x7680"),
     ("dual INT⁻/E2M3⁺ g=128 `[65536×7680]` (A8)", "4", "dual_fc2_intneg_e2m3pos_per_group_fp16_65536x7680"),
     ("dual INT⁻/E2M3⁺ per token `[65536×7680]` (A8)", "4", "dual_fc2_intneg_e2m3pos_per_token_fp16_65536x7680"),
     ("E2M3 per token `[65536×1920]`, FP6 conversion hardware (A6)", "4", "fp6_e2m3_per_token_fp16_65536x1920"),
