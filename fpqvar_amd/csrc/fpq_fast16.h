@@ -870,7 +870,9 @@ __device__ __forceinline__ uint32_t block_max16(uint32_t v, uint32_t* sh) {
   return r;
 }
 
-template <bool DUAL, int MAXC, bool TAB_ARG>
+// GELU: as in rows16_lut_subwave_kernel - x is the fc1 output, every element goes through GELU(tanh) first (the W6A6 run's
+// `fc2.act_quant(act(y))` with the per-token INT-/E2M3+ quantizer, tr/quant_utils.py:614-646 bound at :930-931).
+template <bool DUAL, int MAXC, bool TAB_ARG, bool GELU = false>
 __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t* __restrict__ x,
                                                                  uint16_t* __restrict__ out, int64_t rows,
                                                                  int64_t cols, int64_t rows_per_block, Lut16Args a,
@@ -890,6 +892,16 @@ __global__ __launch_bounds__(kBlock) void rows16_lut_block_kernel(const uint16_t
     for (int c = 0; c < MAXC; ++c) {
       int64_t v = (int64_t)c * kBlock + threadIdx.x;
       raw[c] = (v < vec_per_row) ? __builtin_nontemporal_load(xr + v) : u32x4{0, 0, 0, 0};
+    }
+    if constexpr (GELU) {
+      static_assert(DUAL, "the fused activation belongs to fc2's dual-format input quantizer");
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int64_t v = (int64_t)c * kBlock + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) raw[c][k] = f2h2(gelu_tanh_fast(h2f(raw[c][k] & 0xFFFFu)), gelu_tanh_fast(h2f(raw[c][k] >> 16)));
+        if (a.gelu_out && v < vec_per_row) __builtin_nontemporal_store(raw[c], (u32x4*)((uint16_t*)a.gelu_out + row * cols) + v);
+      }
     }
     if (first) {
       if (TAB_ARG) {

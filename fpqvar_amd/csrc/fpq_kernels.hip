@@ -1376,13 +1376,14 @@ int launch_fast16_pair8(const void* x, void* out, int64_t rows, int neg_id, int 
 
 template <bool DUAL>
 int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, int neg_id, int pos_id,
-                        hipStream_t st, uint32_t* nan_flag = nullptr) {
+                        hipStream_t st, uint32_t* nan_flag = nullptr, bool gelu = false, void* gelu_out = nullptr) {
   const Lut16Host& h = lut16_host(neg_id, pos_id);
   Lut16Args args = h.args;
   args.nan_flag = nan_flag;
+  args.gelu_out = gelu_out;
   const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
   const int64_t vec_per_row = cols / 8;
-  if (vec_per_row <= 64 * 5 && !fpq_flag(OPT_FPQ_NO_WAVE_ROWS)) {
+  if (vec_per_row <= 64 * 5 && !fpq_flag(OPT_FPQ_NO_WAVE_ROWS) && !gelu) {
     // one wavefront per row: 4 rows per workgroup pass, enough workgroups to keep every CU busy while the
     // table staging stays amortised
     const int mc = (int)((vec_per_row + 63) / 64);
@@ -1434,6 +1435,15 @@ int launch_fast16_block(const void* x, void* out, int64_t rows, int64_t cols, in
                          (uint16_t*)out, rows, cols, rpb, args, h.tab);
     return check_launch();
   };
+  if constexpr (DUAL) {
+    if (gelu) {   // GELU in front of the quantizer (fpq_gelu_quant_rows_dual): one workgroup per row for every row length
+      if (maxc <= 1) return go(rows16_lut_block_kernel<true, 1, true, true>, rows16_lut_block_kernel<true, 1, false, true>);
+      if (maxc <= 2) return go(rows16_lut_block_kernel<true, 2, true, true>, rows16_lut_block_kernel<true, 2, false, true>);
+      if (maxc <= 4) return go(rows16_lut_block_kernel<true, 4, true, true>, rows16_lut_block_kernel<true, 4, false, true>);
+      if (maxc <= 5) return go(rows16_lut_block_kernel<true, 5, true, true>, rows16_lut_block_kernel<true, 5, false, true>);
+      return go(rows16_lut_block_kernel<true, 8, true, true>, rows16_lut_block_kernel<true, 8, false, true>);
+    }
+  }
   if (maxc <= 1) return go(rows16_lut_block_kernel<DUAL, 1, true>, rows16_lut_block_kernel<DUAL, 1, false>);
   if (maxc <= 2) return go(rows16_lut_block_kernel<DUAL, 2, true>, rows16_lut_block_kernel<DUAL, 2, false>);
   if (maxc <= 4) return go(rows16_lut_block_kernel<DUAL, 4, true>, rows16_lut_block_kernel<DUAL, 4, false>);
@@ -1896,15 +1906,23 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
 int fpq_gelu_quant_rows_dual(const void* x, void* out, void* gelu_out, int64_t rows, int64_t cols, int neg_table, int pos_table,
                              void* nan_flag, fpq_stream_t stream) {
   if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
-  if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_E2M1_NEG) return FPQ_ERR_TABLE;     // the FP4 dual pairs (small bucket tables)
-  if (pos_table != FPQ_E2M1_POS) return FPQ_ERR_TABLE;
-  if (cols != 128) return FPQ_ERR_SHAPE;
+  if (neg_table != FPQ_E1M2_NEG && neg_table != FPQ_INT_NEG && neg_table != FPQ_E2M1_NEG) return FPQ_ERR_TABLE;
+  if (pos_table != FPQ_E2M1_POS && pos_table != FPQ_E2M3_POS) return FPQ_ERR_TABLE;
+  // groups of 128 (rows inside a wavefront) or rows of at most 16384 elements (one workgroup per row: the per-token forms)
+  if (cols <= 0 || cols % 8 != 0 || cols > 8 * 8 * kBlock) return FPQ_ERR_SHAPE;
   if (rows == 0) return FPQ_OK;
   if (!x || !out) return FPQ_ERR_ARG;
   if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gelu_out) & 15) != 0 || ((uintptr_t)nan_flag & 7) != 0) return FPQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, (uint32_t*)nan_flag, nullptr, 1.0f, true, gelu_out))
-    return rc;
+  uint32_t* flag = (uint32_t*)nan_flag;
+  int rc;
+  if (cols != 128)
+    rc = launch_fast16_block<true>(x, out, rows, cols, neg_table, pos_table, st, flag, true, gelu_out);
+  else if ((1 << (16 - lut16_host(neg_table, pos_table).args.shift)) <= 1024)
+    rc = launch_fast16<true>(x, out, rows, cols, neg_table, pos_table, st, 1 << 20, flag, nullptr, 1.0f, true, gelu_out);
+  else   // int_neg / e2m3_pos: 2 x 1024 buckets to stage per workgroup - many tiles per workgroup, as fpq_quant_rows_dual
+    rc = launch_fast16<true, 4>(x, out, rows, cols, neg_table, pos_table, st, fpq_opt(OPT_FPQ_BIGTAB_CAP, 16384), flag, nullptr, 1.0f, true, gelu_out);
+  if (rc != FPQ_OK) return rc;
   if (!nan_flag) return FPQ_OK;
   hipLaunchKernelGGL(zero_if_flag_kernel, dim3(kFixupBlocks), dim3(kBlock), 0, st, (uint8_t*)out, rows * cols * 2, (uint32_t*)nan_flag);
   return check_launch();

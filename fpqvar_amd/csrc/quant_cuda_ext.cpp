@@ -443,10 +443,11 @@ std::tuple<at::Tensor, c10::optional<at::Tensor>> linear_fp4_gelu_dual(const at:
 }
 
 // `fc2.act_quant(act(y))` in one pass over the fp16 fc1 output y: ops.gelu_quant_rows_dual
-std::tuple<at::Tensor, c10::optional<at::Tensor>> gelu_quant_rows_dual(const at::Tensor& y, int64_t neg_id, int64_t pos_id, bool return_gelu) {
+std::tuple<at::Tensor, c10::optional<at::Tensor>> gelu_quant_rows_dual(const at::Tensor& y, int64_t neg_id, int64_t pos_id, int64_t cols, bool nan_rule,
+                                                                        bool return_gelu) {
   require_gpu(y, "gelu_quant_rows_dual");
-  TORCH_CHECK(y.scalar_type() == at::kHalf && y.dim() >= 1 && y.size(-1) % 128 == 0,
-              "gelu_quant_rows_dual: y must be float16 with a last dimension that is a multiple of 128");
+  TORCH_CHECK(y.scalar_type() == at::kHalf && cols > 0 && cols % 8 == 0 && y.numel() % cols == 0,
+              "gelu_quant_rows_dual: y must be float16 and hold whole rows of ", cols, " (a multiple of 8) elements");
   const at::Tensor yc = y.is_contiguous() ? y : y.contiguous();
   at::Tensor out = at::empty(y.sizes(), y.options());
   c10::optional<at::Tensor> h;
@@ -454,10 +455,11 @@ std::tuple<at::Tensor, c10::optional<at::Tensor>> gelu_quant_rows_dual(const at:
   if (yc.numel() == 0) return {out, h};
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(y.device());
   const fpq_stream_t st = current_stream(y);
-  at::Tensor scratch = nan_scratch(y, st);
-  const int status = fpq_gelu_quant_rows_dual(yc.data_ptr(), out.data_ptr(), h.has_value() ? h->data_ptr() : nullptr, yc.numel() / 128, 128, (int)neg_id,
-                                              (int)pos_id, scratch.data_ptr(), st);
-  if (status != 0) (void)hipMemsetAsync(scratch.data_ptr(), 0, 8, (hipStream_t)st);
+  at::Tensor scratch;
+  if (nan_rule) scratch = nan_scratch(y, st);
+  const int status = fpq_gelu_quant_rows_dual(yc.data_ptr(), out.data_ptr(), h.has_value() ? h->data_ptr() : nullptr, yc.numel() / cols, cols, (int)neg_id,
+                                              (int)pos_id, nan_rule ? scratch.data_ptr() : nullptr, st);
+  if (status != 0 && nan_rule) (void)hipMemsetAsync(scratch.data_ptr(), 0, 8, (hipStream_t)st);
   check(status, "fpq_gelu_quant_rows_dual");
   return {out, h};
 }
@@ -499,7 +501,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("bias") = py::none(), py::arg("gate") = py::none(), py::arg("residual") = py::none());
   m.def("linear_fp4_gelu_dual", &linear_fp4_gelu_dual, py::arg("a_codes"), py::arg("a_scales"), py::arg("w_codes"), py::arg("w_scales"),
         py::arg("bias") = py::none(), py::arg("return_gelu") = false);
-  m.def("gelu_quant_rows_dual", &gelu_quant_rows_dual, py::arg("y"), py::arg("neg_table_id"), py::arg("pos_table_id"), py::arg("return_gelu") = false);
+  m.def("gelu_quant_rows_dual", &gelu_quant_rows_dual, py::arg("y"), py::arg("neg_table_id"), py::arg("pos_table_id"), py::arg("cols") = 128,
+        py::arg("nan_rule") = true, py::arg("return_gelu") = false);
   m.def("fp6_quant_per_token_contig", &fp6_quant_per_token_contig, py::arg("x"), py::arg("n_bits"), py::arg("table_id"));
   m.def("fp6_quant_int_neg_e2m3_pos_per_token_contig", &fp6_quant_int_neg_e2m3_pos_per_token_contig, py::arg("x"), py::arg("n_bits"));
 }

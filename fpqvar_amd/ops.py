@@ -271,26 +271,31 @@ def quant_rows_dual(x: torch.Tensor, neg_table: str, pos_table: str, cols: int,
     return out
 
 
-def gelu_quant_rows_dual(y: torch.Tensor, neg_table: str = "e1m2_neg", pos_table: str = "e2m1_pos", return_gelu: bool = False):
-    """`quant_rows_dual(F.gelu(y, approximate="tanh"), neg, pos, 128, 1.0)` in ONE pass over y (fpq_gelu_quant_rows_dual): the
-    reference's `fc2.act_quant(act(fc1_output))` (tr/basic_var.py:120-121, tr/quant_utils.py:991) for an fp16 fc1 output whose
-    last dimension is a multiple of 128.  return_gelu: also the GELU values the quantizer saw (quantization bit-exact on those;
-    within one fp16 ulp of torch's GELU on every fp16 input)."""
+def gelu_quant_rows_dual(y: torch.Tensor, neg_table: str = "e1m2_neg", pos_table: str = "e2m1_pos", cols: int = 128,
+                         clipping_strength: Optional[float] = 1.0, return_gelu: bool = False):
+    """`quant_rows_dual(F.gelu(y, approximate="tanh"), neg, pos, cols, clipping_strength)` in ONE pass over y
+    (fpq_gelu_quant_rows_dual): the reference's `fc2.act_quant(act(fc1_output))` (tr/basic_var.py:120-121; the quantizer bound
+    at tr/quant_utils.py:991 - W4A4, groups of 128, strength 1.0 - or :930-931 - W6A6, INT-/E2M3+ per token, no clamp:
+    clipping_strength None, cols = the row length) for an fp16 fc1 output.  return_gelu: also the GELU values the quantizer saw
+    (quantization bit-exact on those; within one fp16 ulp of torch's GELU on every fp16 input)."""
+    if clipping_strength is not None and float(clipping_strength) != 1.0:
+        raise RuntimeError("gelu_quant_rows_dual: clipping_strength must be 1.0 (the FP4 pair's default) or None")
+    nan_rule = clipping_strength is not None
     if _native is not None:
-        out, h = _native.gelu_quant_rows_dual(y, TABLE_IDS[neg_table], TABLE_IDS[pos_table], return_gelu)
+        out, h = _native.gelu_quant_rows_dual(y, TABLE_IDS[neg_table], TABLE_IDS[pos_table], cols, nan_rule, return_gelu)
         return (out, h) if return_gelu else out
     require_gpu(y, "gelu_quant_rows_dual")
-    if y.dtype != torch.float16 or y.shape[-1] % 128 != 0:
-        raise RuntimeError(f"gelu_quant_rows_dual: y must be float16 with a last dimension that is a multiple of 128, got {y.dtype} {tuple(y.shape)}")
+    if y.dtype != torch.float16 or cols <= 0 or cols % 8 != 0 or y.numel() % cols != 0:
+        raise RuntimeError(f"gelu_quant_rows_dual: y must be float16 and hold whole rows of {cols} (a multiple of 8) elements, got {y.dtype} {tuple(y.shape)}")
     yc = _contig(y)
     out = torch.empty(y.shape, dtype=torch.float16, device=y.device)
     h = torch.empty(y.shape, dtype=torch.float16, device=y.device) if return_gelu else None
     if yc.numel():
         with device_guard(y.device):
-            flag_ptr = _nan_scratch(y.device).data_ptr()
-            status = lib().fpq_gelu_quant_rows_dual(yc.data_ptr(), out.data_ptr(), None if h is None else h.data_ptr(), yc.numel() // 128, 128,
+            flag_ptr = _nan_scratch(y.device).data_ptr() if nan_rule else None
+            status = lib().fpq_gelu_quant_rows_dual(yc.data_ptr(), out.data_ptr(), None if h is None else h.data_ptr(), yc.numel() // cols, cols,
                                                     TABLE_IDS[neg_table], TABLE_IDS[pos_table], flag_ptr, stream_ptr(y.device))
-            if status != 0:
+            if status != 0 and nan_rule:
                 _NAN_SCRATCH.clear()
             check(status, "fpq_gelu_quant_rows_dual")
     return (out, h) if return_gelu else out

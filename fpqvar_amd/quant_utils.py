@@ -144,6 +144,21 @@ def gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, n_bits, group_size=128):
     return ops.gelu_quant_rows_dual(y, "e1m2_neg", "e2m1_pos")
 
 
+def gelu_fp6_quant_int_neg_e2m3_pos_per_token_cuda(y, n_bits):
+    """`fp6_quant_int_neg_e2m3_pos_per_token_cuda(F.gelu(y, approximate="tanh"), n_bits)` - fc2's input in the W6A6 run
+    (run.sh:7; tr/quant_utils.py:614-646 bound at :930-931) - in one pass over the fc1 output (the layout rule of the
+    reference's `.view(-1)` applies: y must be viewable as rows of its last dimension)."""
+    assert n_bits == 6
+    _require_viewable(y, dual=True)
+    return ops.gelu_quant_rows_dual(y, "int_neg", "e2m3_pos", y.shape[-1], None)
+
+
+def gelu_fp6_quant_int_neg_e2m3_pos_per_group_cuda(y, n_bits, group_size=128):
+    """The per-group twin (tr/quant_utils.py:577-611) with the GELU in front, one pass."""
+    assert n_bits == 6 and group_size == 128
+    return ops.gelu_quant_rows_dual(y, "int_neg", "e2m3_pos", 128, None)
+
+
 def quantize_to_nearest_grid(x, quant_grid):
     """tr/quant_utils.py:209-230 in one launch (no [N, K] distance tensor): quant_grid[argmin |x - quant_grid|]."""
     return ops.quant_nearest_argmin(x, quant_grid)

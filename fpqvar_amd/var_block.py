@@ -117,7 +117,7 @@ class GenerationBatch:
         self.max_len = sum(p * p for p in self.patch_nums)
         self.W6 = config == "w6a6"
         self.fused_fc1 = fused_fc1 and not self.W6 and hasattr(gemm, "linear_fp4_gelu_dual")
-        self.fused_gelu_quant = fused_fc1 and not self.W6      # path F: GELU + fc2's input quantizer in one pass over the fc1 output
+        self.fused_gelu_quant = fused_fc1                       # path F: GELU + fc2's input quantizer in one pass over the fc1 output
         C, HID, B = self.C, self.HID, self.B
         g = torch.Generator(device=dev).manual_seed(seed)
         self.gen = g
@@ -162,6 +162,14 @@ class GenerationBatch:
 
     def f_fc2(self, t):
         return qu.fp6_quant_int_neg_e2m3_pos_per_token_cuda(t, 6) if self.W6 else qu.fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(t, 4, 128)
+
+    def act_then_fc2_quant(self, y):
+        """`fc2.act_quant(act(y))` for an fc1 output y: one pass (GELU in front of the dual quantizer) or GELU, then the quantizer."""
+        if not self.fused_gelu_quant:
+            return self.f_fc2(Fn.gelu(y, approximate="tanh"))
+        if self.W6:
+            return qu.gelu_fp6_quant_int_neg_e2m3_pos_per_token_cuda(y, 6)
+        return qu.gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, 4, 128)
 
     def f_producer(self, t, sc, sh, sm):
         if self.W6:
@@ -231,13 +239,11 @@ class GenerationBatch:
             else:
                 x = self.q_proj(a.view(B * L, C), g1, x).view(B, L, C)
             if path == "F":
-                y = Fn.linear(self.f_producer(x, sc2, sh2, self.s_fc1), self.wq["fc1"])
-                hq = qu.gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, 4, 128) if self.fused_gelu_quant else \
-                    self.f_fc2(Fn.gelu(y, approximate="tanh"))
+                hq = self.act_then_fc2_quant(Fn.linear(self.f_producer(x, sc2, sh2, self.s_fc1), self.wq["fc1"]))
             elif self.fused_fc1:
                 hq = self.q_fc1_gelu_dual(x, sc2, sh2).view(B, L, HID)
             else:
-                hq = self.f_fc2(Fn.gelu(self.q_producer_linear(x, sc2, sh2, self.s_fc1, "fc1").view(B, L, HID), approximate="tanh"))
+                hq = self.act_then_fc2_quant(self.q_producer_linear(x, sc2, sh2, self.s_fc1, "fc1").view(B, L, HID))
             x = ops.gate_residual(Fn.linear(hq, self.wq["fc2"]), g2, x)
         return x
 

@@ -192,10 +192,13 @@ int fpq_quant_rows_dual(const void* x, void* out, int64_t rows, int64_t cols, in
                         float clip_strength, void* nan_flag, fpq_stream_t stream);
 
 /* `fc2.act_quant(act(y))` of the reference's FFN in ONE pass over y (tr/basic_var.py:120-121: act = GELU(approximate="tanh");
- * tr/quant_utils.py:991: fc2's input quantizer): out = fpq_quant_rows_dual(half(gelu_tanh(float(y)))) for fp16 rows of 128 (groups),
- * clipping strength 1.0, neg_table in {E1M2_NEG, E2M1_NEG}, pos_table = E2M1_POS.  gelu_out: NULL, or fp16 [rows, 128] receiving
- * the GELU values the quantizer saw (the quantization is bit-exact on those; they sit within one fp16 ulp of torch's GELU on
- * every fp16 input).  nan_flag as in fpq_quant_rows_dual.  The same fused tail inside the fc1 GEMM: fpq_gemm_fp4_gelu_dual. */
+ * fc2's input quantizer is bound at tr/quant_utils.py:991 (W4A4: fp_quant_e1m2_neg_e2m1_pos_per_group_cuda) and :930-931 (W6A6:
+ * fp6_quant_int_neg_e2m3_pos_per_token_cuda)): out = fpq_quant_rows_dual(half(gelu_tanh(float(y)))) on fp16 rows of `cols`
+ * elements - 128 (per group) or the token's row (per token, cols % 8 == 0, <= 16384) - for any dual table pair.  nan_flag: the
+ * FP4 pair's global-clamp rule at clipping strength 1.0 (as in fpq_quant_rows_dual), NULL for the FP6 pairs (the reference
+ * does not clamp there).  gelu_out: NULL, or fp16 [rows, cols] receiving the GELU values the quantizer saw (the quantization is
+ * bit-exact on those; they sit within one fp16 ulp of torch's GELU on every fp16 input).  The same fused tail inside the fc1
+ * GEMM: fpq_gemm_fp4_gelu_dual. */
 int fpq_gelu_quant_rows_dual(const void* y, void* out, void* gelu_out, int64_t rows, int64_t cols, int neg_table, int pos_table,
                              void* nan_flag, fpq_stream_t stream);
 

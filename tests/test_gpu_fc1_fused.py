@@ -238,3 +238,30 @@ def test_gelu_quant_rows_dual_every_fp16_input_and_nan_rule(dev):
         ops.gelu_quant_rows_dual(every.float())
     with pytest.raises(RuntimeError):
         ops.gelu_quant_rows_dual(every[:100])
+
+
+@pytest.mark.parametrize("cols,rows", [(7680, 300), (9216, 37), (1920, 64), (128, 4000), (1000, 9)])
+def test_gelu_quant_rows_dual_fp6_pairs(dev, cols, rows):
+    """The W6A6 run's fc2 input (INT-/E2M3+, tr/quant_utils.py:577-646) with the GELU in front, one pass: per token (one
+    workgroup per row of 7680 / 9216 / 1920 / a ragged 1000 elements) and per group of 128 - GELU within one ulp of torch's,
+    quantization bit-exact on the emitted values against the plain quantizer and the oracle; no NaN rule (the reference does
+    not clamp the FP6 pairs): a NaN poisons its own row only."""
+    from fpqvar_amd import ops, quant_utils as qu
+    g = torch.Generator().manual_seed(cols + rows)
+    y = (torch.randn(rows, cols, generator=g) * 1.5).half().to(dev)
+    q, h = ops.gelu_quant_rows_dual(y, "int_neg", "e2m3_pos", cols, None, return_gelu=True)
+    d = ulp_diff(h, Fn.gelu(y, approximate="tanh"))
+    assert int(d.max()) <= 1
+    assert_bits_equal(q, ops.quant_rows_dual(h, "int_neg", "e2m3_pos", cols, None), "one pass vs GELU values + plain quantizer")
+    want = orc.dual_per_group_kernel_sem(h.cpu().reshape(-1, cols), "int_neg", "e2m3_pos", cols, None).view(rows, cols) if cols == 128 else \
+        orc.dual_per_token_kernel_sem(h.cpu(), "int_neg", "e2m3_pos")
+    assert_bits_equal(q.cpu(), want, "one pass vs oracle")
+    if cols == 128:
+        assert_bits_equal(qu.gelu_fp6_quant_int_neg_e2m3_pos_per_group_cuda(y, 6, 128), q, "quant_utils per-group name")
+    elif cols % 8 == 0:
+        assert_bits_equal(qu.gelu_fp6_quant_int_neg_e2m3_pos_per_token_cuda(y, 6), q, "quant_utils per-token name")
+    yn = y.clone()
+    yn[1, 5] = float("nan")
+    qn = ops.gelu_quant_rows_dual(yn, "int_neg", "e2m3_pos", cols, None)
+    assert_bits_equal(qn[2:], q[2:], "rows after the NaN row are untouched")
+    assert_bits_equal(qn[0], q[0], "the row before it too")
