@@ -859,7 +859,9 @@ def generation(plat, dist, world, rank, stage):
     the transformer part of one generation batch of VAR-d30 256x256 (50 images with CFG) and VAR-d36 512x512 (10 images),
     W4A4 + FP6 KV cache, random weights, one hipGraph per scale step, one eager warm-up batch + best of 3 replays
     (fpqvar_amd/var_block.py).  Paths: R = the reference's op sequence on this GPU, F = fused fake-quant launches around fp16
-    Linears, Q = operands straight into the FP4 matrix cores.  The loop is independent per (class, seed) - "replicas only",
+    Linears, Q = operands straight into the FP4 matrix cores; torch's OWN GEMMs (fc2 on every path, every Linear of R / F) with
+    TunableOp selections recorded once for these shapes (var_block.tuned_torch_gemms; named in the records; the same on all
+    three paths, no tuning at run time).  The loop is independent per (class, seed) - "replicas only",
     no collective in the model: every rank runs its own replica, the line carries the slowest rank's time
     and images of ALL ranks / that time (fpqvar_amd.generation.aggregate_throughput: one SUM and one MAX per record).
     Weak scaling.  Secondary measurement; every failure is reported in the record, never swallowed."""
@@ -883,7 +885,7 @@ def generation(plat, dist, world, rank, stage):
             t = plat.torch.tensor([float(ranks_ok)], dtype=plat.torch.float64, device=plat.dev if plat.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             ranks_ok = int(t.item())
-        line = {k: rec[k] for k in ("model", "path", "config", "what", "images_per_batch", "clock", "warmup_eager_ms") if k in rec}
+        line = {k: rec[k] for k in ("model", "path", "config", "what", "images_per_batch", "clock", "warmup_eager_ms", "torch_gemms") if k in rec}
         line.update({"model": model, "path": path, "replicas": world, "replicas_ok": ranks_ok})
         if ranks_ok == world and rate > 0:
             line["ms_per_batch"] = round(total / rate * 1e3, 2)               # the slowest replica's batch (total / rate = its seconds)
