@@ -12,7 +12,9 @@ Three ways to run everything around the attention core:
      (tr/basic_var.py:263,266), fp16 Linears on de-quantized tensors (tr/quant_utils.py:767), the whole KV cache
      re-quantized at every step (tr/basic_var.py:186-209)
   F  one launch per quantizer, the fused LayerNorm / modulate / smooth / rotate / quant producer, incremental KV cache, GELU
-     fused in front of fc2's input quantizer; the Linears stay fp16 GEMMs on fake-quantized values (the reference's numerics)
+     fused in front of fc2's input quantizer, attention by fpq_attention_blhc off the cache views (the reference calls
+     flash_attn_func there, tr/basic_var.py:211; rounds 1 - 4 timed this path with torch's SDPA: sdpa_in_f=True); the Linears
+     stay fp16 GEMMs on fake-quantized values (the reference's numerics)
   Q  F with mat_qkv / proj / fc1 on the FP4 (W6A6: FP6) matrix cores - the producers emit the GEMM operands, proj applies
      the block's gate and residual in its epilogue, fc1 applies GELU and fc2's dual-format input quantizer in its epilogue
      (gemm.linear_fp4_gelu_dual; W4A4 only) - and attention by fpq_attention_blhc straight off the cache views
@@ -106,7 +108,7 @@ class GenerationBatch:
     """Weights, modulation vectors and the step function of one model-shaped batch on `device`."""
 
     def __init__(self, model: str = "d30-256", config: str = "w4a4", depth: Optional[int] = None,
-                 batch_rows: Optional[int] = None, device=None, seed: int = 0, fused_fc1: bool = True):
+                 batch_rows: Optional[int] = None, device=None, seed: int = 0, fused_fc1: bool = True, sdpa_in_f: bool = False):
         assert model in MODELS and config in ("w4a4", "w6a6")
         self.model, self.config = model, config
         heads, self.patch_nums, rows = MODELS[model]
@@ -117,6 +119,7 @@ class GenerationBatch:
         self.max_len = sum(p * p for p in self.patch_nums)
         self.W6 = config == "w6a6"
         self.fused_fc1 = fused_fc1 and not self.W6 and hasattr(gemm, "linear_fp4_gelu_dual")
+        self.sdpa_in_f = sdpa_in_f                              # path F with torch's SDPA instead of fpq_attention_blhc (rounds 1 - 4 timed it that way)
         self.fused_gelu_quant = fused_fc1                       # path F: GELU + fc2's input quantizer in one pass over the fc1 output
         C, HID, B = self.C, self.HID, self.B
         g = torch.Generator(device=dev).manual_seed(seed)
@@ -233,7 +236,7 @@ class GenerationBatch:
                 qkv = self.q_producer_linear(x, sc1, sh1, self.s_qkv, "qkv")
             q, k, v = qkv.view(B, L, 3, H, hd).unbind(2)
             kc, vc = caches[b].append(k, v)
-            a = self.attend(q, kc, vc) if path == "F" else ops.attention_blhc(q, kc, vc, hd ** -0.5).view(B, L, C)
+            a = self.attend(q, kc, vc) if (path == "F" and self.sdpa_in_f) else ops.attention_blhc(q, kc, vc, hd ** -0.5).view(B, L, C)
             if path == "F":
                 x = ops.gate_residual(Fn.linear(self.f_act(a), self.wq["proj"]), g1, x)
             else:

@@ -26,11 +26,12 @@ def main():
                     help="w4a4: run.sh line 4 (per-group fp_e2, fc2 dual FP4); w6a6: run.sh line 10 (per-token / per-channel fp6_e2m3, fc2 dual FP6)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--unfused-fc1", action="store_true", help="Q path: GEMM, GELU and the dual quantizer as three launches")
+    ap.add_argument("--sdpa-in-f", action="store_true", help="path F with torch's SDPA instead of fpq_attention_blhc (as rounds 1 - 4 timed it)")
     ap.add_argument("--tuned-gemms", action="store_true", help="torch's own GEMMs with the recorded TunableOp selections (var_block.tuned_torch_gemms)")
     args = ap.parse_args()
     torch.manual_seed(0)
     gb = var_block.GenerationBatch(args.model, args.config, depth=args.depth, batch_rows=args.batch, device="cuda:0",
-                                   fused_fc1=not args.unfused_fc1)
+                                   fused_fc1=not args.unfused_fc1, sdpa_in_f=args.sdpa_in_f)
     res = {"workload": gb.describe(), "depth": gb.depth, "batch_rows": gb.B, "fc1_epilogue_fused": gb.fused_fc1,
            "library": _lib.build_tag()}
     paths = args.paths.split(",")
