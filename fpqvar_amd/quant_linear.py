@@ -72,6 +72,29 @@ def _quantize_weight(w, weight_quant, weight_fp_quant, weight_fp_type, w_bit):
     raise ValueError(f"Invalid weight_quant: {weight_quant}")
 
 
+class GeluThenFc2Quant(nn.Module):
+    """Stands in for an FFN's `act` (GELU, approximate="tanh") when fc2's dual-format input quantizer is fused behind it:
+    `forward(y)` = `fc2.act_quant(F.gelu(y, approximate="tanh"))` in ONE pass over the fc1 output (quant_utils.gelu_*), for the
+    FFN.forward of the reference (`self.fc2(self.act(self.fc1(x)))`, tr/basic_var.py:120-121) - fc2's own input quantizer is
+    switched off by quantize_VAR(..., fuse_ffn=True)."""
+    FUSED = {("per_group", "fp_e1m2_neg_e2m1_pos"): lambda y, bits: qu.gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, bits, _GROUP),
+             ("per_group", "fp4_afpq"): lambda y, bits: qu.gelu_fp4_afpq_per_group_cuda(y, bits, _GROUP),
+             ("per_group", "fp6_int_neg_e2m3_pos"): lambda y, bits: qu.gelu_fp6_quant_int_neg_e2m3_pos_per_group_cuda(y, bits, _GROUP),
+             ("per_token", "fp6_int_neg_e2m3_pos"): lambda y, bits: qu.gelu_fp6_quant_int_neg_e2m3_pos_per_token_cuda(y, bits)}
+
+    def __init__(self, act_quant: str, fc2_fp_type: str, a_bit: int):
+        super().__init__()
+        self.act_quant, self.fc2_fp_type, self.a_bit = act_quant, fc2_fp_type, a_bit
+        self.fn = self.FUSED[(act_quant, fc2_fp_type)]
+
+    @torch.no_grad()
+    def forward(self, y):
+        return self.fn(y.to(torch.float16), self.a_bit)
+
+    def extra_repr(self):
+        return f"GELU(tanh) + {self.fc2_fp_type} {self.act_quant} (one pass)"
+
+
 class QuantizedLinear(nn.Module):
     _FC2 = False
 
@@ -160,10 +183,12 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
     fc1 / mat_qkv / proj become ``gemm.FP4Linear`` - same quantization decisions, product on the FP4 matrix cores
     instead of an fp16 GEMM on de-quantized tensors (fc2 keeps its dual-format fake quantization).
 
-    ``fuse_ffn`` (additive, with ``real_fp4`` and ``fc2_fp_type == "fp_e1m2_neg_e2m1_pos"``): an FFN whose ``act`` is
-    GELU(tanh) gets ``gemm.FP4LinearGeluDual`` as fc1 - the GELU and fc2's dual-format input quantizer run in the fc1 GEMM's
-    epilogue - an identity as ``act`` and an fc2 that multiplies the already quantized input; the FFN's own
-    ``forward`` (``fc2(act(fc1(x)))``, tr/basic_var.py:120-121) stays as it is and computes the same thing in two launches fewer."""
+    ``fuse_ffn`` (additive; needs an FFN whose ``act`` is GELU(tanh) and a dual-format ``fc2_fp_type``): fc2's input quantizer
+    moves in front of fc2 - the FFN's own ``forward`` (``fc2(act(fc1(x)))``, tr/basic_var.py:120-121) stays as it is.
+    With ``real_fp4`` and ``fp_e1m2_neg_e2m1_pos``: fc1 becomes ``gemm.FP4LinearGeluDual`` (GELU and the quantizer in the fc1
+    GEMM's epilogue) and ``act`` an identity; otherwise (the fake-quant default, ``real_fp6``, the FP6 / AFPQ dual pairs) ``act``
+    becomes ``GeluThenFc2Quant`` - GELU and the quantizer in one pass over the fc1 output.  fc2 multiplies its already
+    quantized input either way."""
     fp4_ok = (real_fp4 and weight_quant == "per_group" and act_quant == "per_group" and w_bit == 4 and a_bit == 4
               and activation_fp_quant and weight_fp_quant and act_fp_type == "fp_e2" and weight_fp_type == "fp_e2")
     if real_fp4 and not fp4_ok:
@@ -194,14 +219,17 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
         qkv, proj = getattr(m, "mat_qkv", None), getattr(m, "proj", None)
         if isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear):
             act = getattr(m, "act", None)
-            fuse = (fuse_ffn and fp4_ok and fc2_fp_type == "fp_e1m2_neg_e2m1_pos" and isinstance(act, nn.GELU)
-                    and getattr(act, "approximate", "none") == "tanh" and fc1.in_features % 128 == 0 and fc1.out_features % 128 == 0)
-            if fuse_ffn and not fuse:
-                raise ValueError("fuse_ffn needs real_fp4, fc2_fp_type='fp_e1m2_neg_e2m1_pos', an FFN with act = GELU(approximate='tanh') "
-                                 "and widths that are multiples of 128")
+            gelu_tanh = isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "tanh"
+            in_gemm = (fuse_ffn and gelu_tanh and fp4_ok and fc2_fp_type == "fp_e1m2_neg_e2m1_pos"
+                       and fc1.in_features % 128 == 0 and fc1.out_features % 128 == 0)
+            one_pass = (fuse_ffn and gelu_tanh and not in_gemm and activation_fp_quant and (act_quant, fc2_fp_type) in GeluThenFc2Quant.FUSED
+                        and fc1.out_features % (128 if act_quant == "per_group" else 8) == 0)
+            if fuse_ffn and not (in_gemm or one_pass):
+                raise ValueError("fuse_ffn needs an FFN with act = GELU(approximate='tanh') and a dual-format fc2_fp_type "
+                                 "(fp_e1m2_neg_e2m1_pos / fp4_afpq per group, fp6_int_neg_e2m3_pos per group or per token)")
             m.fc2 = QuantizedLinear_fc2.from_float(fc2, act_quant_sym=False, fc2_act_log2_quant=fc2_act_log2_quant,
                                                    act_fp_type=fc2_fp_type, **common)
-            if fuse:
+            if in_gemm:
                 from .gemm import FP4LinearGeluDual
                 m.fc1 = FP4LinearGeluDual.from_float(fc1)
                 m.act = nn.Identity()
@@ -209,6 +237,10 @@ def quantize_VAR(model, weight_quant=None, act_quant=None, quantize_bmm_input=Fa
                 m.fc2.act_quant_name = "in fc1's epilogue"
             else:
                 m.fc1 = plain(fc1, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
+                if one_pass:
+                    m.act = GeluThenFc2Quant(act_quant, fc2_fp_type, a_bit)
+                    m.fc2.act_quant = lambda t: t                  # ... from the activation module in front of it
+                    m.fc2.act_quant_name = "behind the GELU (one pass)"
         elif isinstance(qkv, nn.Linear) and isinstance(proj, nn.Linear):
             m.mat_qkv = plain(qkv, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)
             m.proj = plain(proj, act_quant_sym=act_quant_sym, act_fp_type=act_fp_type, **common)

@@ -144,6 +144,13 @@ def gelu_fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(y, n_bits, group_size=128):
     return ops.gelu_quant_rows_dual(y, "e1m2_neg", "e2m1_pos")
 
 
+def gelu_fp4_afpq_per_group_cuda(y, n_bits, group_size=128):
+    """`fp4_afpq_per_group_cuda(F.gelu(y, approximate="tanh"), n_bits, 128)` (models_fp_quant/quant_utils.py:498-535 behind the
+    FFN's activation) in one pass."""
+    assert n_bits == 4 and group_size == 128
+    return ops.gelu_quant_rows_dual(y, "e2m1_neg", "e2m1_pos")
+
+
 def gelu_fp6_quant_int_neg_e2m3_pos_per_token_cuda(y, n_bits):
     """`fp6_quant_int_neg_e2m3_pos_per_token_cuda(F.gelu(y, approximate="tanh"), n_bits)` - fc2's input in the W6A6 run
     (run.sh:7; tr/quant_utils.py:614-646 bound at :930-931) - in one pass over the fc1 output (the layout rule of the

@@ -194,9 +194,21 @@ def test_quantize_var_fuses_the_ffn(dev):
     ya, yb = plain.ffn(x).float(), fused.ffn(x).float()
     assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
     with pytest.raises(ValueError):
-        ql.quantize_VAR(copy.deepcopy(base), fuse_ffn=True, **cfg)                        # needs real_fp4
-    with pytest.raises(ValueError):
-        ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, fuse_ffn=True, **{**cfg, "fc2_fp_type": "fp_e2"})
+        ql.quantize_VAR(copy.deepcopy(base), real_fp4=True, fuse_ffn=True, **{**cfg, "fc2_fp_type": "fp_e2"})   # not a dual format
+    # without real_fp4 (the reference's fake-quant numerics), with the FP6 run's configuration, and with real_fp6: the activation
+    # module does GELU + fc2's input quantizer in one pass, fc2 multiplies what it gets
+    cfg6 = dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True, activation_fp_quant=True,
+                weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3", fc2_fp_type="fp6_int_neg_e2m3_pos")
+    for c, extra in ((cfg, {}), (cfg6, {}), (cfg6, {"real_fp6": True}), ({**cfg, "fc2_fp_type": "fp4_afpq"}, {})):
+        ref = ql.quantize_VAR(copy.deepcopy(base), **extra, **c).half()
+        one = ql.quantize_VAR(copy.deepcopy(base), fuse_ffn=True, **extra, **c).half()
+        assert isinstance(one.ffn.act, ql.GeluThenFc2Quant) and "one pass" in repr(one.ffn.act) and "one pass" in repr(one.ffn.fc2)
+        assert type(one.ffn.fc1) is type(ref.ffn.fc1)
+        y1 = ref.ffn.fc1(x)
+        want, got = ref.ffn.fc2.act_quant(ref.ffn.act(y1)), one.ffn.act(one.ffn.fc1(x))
+        assert float((want.view(torch.int16) == got.view(torch.int16)).float().mean()) >= 0.999, (c["fc2_fp_type"], extra)
+        ya, yb = ref.ffn(x).float(), one.ffn(x).float()
+        assert float((ya - yb).abs().max()) <= 2e-2 * float(ya.abs().max()) + 1e-3
 
 
 @pytest.mark.parametrize("shape", [(300, 7680), (1, 128), (5, 37, 1024), (16900, 7680)])
