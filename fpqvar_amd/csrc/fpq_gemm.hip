@@ -188,6 +188,13 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   return check_launch();
 }
 
+#ifdef FPQ_GEMM6_STAMPS
+// diagnostic builds only: where the FP6 GEMM's wavefronts put their per-phase stamp sums ([wavefronts][8] uint64, zeroed by the caller)
+int fpq_debug_gemm6_stamp_buffer(void* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm6_stamps), &device_buffer, sizeof(void*)) == hipSuccess ? FPQ_OK : FPQ_ERR_LAUNCH;
+}
+#endif
+
 // fc1 with GELU and fc2's dual-format input quantizer in the GEMM's epilogue (fpq_gemm_fp4.h, GemmFc1)
 int fpq_gemm_fp4_gelu_dual(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
                            int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,

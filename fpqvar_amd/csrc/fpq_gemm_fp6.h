@@ -22,6 +22,24 @@ FPQ_NOPK __device__ __forceinline__ int fp6_rot(int r) { return (r >> 3) & 1; }
 typedef const volatile __attribute__((address_space(3))) u32x2* fpq_lds_v64_ptr;
 #define FPQ_LDS_READ64(ptr) (*(fpq_lds_v64_ptr)(const __attribute__((address_space(3))) void*)(ptr))
 
+// -DFPQ_GEMM6_STAMPS: diagnostic build (tools/build_variant.sh --gemm stamps6 -DFPQ_GEMM6_STAMPS, tools/gemm6_stamps.py): s_memtime
+// stamps between the phases of a K step, summed per wavefront in scalar registers and written once at the end to a buffer of
+// their own (fpq_debug_gemm6_stamp_buffer; no output value depends on them): where a wavefront's step time goes.  Each stamp
+// waits for the scalar-memory counter, which the LDS reads share: read the SHARES.  No stamp executes in a regular build.
+#ifdef FPQ_GEMM6_STAMPS
+__device__ unsigned long long* g_gemm6_stamps;   // [wavefronts][8]: wait for the stage, barrier, LDS-DMA issue, fragments + MFMAs, prologue, epilogue, steps
+#define FPQ_ST6(k)                                                   \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    st6_sum[k] += t_ - st6_last;                                     \
+    st6_last = t_;                                                   \
+  } while (0)
+#else
+#define FPQ_ST6(k) do { } while (0)
+#endif
+
 template <typename Tsa, typename Tsw, int MT, int NT>
 __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const uint8_t* __restrict__ A,
                                                                        const Tsa* __restrict__ sa,
@@ -45,6 +63,10 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
   const int col_blk = xcd * cpx + local % cpx, row_blk = local / cpx;
   if (col_blk >= n_col || row_blk >= n_row) return;   // uniform over the workgroup
   const int t0 = row_blk * BM, o0 = col_blk * BN;
+#ifdef FPQ_GEMM6_STAMPS
+  unsigned long long st6_sum[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long st6_last = __builtin_amdgcn_s_memtime();
+#endif
 
   // LDS-DMA sources: scalar base per operand + 32-bit lane offset, in assembly with explicit waits (as in gemm_fp4_glds_kernel)
   const uint8_t* const gbase[2] = {A + (int64_t)t0 * row_bytes, W + (int64_t)o0 * row_bytes};
@@ -102,11 +124,15 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
   // with scalar base + lane offset in assembly (round 4) the burst is the faster one: 0.627 interleaved, 0.603 burst.
   // Also measured: register staging (global_load + ds_write) 0.85 - 0.88, a three-stage ring with counted vmcnt 0.92,
   // requesting tile row m + 1's fragment before the MFMAs of row m (no gain: the SIMD's second wavefront covers it).
+  FPQ_ST6(4);
   for (int s = 0; s < steps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler does not see the LDS-DMA loads
+    FPQ_ST6(0);
     FPQ_SYNC();   // stage s has landed; the other buffer's readers are done
+    FPQ_ST6(1);
     const uint8_t* st = smem + (s & 1) * STAGE;
     if (s + 1 < steps) { FPQ_GLDS6_ISSUE(s + 1, (s + 1) & 1); }
+    FPQ_ST6(2);
     v8i_t bf[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -128,10 +154,21 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
         if ((m * NT + n) % 3 == 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    FPQ_ST6(3);
   }
 #undef FPQ_GLDS6_ISSUE
 #undef FPQ_GLDS6_ONE
   FPQ_GEMM_ROWS_EPILOGUE();
+#ifdef FPQ_GEMM6_STAMPS
+  FPQ_ST6(5);
+  if (lane == 0 && g_gemm6_stamps) {
+    unsigned long long* dst = g_gemm6_stamps + ((int64_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[k] = st6_sum[k];
+    dst[6] = (unsigned long long)steps;
+    dst[7] = 1;
+  }
+#endif
 }
 
 template <int MT, int NT>
