@@ -47,6 +47,37 @@ struct GemmEpi {
 typedef _Float16 fpq_h2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 fpq_h4_t __attribute__((ext_vector_type(4)));
 
+// The four 8-byte stores of a lane (rows t_first .. +3, outputs o .. o+3), or with -DFPQ_GEMM_WIDE_STORES two 16-byte ones: lanes
+// q and q ^ 1 hold neighbouring outputs of the same four rows; the even lane trades its rows 2, 3 for the odd lane's rows 0, 1
+// (one DPP quad_perm [1,0,3,2] per dword) and each then owns eight consecutive outputs of two rows.  outs % 8 == 0 and 4q % 8 == 0
+// on the even lane: both 16-byte pieces are inside the row or both outside; `out` is 16-byte aligned (checked on the host).
+#ifdef FPQ_GEMM_WIDE_STORES
+#define FPQ_GEMM_ROWS_STORE(y_, t_first_, tc_, o_, oc_)                                                             \
+  do {                                                                                                              \
+    const bool odd_ = (lane & 1) != 0;                                                                              \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                              \
+      const u32x2 own_lo_ = __builtin_bit_cast(u32x2, (y_)[j_]), own_hi_ = __builtin_bit_cast(u32x2, (y_)[2 + j_]); \
+      const u32x2 send_ = odd_ ? own_lo_ : own_hi_;                                                                 \
+      u32x2 recv_;                                                                                                  \
+      recv_[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send_[0], 0xB1, 0xF, 0xF, false);                    \
+      recv_[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send_[1], 0xB1, 0xF, 0xF, false);                    \
+      const u32x2 first_ = odd_ ? recv_ : own_lo_, second_ = odd_ ? own_hi_ : recv_;                                \
+      const u32x4 w_ = u32x4{first_[0], first_[1], second_[0], second_[1]};                                         \
+      const int r_ = (odd_ ? 2 : 0) + j_;                                                                           \
+      const int trow_ = odd_ ? (tc_)[2 + j_] : (tc_)[j_];                                                           \
+      if ((t_first_) + r_ < T && (o_) < O)                                                                          \
+        __builtin_nontemporal_store(w_, (u32x4*)(out + (int64_t)trow_ * O + (oc_) - (odd_ ? 4 : 0)));               \
+    }                                                                                                               \
+  } while (0)
+#else
+#define FPQ_GEMM_ROWS_STORE(y_, t_first_, tc_, o_, oc_)                                                             \
+  do {                                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                \
+        if ((t_first_) + i_ < T && (o_) < O)                                                                        \
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x2, (y_)[i_]), (u32x2*)(out + (int64_t)(tc_)[i_] * O + (oc_))); \
+  } while (0)
+#endif
+
 // (macros, not functions: the kernels carry different target attributes and a callee is only inlined into a kernel
 // with the same ones)
 #define FPQ_GEMM_EPI_VEC(y, e, t, o, O)                                                                  \
@@ -599,14 +630,16 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int r_first = wm * WROWS + m * 16 + 4 * (lane >> 4);
+      u32x2 q[4];
+      int tq[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const u32x4 sc = rsc[r_first + i];
-        const uint32_t q0 = quant_pair16_dual(hw[m][i][0], lut, xe.a.shift, u2f(sc[0]), sc[2], u2f(sc[1]), sc[3]);
-        const uint32_t q1 = quant_pair16_dual(hw[m][i][1], lut, xe.a.shift, u2f(sc[0]), sc[2], u2f(sc[1]), sc[3]);
-        if (t0 + r_first + i < T && o < O)
-          __builtin_nontemporal_store(u32x2{q0, q1}, (u32x2*)(out + (int64_t)(t0 + r_first + i) * O + oc));
+        q[i][0] = quant_pair16_dual(hw[m][i][0], lut, xe.a.shift, u2f(sc[0]), sc[2], u2f(sc[1]), sc[3]);
+        q[i][1] = quant_pair16_dual(hw[m][i][1], lut, xe.a.shift, u2f(sc[0]), sc[2], u2f(sc[1]), sc[3]);
+        tq[i] = t0 + r_first + i;
       }
+      FPQ_GEMM_ROWS_STORE(q, t0 + r_first, tq, o, oc);
     }
     return;
   }
@@ -652,10 +685,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = rs[i] + y[i];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      // (non-temporal: a round of tiles writes as much as an XCD's L2 holds - the operands should stay there; +1-2 %)
-      if (t_first + i < T && o < O) __builtin_nontemporal_store(y[i], (fpq_h4_t*)(out + (int64_t)tc[i] * O + oc));
+    // (non-temporal: a round of tiles writes as much as an XCD's L2 holds - the operands should stay there; +1-2 %)
+    FPQ_GEMM_ROWS_STORE(y, t_first, tc, o, oc);
   }
 }
 

@@ -79,8 +79,7 @@
         _Pragma("unroll") for (int i = 0; i < 4; ++i) r_[i] = *(const fpq_h4_t*)(epi.resid + (int64_t)tc_[i] * O + oc_); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) y_[i] = r_[i] + y_[i];                                        \
       }                                                                                                             \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
-          if (t_first_ + i < T && o_ < O) __builtin_nontemporal_store(y_[i], (fpq_h4_t*)(out + (int64_t)tc_[i] * O + oc_)); \
+      FPQ_GEMM_ROWS_STORE(y_, t_first_, tc_, o_, oc_);                                                              \
     }                                                                                                               \
   } while (0)
 
