@@ -112,6 +112,25 @@ _SIGS = {
                                        _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_gemm_fp4_gelu_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                            _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_gemm_fp4_mx_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                       _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_gemm_fp4_gelu_dual_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                              _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_gemm_fp6_rows_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                         _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_quant_rows_codes_mx_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p]),
+    "fpq_rotate_quant_rows_codes_mx_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                                      _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_void_p]),
+    "fpq_adaln_rotate_quant_rows_codes_mx_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                                            _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
+                                                            _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_void_p]),
+    "fpq_quant_rows_codes_fp6_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                                _c.c_int, _c.c_void_p]),
+    "fpq_adaln_rotate_quant_token_rows_codes_fp6_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                                                   _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
+                                                                   _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int,
+                                                                   _c.c_void_p]),
+    "fpq_codes_to_kmajor": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
     "fpq_gemm_fp8_rows_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                          _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_gemm_fp6_rows_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,

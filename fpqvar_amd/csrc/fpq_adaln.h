@@ -1069,7 +1069,16 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
     const int64_t slot_at = slot_row * vpr + 256 + slot_idx;
     const bool slot_live = do_slot && 256 + slot_idx < vpr;
     if constexpr (CODES && TOKEN) {   // per-token operands: E4M3 bytes or dense 6-bit codes, the row scale is out already
-      if (r.code_bits == 6) rq_store_codes6((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 6), vpr * 6), lane);
+      if (r.code_bits == 6) {
+        // row-major: the row's 6 vpr bytes behind its start; k-major (include/fpq.h): chunk ch of the row = chunk ch % 6 of K step ch / 6
+        const uint32_t steps = (uint32_t)vpr >> 4;
+        const __amdgpu_buffer_rsrc_t d6 = r.km_rows ? rq_rsrc(out, (int)(r.km_rows * steps * 96u)) : rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 6), vpr * 6);
+        rq_store_codes6((u32x4*)img, yw, s, lut, a.shift, d6, lane, [&](int ch) -> uint32_t {
+          if (!r.km_rows) return (uint32_t)ch * 16u;
+          const uint32_t st = (uint32_t)ch / 6u;
+          return st < steps ? km6_off((uint32_t)row, st, (uint32_t)ch - 6u * st, r.km_rows) : 0xFFFFFFFFu;
+        });
+      }
       else rq_store_codes8((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint8_t*)out + row * ((int64_t)vpr * 8), vpr * 8), lane);
       if constexpr (MAXC == 5) {
         if (slot_live) {
@@ -1095,6 +1104,10 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
             const uint64_t w6 = (own >> sr) | (nb << (48 - sr));
             if (qp < 3) {
               uint8_t* dst = (uint8_t*)out + row * ((int64_t)vpr * 6) + (int64_t)4 * (64 * 6) + 24 * (lane >> 2) + 8 * qp;
+              if (r.km_rows) {   // the same 8 bytes of the row, at byte wb: K step wb / 96, chunk (wb % 96) / 16 of the k-major image
+                const uint32_t wb = 1536u + 24u * ((uint32_t)lane >> 2) + 8u * (uint32_t)qp, w = wb % 96u;
+                dst = (uint8_t*)out + km6_off((uint32_t)row, wb / 96u, w >> 4, r.km_rows) + (w & 15u);
+              }
               __builtin_nontemporal_store(u32x2{(uint32_t)w6, (uint32_t)(w6 >> 32)}, (u32x2*)dst);
             }
           } else {
@@ -1104,16 +1117,28 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
         }
       }
     } else if constexpr (CODES) {   // FP4 operands: codes + one fp16 scale per group (fpq_gemm_fp4.h)
+      // row-major: the unit's groups (one row's, or two short rows' with PAIR2) are contiguous behind `row`; k-major: group
+      // u = lane / 4 of the unit is group u % gpr of row + u / gpr, the range check of the row-major buffer becomes `live`
+      const uint32_t gpr = (uint32_t)vpr >> 4;
+      const __amdgpu_buffer_rsrc_t cdst = r.km_rows ? rq_rsrc(out, (int)(r.km_rows * gpr * 64u)) : rq_rsrc((const uint32_t*)out + row * vpr, nrows * vpr * 4);
+      const auto coff = [&](int ln) -> uint32_t {
+        if (!r.km_rows) return (uint32_t)ln * 16u;
+        const uint32_t u = (uint32_t)ln >> 2, second = (nrows == 2 && u >= gpr) ? 1u : 0u;
+        return rq_km4_off((uint32_t)row + second, u - second * gpr, u < (uint32_t)nrows * gpr, ln, r.km_rows);
+      };
       if constexpr (HW4)
-        rq_store_codes_hw(img, yw, s, rq_rsrc((const uint32_t*)out + row * vpr, nrows * vpr * 4),
-                          rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane);
+        rq_store_codes_hw(img, yw, s, cdst, rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane, coff);
       else
-        rq_store_codes((u32x4*)img, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + row * vpr, nrows * vpr * 4),
-                       rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane);
+        rq_store_codes((u32x4*)img, yw, s, lut, a.shift, cdst, rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane, coff);
       if (MAXC == 5 && do_slot) {
         const uint32_t cd = HW4 ? codes_vec16_hw(y1, s1.inv) : codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
         if (slot_live) {
-          ((uint32_t*)out)[slot_at] = cd;
+          if (r.km_rows) {   // vector j = 256 + slot_idx of slot_row: 4 bytes at byte 4 (j & 3) of chunk (j & 15) >> 2 of group j >> 4
+            const uint32_t j = 256u + (uint32_t)slot_idx;
+            ((uint32_t*)out)[(km4_off((uint32_t)slot_row, j >> 4, (j & 15u) >> 2, r.km_rows) >> 2) + (j & 3u)] = cd;
+          } else {
+            ((uint32_t*)out)[slot_at] = cd;
+          }
           if ((lane & 15) == 0) r.code_scales[slot_at >> 4] = (uint16_t)(s1.s16x2 & 0xFFFFu);
         }
       }

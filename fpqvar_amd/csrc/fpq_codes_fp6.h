@@ -7,7 +7,7 @@
 template <int MAXC>
 __global__ __launch_bounds__(kBlock) void rows16_codes6_wave_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ codes,
                                                                    uint16_t* __restrict__ scales, int64_t rows, int64_t cols,
-                                                                   Lut16Args a, Lut16Tab tab) {
+                                                                   Lut16Args a, Lut16Tab tab, uint32_t km_rows) {
   __shared__ __attribute__((aligned(16))) uint16_t lut[kLutLdsEntries];   // static: a compile-time LDS address (a dynamic base is not folded into the ds_read offsets)
   {
     lut16_stage(lut, tab, a.shift);
@@ -52,10 +52,19 @@ __global__ __launch_bounds__(kBlock) void rows16_codes6_wave_kernel(const uint16
           o[(bit >> 5) + 1] |= (uint32_t)(p48 >> (32 - (bit & 31)));
           if ((bit & 31) + 48 > 64) o[(bit >> 5) + 2] |= (uint32_t)(p48 >> (64 - (bit & 31)));
         }
-        u32x2* dst = (u32x2*)(codes + row * (nblk * 24) + b * 24);
-        __builtin_nontemporal_store(u32x2{o[0], o[1]}, dst);
-        __builtin_nontemporal_store(u32x2{o[2], o[3]}, dst + 1);
-        __builtin_nontemporal_store(u32x2{o[4], o[5]}, dst + 2);
+        if (km_rows) {   // k-major image (include/fpq.h): block b = bytes 24 (b & 3) .. + 23 of K step b >> 2, three 8-byte halves of chunks
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const uint32_t w = 24u * ((uint32_t)b & 3u) + 8u * j;
+            u32x2* dst = (u32x2*)(codes + km6_off((uint32_t)row, (uint32_t)b >> 2, w >> 4, km_rows) + (w & 15u));
+            __builtin_nontemporal_store(u32x2{o[2 * j], o[2 * j + 1]}, dst);
+          }
+        } else {
+          u32x2* dst = (u32x2*)(codes + row * (nblk * 24) + b * 24);
+          __builtin_nontemporal_store(u32x2{o[0], o[1]}, dst);
+          __builtin_nontemporal_store(u32x2{o[2], o[3]}, dst + 1);
+          __builtin_nontemporal_store(u32x2{o[4], o[5]}, dst + 2);
+        }
       }
     }
   }
@@ -76,7 +85,8 @@ __host__ __device__ __forceinline__ uint32_t e2m3_of_level(float q) {
 // Generic form (fp32 weights, long or unaligned rows): one workgroup per row, a thread packs whole 32-element blocks.
 template <typename Tin>
 __global__ __launch_bounds__(kBlock) void rows_codes_fp6_kernel(const Tin* __restrict__ x, uint8_t* __restrict__ codes,
-                                                               Tin* __restrict__ scales, int64_t rows, int64_t cols, Fmt f) {
+                                                               Tin* __restrict__ scales, int64_t rows, int64_t cols, Fmt f,
+                                                               uint32_t km_rows) {
   __shared__ uint32_t sh[kBlock / 64];
   const int64_t nblk = cols >> 5;
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -100,8 +110,15 @@ __global__ __launch_bounds__(kBlock) void rows_codes_fp6_kernel(const Tin* __res
         o[bit >> 5] |= code << (bit & 31);
         if ((bit & 31) > 26) o[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
       }
-      uint32_t* dst = (uint32_t*)(codes + row * (nblk * 24) + b * 24);
-      for (int i = 0; i < 6; ++i) dst[i] = o[i];
+      if (km_rows) {
+        for (int i = 0; i < 6; ++i) {
+          const uint32_t w = 24u * ((uint32_t)b & 3u) + 4u * i;
+          *(uint32_t*)(codes + km6_off((uint32_t)row, (uint32_t)(b >> 2), w >> 4, km_rows) + (w & 15u)) = o[i];
+        }
+      } else {
+        uint32_t* dst = (uint32_t*)(codes + row * (nblk * 24) + b * 24);
+        for (int i = 0; i < 6; ++i) dst[i] = o[i];
+      }
     }
   }
 }

@@ -338,6 +338,37 @@ __device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t* sh) {
 }
 
 // ---------------------------------------------------------------------------------
+// K-major operand images (include/fpq.h): where a producer's 16-byte chunk goes
+// ---------------------------------------------------------------------------------
+// n / d for n < 2^31 and 1 <= d < 2^31 by one multiply-high: m = ceil(2^(32 + s) / d) with s = floor(log2 d) (exact for
+// n < 2^(32 + s) / d, which is > 2^31); a power of two has m == 0 and is a shift.
+struct FastDiv {
+  uint32_t d, m, s;
+};
+inline FastDiv fast_div(uint32_t d) {
+  FastDiv f{d, 0, 0};
+  while ((2u << f.s) <= d && f.s < 31) ++f.s;
+  if ((d & (d - 1)) != 0) f.m = (uint32_t)((((uint64_t)1 << (32 + f.s)) + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ uint32_t fast_div_q(uint32_t n, const FastDiv& f) {
+  return f.m ? __umulhi(n, f.m) >> f.s : n >> f.s;
+}
+// the permutations of the GEMMs' LDS images (fpq_gemm_fp4.h glds_chunk_perm, fpq_gemm_fp6.h fp6_rot), restated for the producers
+__host__ __device__ __forceinline__ uint32_t km4_perm(uint32_t row) { return (0x78u >> (((row & 15u) >> 2) << 1)) & 3u; }
+__host__ __device__ __forceinline__ uint32_t km6_rot(uint32_t row) { return (row >> 3) & 1u; }
+// FP4 (64 bytes per row and group): byte offset of logical chunk c (0..3) of group g of row t in an image of `rows` rows
+__device__ __forceinline__ uint32_t km4_off(uint32_t t, uint32_t g, uint32_t c, uint32_t rows) {
+  return ((g * rows + t) << 6) + ((c ^ km4_perm(t)) << 4);
+}
+// FP6 (96 bytes per row and K step): byte offset of logical chunk c (0..5) of step s of row t
+__device__ __forceinline__ uint32_t km6_off(uint32_t t, uint32_t s, uint32_t c, uint32_t rows) {
+  uint32_t p = c + km6_rot(t);
+  p = p >= 6 ? p - 6 : p;
+  return (s * rows + t) * 96u + (p << 4);
+}
+
+// ---------------------------------------------------------------------------------
 // Host-side launch helpers
 // ---------------------------------------------------------------------------------
 inline int grid_for(int64_t work_items_of_block, int64_t cap = kMaxBlocks) {

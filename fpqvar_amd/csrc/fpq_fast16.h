@@ -1114,6 +1114,8 @@ struct RotArgs {
                          // hardware E2M1 codes (4 bytes per 8 elements), this array one fp16 scale per 128-group,
                          // and the staged table is the code table (fpq_gemm_fp4.h)
   int code_bits;         // per-token code emission: 8 = E4M3 bytes (fpq_gemm_fp8.h), 6 = dense 6-bit E2M3 (fpq_gemm_fp6.h)
+  uint32_t km_rows;      // != 0: FP4 / FP6 codes go to a k-major image of this many rows (include/fpq.h) instead of row-major
+  FastDiv km_gpr;        // ... groups (K steps) per row, for the kernels that walk the tensor as a flat run of groups
 };
 
 __device__ __forceinline__ float xlane_xor4(float v) {

@@ -108,6 +108,7 @@ static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi*
   epi->gate = nullptr;
   epi->resid = nullptr;
   epi->rows_per_gate = 1;
+  epi->km_w_rows = 0;
   if (!ep) return FPQ_OK;
   if (ep->gate && (ep->rows_per_gate < 1 || ep->rows_per_gate > 0x7FFFFFFF)) return FPQ_ERR_ARG;
   if ((((uintptr_t)ep->gate | (uintptr_t)ep->residual) & 15) != 0) return FPQ_ERR_ARG;
@@ -118,12 +119,14 @@ static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi*
   return FPQ_OK;
 }
 
-int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
-                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
-                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+// km: both operands are k-major images (include/fpq.h); only the LDS-DMA kernels read them
+static int gemm_fp4_mx_impl(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                            int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                            const fpq_gemm_epilogue_t* epilogue, bool km, fpq_stream_t stream) {
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
   GemmEpi epi;
   if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
+  if (km) epi.km_w_rows = (int)((outs + 63) / 64 * 64);
   if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
   if (k % 128 != 0 || k > 128 * 64 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
   if (tokens == 0 || outs == 0) return FPQ_OK;
@@ -142,7 +145,11 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   const int64_t mid_tiles = ((tokens + 127) / 128) * ((outs + 127) / 128);
   const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds(G) <= 160 * 1024;
   // (the LDS-DMA kernel reads the bias four outputs at a time: a bias that is not 8-byte aligned goes to the other kernel)
-  const int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : fpq_opt_set(OPT_FPQ_GEMM_CFG) ? fpq_opt(OPT_FPQ_GEMM_CFG, 0) : mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
+  int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : fpq_opt_set(OPT_FPQ_GEMM_CFG) ? fpq_opt(OPT_FPQ_GEMM_CFG, 0) : mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
+  if (km) {
+    if (((uintptr_t)bias & 7) != 0 || outs + 63 > 0x7FFFFFFF) return FPQ_ERR_ARG;
+    if (cfg != 10 && cfg != 20 && cfg != 30) cfg = mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
+  }
 #define FPQ_GEMM_LAUNCH(MT, NT, WR, WC)                                                                              \
   do {                                                                                                               \
     using Cfg = GemmCfg<MT, NT, WR, WC>;                                                                             \
@@ -181,11 +188,23 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
   if (cfg == 10) FPQ_GEMM_GLDS(8, 4);
   if (cfg == 10 || cfg == 20 || cfg == 30) FPQ_GEMM_GLDS(4, 4);   // (the larger tile's LDS image may not fit where the smaller one's does)
 #undef FPQ_GEMM_GLDS
+  if (km) return FPQ_ERR_SHAPE;   // K too long for the LDS-DMA kernel's scale tiles: the register-staged kernels read row-major codes only
   if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
   else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
   else FPQ_GEMM_LAUNCH(4, 4, 2, 2);
 #undef FPQ_GEMM_LAUNCH
   return check_launch();
+}
+
+int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+  return gemm_fp4_mx_impl(a_codes, a_scales, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k, epilogue, false, stream);
+}
+int fpq_gemm_fp4_mx_km(const uint8_t* a_image, const void* a_scales, const uint8_t* w_image, const void* w_scales,
+                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+  return gemm_fp4_mx_impl(a_image, a_scales, w_image, w_scales, w_scale_dtype, bias, out, tokens, outs, k, epilogue, true, stream);
 }
 
 #ifdef FPQ_GEMM6_STAMPS
@@ -196,9 +215,9 @@ int fpq_debug_gemm6_stamp_buffer(void* device_buffer) {
 #endif
 
 // fc1 with GELU and fc2's dual-format input quantizer in the GEMM's epilogue (fpq_gemm_fp4.h, GemmFc1)
-int fpq_gemm_fp4_gelu_dual(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
-                           int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
-                           int64_t k, void* nan_flag, fpq_stream_t stream) {
+static int gemm_fp4_gelu_dual_impl(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                                   int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
+                                   int64_t k, void* nan_flag, bool km, fpq_stream_t stream) {
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
   if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
   // outs % 128: an output tile is one quantization group wide
@@ -223,7 +242,7 @@ int fpq_gemm_fp4_gelu_dual(const uint8_t* a_codes, const void* a_scales, const u
   xe.nan_flag = (uint32_t*)nan_flag;
   const int G = (int)(k / 128);
   hipStream_t st = (hipStream_t)stream;
-  GemmEpi epi{nullptr, nullptr, 1};
+  GemmEpi epi{nullptr, nullptr, 1, km ? (int)outs : 0};   // (outs % 128 == 0: the weight image has exactly outs rows)
   // tile choice as fpq_gemm_fp4_mx_ex (FPQ_GEMM_CFG 10 / 20 / 30 forces one of the three LDS-DMA tilings)
   const int64_t big_tiles = ((tokens + 255) / 256) * (outs / 128), mid_tiles = ((tokens + 127) / 128) * (outs / 128);
   const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds_fc1(G, xe.a.shift) <= 160 * 1024;
@@ -255,13 +274,27 @@ int fpq_gemm_fp4_gelu_dual(const uint8_t* a_codes, const void* a_scales, const u
 #undef FPQ_GEMM_FC1
   return FPQ_ERR_SHAPE;   // K too long for the LDS-DMA kernel's scale tiles
 }
+int fpq_gemm_fp4_gelu_dual(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
+                           int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
+                           int64_t k, void* nan_flag, fpq_stream_t stream) {
+  return gemm_fp4_gelu_dual_impl(a_codes, a_scales, w_codes, w_scales, w_scale_dtype, bias, out, gelu_out, tokens, outs, k, nan_flag, false, stream);
+}
+int fpq_gemm_fp4_gelu_dual_km(const uint8_t* a_image, const void* a_scales, const uint8_t* w_image, const void* w_scales,
+                              int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
+                              int64_t k, void* nan_flag, fpq_stream_t stream) {
+  return gemm_fp4_gelu_dual_impl(a_image, a_scales, w_image, w_scales, w_scale_dtype, bias, out, gelu_out, tokens, outs, k, nan_flag, true, stream);
+}
 
-int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
-                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
-                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+static int gemm_fp6_rows_impl(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                              const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                              int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, bool km, fpq_stream_t stream) {
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
   GemmEpi epi;
   if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
+  if (km) {
+    if (outs + 63 > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+    epi.km_w_rows = (int)((outs + 63) / 64 * 64);
+  }
   if (k % 128 != 0 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF || k > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
   if ((a_scale_dtype != FPQ_F16 && a_scale_dtype != FPQ_F32) || (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32))
     return FPQ_ERR_DTYPE;
@@ -296,6 +329,48 @@ int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_sca
   else FPQ_GO6T(4, 4);
 #undef FPQ_GO6T
 #undef FPQ_GO6
+  return check_launch();
+}
+int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+  return gemm_fp6_rows_impl(a_codes, a_scales, a_scale_dtype, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k, epilogue, false, stream);
+}
+int fpq_gemm_fp6_rows_km(const uint8_t* a_image, const void* a_scales, int a_scale_dtype, const uint8_t* w_image,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
+  return gemm_fp6_rows_impl(a_image, a_scales, a_scale_dtype, w_image, w_scales, w_scale_dtype, bias, out, tokens, outs, k, epilogue, true, stream);
+}
+
+// Row-major codes -> k-major image (include/fpq.h): one thread per 16-byte chunk of the image.  seg = bytes of a row per K step of
+// 128 elements (64: FP4 nibbles, 96: dense 6-bit codes); dealt: the weight side's row order, image rows = rows rounded up to 64
+// (rows past the tensor's end are zero).
+__global__ __launch_bounds__(256) void codes_to_kmajor_kernel(const u32x4* __restrict__ codes, u32x4* __restrict__ image, int64_t rows,
+                                                              int64_t image_rows, int steps, int seg, int dealt) {
+  const int cps = seg >> 4;   // chunks per segment
+  const int64_t n = (int64_t)steps * image_rows * cps;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int pc = (int)(i % cps);
+    const int64_t sj = i / cps;
+    const int64_t j = sj % image_rows;
+    const int s = (int)(sj / image_rows);
+    const int c = seg == 64 ? (pc ^ glds_chunk_perm((int)(j & 15))) : (pc - fp6_rot((int)(j & 31)) + 6) % 6;
+    const int64_t row = dealt ? (j & ~(int64_t)63) + 4 * (j & 15) + ((j >> 4) & 3) : j;
+    u32x4 v = u32x4{0, 0, 0, 0};
+    if (row < rows) v = codes[(row * steps + s) * cps + c];
+    image[i] = v;
+  }
+}
+int fpq_codes_to_kmajor(const uint8_t* codes, uint8_t* image, int64_t rows, int64_t k, int code_bits, int dealt, fpq_stream_t stream) {
+  if (rows < 0 || k < 0 || (code_bits != 4 && code_bits != 6)) return FPQ_ERR_ARG;
+  if (k % 128 != 0 || k / 128 > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
+  if (rows == 0 || k == 0) return FPQ_OK;
+  if (!codes || !image || (((uintptr_t)codes | (uintptr_t)image) & 15) != 0) return FPQ_ERR_ARG;
+  const int seg = code_bits == 4 ? 64 : 96;
+  const int64_t image_rows = dealt ? (rows + 63) / 64 * 64 : rows;
+  const int64_t n = (k / 128) * image_rows * (seg / 16);
+  hipLaunchKernelGGL(codes_to_kmajor_kernel, dim3(grid_for((n + 255) / 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)codes, (u32x4*)image, rows, image_rows, (int)(k / 128), seg, dealt ? 1 : 0);
   return check_launch();
 }
 

@@ -43,6 +43,9 @@ struct GemmEpi {
   const _Float16* gate;    // [ceil(T / rows_per_gate), O] or nullptr
   const _Float16* resid;   // [T, O] or nullptr; may alias out
   int rows_per_gate;
+  // K-MAJOR OPERAND IMAGES (include/fpq.h, "k-major operand images"; the FP4 and FP6 LDS-DMA kernels): 0 = row-major codes,
+  // else the image rows of the weight side (outs rounded up to 64; the activation side has exactly T).
+  int km_w_rows;
 };
 typedef _Float16 fpq_h2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 fpq_h4_t __attribute__((ext_vector_type(4)));
@@ -431,20 +434,27 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   // Issuing a stage's pieces between the MFMAs of the previous one instead of in front of them: 2.5 x slower (measured).
   // A persistent form (one workgroup per resident slot looping over its tiles, the next tile's stage 0 and scale tiles
   // requested in front of the current tile's stores): 5 - 10 % slower than one workgroup per tile (measured, round 4).
-  const uint8_t* const gbase[2] = {A + (int64_t)t0 * row_bytes, W + (int64_t)o0 * row_bytes};
+  // K-major images (epi.km_w_rows != 0): plane g holds every row's 64 bytes of group g, [G][rows][64], the 16-byte chunks of a row
+  // already in the LDS image's order and the weight rows in dealt order - a piece is 1 KiB CONTIGUOUS (8 whole 128-byte lines)
+  // instead of 16 rows' half lines row_bytes apart: 70 against 105 cycles to issue, profiles/r05_lds_dma_issue.txt.
+  const bool km = epi.km_w_rows != 0;
+  const int row_stride = km ? 64 : row_bytes;
+  const int64_t a_step = km ? (int64_t)T * 64 : 64, w_step = km ? (int64_t)epi.km_w_rows * 64 : 64;
+  const uint8_t* const gbase[2] = {A + (int64_t)t0 * row_stride, W + (int64_t)o0 * row_stride};
   uint32_t voff[PIECES];
   {
-    const int q = lane >> 2, kb = (lane & 3) ^ glds_chunk_perm(q);
+    const int q = lane >> 2, kb = km ? (lane & 3) : (lane & 3) ^ glds_chunk_perm(q);
+    const int w_rows = km ? epi.km_w_rows : O;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int blk = wave + 4 * i;
       if (blk < ABLK) {
         const int t = t0 + blk * 16 + q;
-        voff[i] = (uint32_t)((t < T ? t : T - 1) - t0) * (uint32_t)row_bytes + (uint32_t)(kb * 16);
+        voff[i] = (uint32_t)((t < T ? t : T - 1) - t0) * (uint32_t)row_stride + (uint32_t)(kb * 16);
       } else {
         const int wb = blk - ABLK;
-        const int o = o0 + (wb / NT) * (16 * NT) + NT * q + wb % NT;
-        voff[i] = (uint32_t)((o < O ? o : O - 1) - o0) * (uint32_t)row_bytes + (uint32_t)(kb * 16);
+        const int o = km ? o0 + wb * 16 + q : o0 + (wb / NT) * (16 * NT) + NT * q + wb % NT;
+        voff[i] = (uint32_t)((o < w_rows ? o : w_rows - 1) - o0) * (uint32_t)row_stride + (uint32_t)(kb * 16);
       }
     }
   }
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   _Pragma("unroll") for (int i_ = 0; i_ < PIECES; ++i_)                                                             \
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                 \
                    :                                                                                                \
-                   : "v"(voff[i_]), "s"(gbase[i_ < ABLK / 4 ? 0 : 1] + (g) * 64),                                   \
+                   : "v"(voff[i_]), "s"(gbase[i_ < ABLK / 4 ? 0 : 1] + (g) * (i_ < ABLK / 4 ? a_step : w_step)),                                   \
                      "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +     \
                                                                                        (wave + 4 * i_) * 1024))    \
                    : "m0")

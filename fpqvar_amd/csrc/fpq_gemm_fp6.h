@@ -69,10 +69,17 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
 #endif
 
   // LDS-DMA sources: scalar base per operand + 32-bit lane offset, in assembly with explicit waits (as in gemm_fp4_glds_kernel)
-  const uint8_t* const gbase[2] = {A + (int64_t)t0 * row_bytes, W + (int64_t)o0 * row_bytes};
-  uint32_t voff[PIECES];
   static_assert((3 * ASB) % 4 == 0, "the A / W boundary falls between two rounds of the four wavefronts");
   constexpr int APIECES = 3 * ASB / 4;              // a wavefront's pieces i < APIECES are rows of A
+  // K-major images (epi.km_w_rows != 0, as in gemm_fp4_glds_kernel): plane s holds every row's 96 bytes of K step s, [steps][rows][96],
+  // chunks already rotated as in the LDS image, weight rows in dealt order: a super-block's three pieces are 3 KiB contiguous
+  // (70 against 100 - 150 cycles to issue a piece; profiles/r05_lds_dma_issue.txt, r05_gemm6_stamps.txt).
+  const bool km = epi.km_w_rows != 0;
+  const int row_stride = km ? 96 : row_bytes;
+  const int64_t a_step = km ? (int64_t)T * 96 : 96, w_step = km ? (int64_t)epi.km_w_rows * 96 : 96;
+  const uint8_t* const gbase[2] = {A + (int64_t)t0 * row_stride, W + (int64_t)o0 * row_stride};
+  const int w_rows = km ? epi.km_w_rows : O;
+  uint32_t voff[PIECES];
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
     const int piece = wave + 4 * i;                 // super-block piece / 3, part piece % 3
@@ -80,19 +87,20 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
     const int r = ci / 6, pc = ci - 6 * r;          // row inside the super-block, physical chunk
     int c = pc - fp6_rot(r);
     c = c < 0 ? c + 6 : c;                          // logical chunk this lane fetches
+    c = km ? pc : c;                                // (the image holds the rotated order)
     if (sb < ASB) {
       const int t = t0 + sb * 32 + r;
-      voff[i] = (uint32_t)((t < T ? t : T - 1) - t0) * (uint32_t)row_bytes + (uint32_t)(c * 16);
+      voff[i] = (uint32_t)((t < T ? t : T - 1) - t0) * (uint32_t)row_stride + (uint32_t)(c * 16);
     } else {
       const int ti = 2 * (sb - ASB) + (r >> 4);      // 16-row tile of the weight side; its rows are dealt over a wavefront's
-      const int o = o0 + (ti / NT) * (16 * NT) + NT * (r & 15) + ti % NT;   // NT tiles (FPQ_GEMM_ROWS_EPILOGUE)
-      voff[i] = (uint32_t)((o < O ? o : O - 1) - o0) * (uint32_t)row_bytes + (uint32_t)(c * 16);
+      const int o = km ? o0 + (sb - ASB) * 32 + r : o0 + (ti / NT) * (16 * NT) + NT * (r & 15) + ti % NT;   // NT tiles (FPQ_GEMM_ROWS_EPILOGUE)
+      voff[i] = (uint32_t)((o < w_rows ? o : w_rows - 1) - o0) * (uint32_t)row_stride + (uint32_t)(c * 16);
     }
   }
 #define FPQ_GLDS6_ONE(s, buf, i_)                                                                                   \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                     \
                :                                                                                                    \
-               : "v"(voff[i_]), "s"(gbase[(i_) < APIECES ? 0 : 1] + (s) * 96),                                      \
+               : "v"(voff[i_]), "s"(gbase[(i_) < APIECES ? 0 : 1] + (s) * ((i_) < APIECES ? a_step : w_step)),                                      \
                  "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + (buf) * STAGE +         \
                                                                                    (wave + 4 * (i_)) * 1024))      \
                : "m0")

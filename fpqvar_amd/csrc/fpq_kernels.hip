@@ -1092,15 +1092,22 @@ int launch_fast16(const void* x, void* out, int64_t rows, int64_t cols, int neg_
 
 inline const Lut16Tab& lut16_mx_codes_e2m1();
 
+// k-major images are addressed with 32-bit byte offsets (and int buffer ranges) by their producers: the whole image must stay below 2 GiB
+static bool km_image_fits(int64_t rows, int64_t row_bytes) { return rows < (1ll << 31) && rows * row_bytes < (1ll << 31); }
+
 template <typename Tin>
 int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, int64_t cols, const float* smooth,
-                        const uint32_t sign[4], int table_id, hipStream_t st, uint16_t* code_scales = nullptr) {
+                        const uint32_t sign[4], int table_id, hipStream_t st, uint16_t* code_scales = nullptr,
+                        bool km = false /* FP4 codes into a k-major image (include/fpq.h): the matrix-core form only */) {
   const Lut16Host& h = lut16_host(table_id, table_id);
   if (!h.tab_valid) return FPQ_ERR_TABLE;
   const Lut16Tab& tab = code_scales ? lut16_mx_codes_e2m1() : h.tab;
   RotArgs r;
   r.code_scales = code_scales;
   r.code_bits = 8;
+  r.km_rows = km ? (uint32_t)rows : 0u;
+  r.km_gpr = fast_div((uint32_t)(cols / 128));
+  if (km && (!code_scales || !km_image_fits(rows, cols / 2))) return FPQ_ERR_SHAPE;
   r.smooth = smooth;
   for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));   // torch.tensor(128).sqrt() is float32; autocast makes Q fp16
@@ -1142,6 +1149,7 @@ int launch_rotate_quant(const void* x, void* out, void* rot_out, int64_t rows, i
 #undef FPQ_ROT_MFMA
     return check_launch();
   }
+  if (km) return FPQ_ERR_SHAPE;   // the butterfly forms (a build / experiment switch) write row-major codes only
   if (code_scales)
     hipLaunchKernelGGL((rotate_quant16_kernel<Tin, false, U, true>), grid, dim3(kBlock), lds, st, x, (u32x4*)out,
                        (u32x4*)nullptr, n_vec, r, h.args, tab);
@@ -1159,13 +1167,23 @@ int launch_adaln_rotate_quant(const void* x, void* out, void* h_out, void* y_out
                               const AdaLnArgs& ad, const float* smooth, const uint32_t sign[4], int table_id,
                               hipStream_t st, int lanes_per_row, uint16_t* code_scales = nullptr,
                               int token_mode = 0 /*1: per-token values, 2: per-token E4M3 codes, 3: per-token packed 6-bit codes*/,
-                              const Lut16Tab* token_code_tab = nullptr) {
+                              const Lut16Tab* token_code_tab = nullptr,
+                              bool km = false /* FP4 / 6-bit codes into a k-major image (include/fpq.h): adaln_mfma_kernel only */) {
   const Lut16Host& h = lut16_host(table_id, table_id);
   if (!h.tab_valid) return FPQ_ERR_TABLE;
   const Lut16Tab& tab = token_mode >= 2 ? *token_code_tab : (code_scales && !token_mode ? lut16_mx_codes_e2m1() : h.tab);
   RotArgs r;
   r.code_scales = code_scales;
   r.code_bits = token_mode == 3 ? 6 : 8;
+  r.km_rows = km ? (uint32_t)rows : 0u;
+  r.km_gpr = fast_div((uint32_t)(cols / 128));
+  if (km) {
+    const bool fp4_codes = code_scales && !token_mode;
+    if (!(fp4_codes || token_mode == 3) || !km_image_fits(rows, token_mode == 3 ? cols / 4 * 3 : cols / 2)) return FPQ_ERR_SHAPE;
+    // the forms that write row-major codes only: rows beyond one wavefront, the first-generation kernel, the butterfly build
+    if (lanes_per_row != 64 || cols / 8 > 64 * 5 || fpq_flag(OPT_FPQ_ADALN_V1) || FPQ_ROT_BUTTERFLY_BUILD || fpq_flag(OPT_FPQ_ROT_BUTTERFLY))
+      return FPQ_ERR_SHAPE;
+  }
   r.smooth = smooth;
   for (int i = 0; i < 4; ++i) r.sign[i] = sign[i];
   r.c_h = h2f(f2h(1.0f / __builtin_sqrtf(128.0f)));
@@ -1941,7 +1959,7 @@ int fpq_quant_rows_neg_reverse(const void* x, void* out, int64_t rows, int64_t c
 
 static int rotate_quant_impl(const void* x, void* out, void* rotated_out, void* code_scales, int64_t rows, int64_t cols,
                              int in_dtype, const float* smooth, const uint32_t* sign_mask_host, int table_id,
-                             fpq_stream_t stream) {
+                             fpq_stream_t stream, bool km = false) {
   if (rows < 0 || cols < 0 || !sign_mask_host) return FPQ_ERR_ARG;
   if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
   if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
@@ -1951,9 +1969,9 @@ static int rotate_quant_impl(const void* x, void* out, void* rotated_out, void* 
   if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)rotated_out | (uintptr_t)smooth) & 15) != 0) return FPQ_ERR_ARG;
   if (in_dtype == FPQ_F16)
     return launch_rotate_quant<_Float16>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
-                                         (hipStream_t)stream, (uint16_t*)code_scales);
+                                         (hipStream_t)stream, (uint16_t*)code_scales, km);
   return launch_rotate_quant<float>(x, out, rotated_out, rows, cols, smooth, sign_mask_host, table_id,
-                                    (hipStream_t)stream, (uint16_t*)code_scales);
+                                    (hipStream_t)stream, (uint16_t*)code_scales, km);
 }
 
 int fpq_quant_rows_dual_argmin(const void* x, float* out, int64_t rows, int64_t cols, int neg_table, int pos_table,
@@ -1984,12 +2002,17 @@ int fpq_rotate_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, 
   if (rows > 0 && cols > 0 && !scales) return FPQ_ERR_ARG;
   return rotate_quant_impl(x, codes, nullptr, scales, rows, cols, in_dtype, smooth, sign_mask_host, FPQ_E2M1, stream);
 }
+int fpq_rotate_quant_rows_codes_mx_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                                      const float* smooth, const uint32_t* sign_mask_host, fpq_stream_t stream) {
+  if (rows > 0 && cols > 0 && !scales) return FPQ_ERR_ARG;
+  return rotate_quant_impl(x, image, nullptr, scales, rows, cols, in_dtype, smooth, sign_mask_host, FPQ_E2M1, stream, true);
+}
 
 static int adaln_rotate_quant_impl(const void* x, void* out, void* h_out, void* rotated_out, void* code_scales,
                                    int64_t rows, int64_t cols, int in_dtype, const void* scale, const void* shift,
                                    int mod_dtype, int64_t rows_per_batch, float eps, const float* smooth,
                                    const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream,
-                                   int token_mode = 0, const Lut16Tab* token_code_tab = nullptr) {
+                                   int token_mode = 0, const Lut16Tab* token_code_tab = nullptr, bool km = false) {
   if (rows < 0 || cols < 0 || rows_per_batch <= 0 || !sign_mask_host) return FPQ_ERR_ARG;
   if (table_id < 0 || table_id >= FPQ_NUM_TABLES || !kTables[table_id].symmetric) return FPQ_ERR_TABLE;
   if ((in_dtype != FPQ_F16 && in_dtype != FPQ_F32) || (mod_dtype != FPQ_F16 && mod_dtype != FPQ_F32))
@@ -2016,7 +2039,7 @@ static int adaln_rotate_quant_impl(const void* x, void* out, void* h_out, void* 
   hipStream_t st = (hipStream_t)stream;
 #define FPQ_GO(TI, TM) return launch_adaln_rotate_quant<TI, TM>(x, out, h_out, rotated_out, rows, cols, ad, smooth, \
                                                               sign_mask_host, table_id, st, lpr, (uint16_t*)code_scales, \
-                                                              token_mode, token_code_tab)
+                                                              token_mode, token_code_tab, km)
   if (in_dtype == FPQ_F16 && mod_dtype == FPQ_F16) FPQ_GO(_Float16, _Float16);
   if (in_dtype == FPQ_F16) FPQ_GO(_Float16, float);
   if (mod_dtype == FPQ_F16) FPQ_GO(float, _Float16);
@@ -2040,12 +2063,21 @@ int fpq_adaln_rotate_quant_rows_codes_mx(const void* x, uint8_t* codes, void* sc
   return adaln_rotate_quant_impl(x, codes, nullptr, nullptr, scales, rows, cols, in_dtype, scale, shift, mod_dtype,
                                  rows_per_batch, eps, smooth, sign_mask_host, FPQ_E2M1, stream);
 }
+int fpq_adaln_rotate_quant_rows_codes_mx_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols,
+                                            int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                            int64_t rows_per_batch, float eps, const float* smooth,
+                                            const uint32_t* sign_mask_host, fpq_stream_t stream) {
+  if (rows > 0 && cols > 0 && !scales) return FPQ_ERR_ARG;
+  return adaln_rotate_quant_impl(x, image, nullptr, nullptr, scales, rows, cols, in_dtype, scale, shift, mod_dtype,
+                                 rows_per_batch, eps, smooth, sign_mask_host, FPQ_E2M1, stream, 0, nullptr, true);
+}
 
-int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int in_dtype,
-                            fpq_stream_t stream) {
+static int quant_rows_codes_mx_impl(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                                    bool km, fpq_stream_t stream) {
   if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
   if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
-  if (cols % 128 != 0) return FPQ_ERR_SHAPE;
+  if (km && in_dtype != FPQ_F16) return FPQ_ERR_DTYPE;   // fp32 rows (weights): fpq_quant_rows_codes_mx + fpq_codes_to_kmajor
+  if (cols % 128 != 0 || (km && !km_image_fits(rows, cols / 2))) return FPQ_ERR_SHAPE;
   if (rows == 0 || cols == 0) return FPQ_OK;
   if (!x || !codes || !scales) return FPQ_ERR_ARG;
   if ((((uintptr_t)x | (uintptr_t)codes | (uintptr_t)scales) & 15) != 0) return FPQ_ERR_ARG;
@@ -2055,13 +2087,22 @@ int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t
     const int64_t n_vec = rows * (cols / 8);
     const size_t lds = 0;   // the bucket table lives in static LDS (fpq_fast16.h)
     hipLaunchKernelGGL(rows16_codes_mx_kernel, dim3(grid_for((n_vec + kBlock - 1) / kBlock, 16384)), dim3(kBlock), lds, st,
-                       (const u32x4*)x, (uint32_t*)codes, (uint16_t*)scales, n_vec, h.args, lut16_mx_codes_e2m1());
+                       (const u32x4*)x, (uint32_t*)codes, (uint16_t*)scales, n_vec, h.args, lut16_mx_codes_e2m1(),
+                       km ? (uint32_t)rows : 0u, fast_div((uint32_t)(cols / 128)));
   } else {
     const int64_t n_vec = rows * (cols / 4);
     hipLaunchKernelGGL((codes128_kernel<float, true, true>), dim3(grid_for((n_vec + kBlock - 1) / kBlock, 1 << 20)),
                        dim3(kBlock), 0, st, (const u32x4*)x, codes, (float*)scales, n_vec, make_fmt(FPQ_E2M1));
   }
   return check_launch();
+}
+int fpq_quant_rows_codes_mx(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                            fpq_stream_t stream) {
+  return quant_rows_codes_mx_impl(x, codes, scales, rows, cols, in_dtype, false, stream);
+}
+int fpq_quant_rows_codes_mx_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                               fpq_stream_t stream) {
+  return quant_rows_codes_mx_impl(x, image, scales, rows, cols, in_dtype, true, stream);
 }
 
 // host: OCP E4M3 byte of a value that is exactly representable (every level of the symmetric tables is)
@@ -2169,13 +2210,24 @@ int fpq_adaln_rotate_quant_token_rows_codes_fp6(const void* x, uint8_t* codes, v
   return adaln_rotate_quant_impl(x, codes, nullptr, nullptr, row_scales, rows, cols, in_dtype, scale, shift, mod_dtype,
                                  rows_per_batch, eps, smooth, sign_mask_host, table_id, stream, 3, &lut16_codes6_e2m3());
 }
+int fpq_adaln_rotate_quant_token_rows_codes_fp6_km(const void* x, uint8_t* image, void* row_scales, int64_t rows, int64_t cols,
+                                                   int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                                   int64_t rows_per_batch, float eps, const float* smooth,
+                                                   const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream) {
+  if (rows > 0 && cols > 0 && !row_scales) return FPQ_ERR_ARG;
+  if (table_id != FPQ_E2M3) return FPQ_ERR_TABLE;
+  if (cols % 128 != 0) return FPQ_ERR_SHAPE;
+  return adaln_rotate_quant_impl(x, image, nullptr, nullptr, row_scales, rows, cols, in_dtype, scale, shift, mod_dtype,
+                                 rows_per_batch, eps, smooth, sign_mask_host, table_id, stream, 3, &lut16_codes6_e2m3(), true);
+}
 
-int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
-                             int in_dtype, fpq_stream_t stream) {
+static int quant_rows_codes_fp6_impl(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
+                                     int in_dtype, bool km, fpq_stream_t stream) {
   if (rows < 0 || cols < 0) return FPQ_ERR_ARG;
   if (table_id != FPQ_E2M3) return FPQ_ERR_TABLE;
   if (in_dtype != FPQ_F16 && in_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
-  if (cols % 32 != 0) return FPQ_ERR_SHAPE;
+  if (cols % 32 != 0 || (km && (cols % 128 != 0 || !km_image_fits(rows, cols / 4 * 3)))) return FPQ_ERR_SHAPE;
+  const uint32_t km_rows = km ? (uint32_t)rows : 0u;
   if (rows == 0 || cols == 0) return FPQ_OK;
   if (!x || !codes || !scales) return FPQ_ERR_ARG;
   if ((((uintptr_t)codes) & 7) != 0) return FPQ_ERR_ARG;
@@ -2187,7 +2239,7 @@ int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_
     const dim3 gw(grid_for(wgs, 8192));
     const int maxc = (int)((cols / 32 + 63) / 64);
 #define FPQ_C6(M) hipLaunchKernelGGL((rows16_codes6_wave_kernel<M>), gw, dim3(kBlock), lds, st, (const uint16_t*)x, codes, \
-                                     (uint16_t*)scales, rows, cols, h.args, lut16_codes6_e2m3())
+                                     (uint16_t*)scales, rows, cols, h.args, lut16_codes6_e2m3(), km_rows)
     if (maxc <= 1) FPQ_C6(1);
     else if (maxc <= 2) FPQ_C6(2);
     else FPQ_C6(4);
@@ -2197,11 +2249,19 @@ int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_
   const dim3 g(grid_for(rows, 65535));
   if (in_dtype == FPQ_F16)
     hipLaunchKernelGGL(rows_codes_fp6_kernel<_Float16>, g, dim3(kBlock), 0, st, (const _Float16*)x, codes,
-                       (_Float16*)scales, rows, cols, make_fmt(table_id));
+                       (_Float16*)scales, rows, cols, make_fmt(table_id), km_rows);
   else
     hipLaunchKernelGGL(rows_codes_fp6_kernel<float>, g, dim3(kBlock), 0, st, (const float*)x, codes, (float*)scales, rows,
-                       cols, make_fmt(table_id));
+                       cols, make_fmt(table_id), km_rows);
   return check_launch();
+}
+int fpq_quant_rows_codes_fp6(const void* x, uint8_t* codes, void* scales, int64_t rows, int64_t cols, int table_id,
+                             int in_dtype, fpq_stream_t stream) {
+  return quant_rows_codes_fp6_impl(x, codes, scales, rows, cols, table_id, in_dtype, false, stream);
+}
+int fpq_quant_rows_codes_fp6_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols, int table_id,
+                                int in_dtype, fpq_stream_t stream) {
+  return quant_rows_codes_fp6_impl(x, image, scales, rows, cols, table_id, in_dtype, true, stream);
 }
 
 int fpq_absmax(const void* x, int64_t n, int dtype, void* out, fpq_stream_t stream) {

@@ -239,9 +239,17 @@ __device__ __forceinline__ uint32_t rq_lut_pair(const uint16_t* lut, uint32_t u,
 // 8 c + 2 quarter of its group's 64: 2-byte LDS writes (dword index xor-swizzled with bits 2, 3 of the group: the 64
 // lanes of a write hit 32 different dwords, two lanes each), then every lane reads 16 bytes = chunk lane % 4 of group
 // lane / 4 and the tile's 1 KiB of codes leaves as ONE coalesced store per lane; lanes 0 .. 15 store the scales.
+// code_off(lane): where this lane's 16 bytes (chunk lane % 4 of the tile's group lane / 4) go inside codes_dst - lane * 16 for
+// row-major codes (the tile's 16 groups are 1 KiB in a row), rq_km4_off for a k-major image (codes_dst then spans the whole
+// image); 0xFFFFFFFF: outside every buffer, the store is dropped.  A callable evaluated on an opaque copy of the lane index right
+// in front of the store: computed ahead of the conversion it costs the one register the kernel does not have (tests/test_no_spill.py).
+__device__ __forceinline__ uint32_t rq_km4_off(uint32_t t, uint32_t g, bool live, int lane, uint32_t km_rows) {
+  return live ? km4_off(t, g, (uint32_t)lane & 3u, km_rows) : 0xFFFFFFFFu;
+}
+template <typename OffFn>
 __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[8][2], const RowScale16& s,
                                                const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t codes_dst,
-                                               __amdgpu_buffer_rsrc_t scales_dst, int lane) {
+                                               __amdgpu_buffer_rsrc_t scales_dst, int lane, OffFn code_off) {
   lane = rq_opaque(lane);
   const int g = lane & 15, quarter = lane >> 4;
   const int swz = ((g >> 2) & 3) << 2;
@@ -262,7 +270,7 @@ __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[
   lane = rq_opaque(lane);
   const int gg = lane >> 2, j = lane & 3;
   const u32x4 o = buf[gg * 4 + (j ^ ((gg >> 2) & 3))];
-  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, lane * 16, 0, kRqNt);
+  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, code_off(lane), 0, kRqNt);
   if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
   __builtin_amdgcn_wave_barrier();
 }
@@ -273,9 +281,10 @@ __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[
 // bytes in the image (20 dwords: the 64 lanes of a 2-byte write hit 32 dwords, two lanes each sharing one), every
 // address a lane constant + an immediate.
 constexpr int kRqCodeStride = 80;
+template <typename OffFn>
 __device__ __forceinline__ void rq_store_codes_hw(char* img, const uint32_t (&yw)[8][2], const RowScale16& s,
                                                   __amdgpu_buffer_rsrc_t codes_dst, __amdgpu_buffer_rsrc_t scales_dst,
-                                                  int lane) {
+                                                  int lane, OffFn code_off) {
   const int g = lane & 15, quarter = lane >> 4;
   const int cw = g * kRqCodeStride + 2 * quarter;
 #pragma unroll
@@ -291,7 +300,7 @@ __device__ __forceinline__ void rq_store_codes_hw(char* img, const uint32_t (&yw
   }
   __builtin_amdgcn_wave_barrier();
   const u32x4 o = *(const u32x4*)(img + (lane >> 2) * kRqCodeStride + (lane & 3) * 16);   // chunk lane % 4 of group lane / 4
-  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, lane * 16, 0, kRqNt);
+  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, code_off(rq_opaque(lane)), 0, kRqNt);
   if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
   __builtin_amdgcn_wave_barrier();
 }
@@ -330,8 +339,10 @@ __device__ __forceinline__ void rq_store_codes8(u32x4* buf, const uint32_t (&yw)
 
 // Dense 6-bit codes (E2M3): a piece is 24 bits at byte 12 c + 3 quarter of its group's 96: one 2-byte and one 1-byte LDS
 // write, in the order the address parity asks for; the tile's 1.5 KiB leave as 16-byte stores (lanes 0 .. 31 two).
+template <typename OffFn>
 __device__ __forceinline__ void rq_store_codes6(u32x4* buf, const uint32_t (&yw)[8][2], const RowScale16& s,
-                                                const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t dst, int lane) {
+                                                const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t dst, int lane,
+                                                OffFn off) {
   lane = rq_opaque(lane);
   const int g = lane & 15, quarter = lane >> 4;
   const bool odd = (quarter & 1) != 0;
@@ -353,8 +364,8 @@ __device__ __forceinline__ void rq_store_codes6(u32x4* buf, const uint32_t (&yw)
   }
   __builtin_amdgcn_wave_barrier();
   lane = rq_opaque(lane);
-  __builtin_amdgcn_raw_buffer_store_b128(buf[lane], dst, lane * 16, 0, kRqNt);
-  if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(buf[64 + lane], dst, lane * 16 + 1024, 0, kRqNt);
+  __builtin_amdgcn_raw_buffer_store_b128(buf[lane], dst, off(lane), 0, kRqNt);   // chunk `lane` of the tile's 96: row-major lane * 16
+  if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(buf[64 + lane], dst, off(64 + lane), 0, kRqNt);   // chunk 64 + lane: row-major 1024 + lane * 16
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -513,12 +524,18 @@ __global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES)
     }
     RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
     if constexpr (HW4) scale_nan_if_not_finite(s);
-    if constexpr (CODES && HW4) {
-      rq_store_codes_hw(img, yw, s, rq_rsrc((const uint32_t*)out + base_vec, rem * 4),
-                        rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), rq_opaque(lane));
-    } else if constexpr (CODES) {
-      rq_store_codes(buf, yw, s, lut, a.shift, rq_rsrc((const uint32_t*)out + base_vec, rem * 4),
-                     rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), lane);
+    if constexpr (CODES) {
+      // row-major: the tile's 16 groups are 1 KiB in a row behind base_vec; k-major: every group has its own (row, group) slot
+      const __amdgpu_buffer_rsrc_t cdst = r.km_rows ? rq_rsrc(out, (int)(r.km_rows * r.km_gpr.d * 64u)) : rq_rsrc((const uint32_t*)out + base_vec, rem * 4);
+      const auto coff = [&](int ln) -> uint32_t {
+        if (!r.km_rows) return (uint32_t)ln * 16u;
+        const uint32_t gi = (uint32_t)(base_vec >> 4) + ((uint32_t)ln >> 2), t = fast_div_q(gi, r.km_gpr);
+        return rq_km4_off(t, gi - t * r.km_gpr.d, (int64_t)gi * 16 < n_vec, ln, r.km_rows);
+      };
+      if constexpr (HW4)
+        rq_store_codes_hw(img, yw, s, cdst, rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), rq_opaque(lane), coff);
+      else
+        rq_store_codes(buf, yw, s, lut, a.shift, cdst, rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), lane, coff);
     } else {
 #pragma unroll
       for (int c = 0; c < 8; ++c)

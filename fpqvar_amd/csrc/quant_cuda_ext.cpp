@@ -278,31 +278,38 @@ ProducerArgs producer_checks(const char* what, const at::Tensor& x, const at::Te
   return a;
 }
 
+// FP4 operand codes: row-major [rows, C / 2], or (kmajor) the activation side's k-major image [C / 128, rows, 64] (include/fpq.h)
+static at::Tensor mx_codes_tensor(const at::Tensor& x, int64_t rows, int64_t c, bool kmajor) {
+  return kmajor ? at::empty({c / 128, rows, 64}, x.options().dtype(at::kByte)) : at::empty({rows, c / 2}, x.options().dtype(at::kByte));
+}
+
 std::tuple<at::Tensor, at::Tensor> rotate_quant_mx(const at::Tensor& x, const std::array<uint32_t, 4>& sign_mask,
-                                                   const c10::optional<at::Tensor>& smooth) {
+                                                   const c10::optional<at::Tensor>& smooth, bool kmajor) {
   const ProducerArgs a = producer_checks("rotate_quant_mx", x, nullptr, nullptr, smooth, 1 << 30);
   const int64_t rows = a.l;
-  at::Tensor codes = at::empty({rows, a.c / 2}, x.options().dtype(at::kByte));
+  at::Tensor codes = mx_codes_tensor(x, rows, a.c, kmajor);
   at::Tensor scales = at::empty({rows, a.c / 128}, x.options().dtype(at::kHalf));
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
-  check(fpq_rotate_quant_rows_codes_mx(x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c,
-                                       dtype_id(x.scalar_type(), "rotate_quant_mx"), a.smooth, sign_mask.data(), current_stream(x)),
-        "fpq_rotate_quant_rows_codes_mx");
+  check((kmajor ? fpq_rotate_quant_rows_codes_mx_km : fpq_rotate_quant_rows_codes_mx)(
+            x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c, dtype_id(x.scalar_type(), "rotate_quant_mx"), a.smooth,
+            sign_mask.data(), current_stream(x)),
+        kmajor ? "fpq_rotate_quant_rows_codes_mx_km" : "fpq_rotate_quant_rows_codes_mx");
   return {codes, scales};
 }
 
 std::tuple<at::Tensor, at::Tensor> adaln_rotate_quant_mx(const at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift,
                                                          const std::array<uint32_t, 4>& sign_mask,
-                                                         const c10::optional<at::Tensor>& smooth, double eps) {
+                                                         const c10::optional<at::Tensor>& smooth, double eps, bool kmajor) {
   const ProducerArgs a = producer_checks("adaln_rotate_quant_mx", x, &scale, &shift, smooth, 4096);
   const int64_t rows = a.b * a.l;
-  at::Tensor codes = at::empty({rows, a.c / 2}, x.options().dtype(at::kByte));
+  at::Tensor codes = mx_codes_tensor(x, rows, a.c, kmajor);
   at::Tensor scales = at::empty({rows, a.c / 128}, x.options().dtype(at::kHalf));
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
-  check(fpq_adaln_rotate_quant_rows_codes_mx(x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c,
-                                             dtype_id(x.scalar_type(), "adaln_rotate_quant_mx"), scale.data_ptr(), shift.data_ptr(),
-                                             dtype_id(scale.scalar_type(), "adaln_rotate_quant_mx"), a.l, (float)eps, a.smooth,
-                                             sign_mask.data(), current_stream(x)), "fpq_adaln_rotate_quant_rows_codes_mx");
+  check((kmajor ? fpq_adaln_rotate_quant_rows_codes_mx_km : fpq_adaln_rotate_quant_rows_codes_mx)(
+            x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c, dtype_id(x.scalar_type(), "adaln_rotate_quant_mx"),
+            scale.data_ptr(), shift.data_ptr(), dtype_id(scale.scalar_type(), "adaln_rotate_quant_mx"), a.l, (float)eps, a.smooth,
+            sign_mask.data(), current_stream(x)),
+        kmajor ? "fpq_adaln_rotate_quant_rows_codes_mx_km" : "fpq_adaln_rotate_quant_rows_codes_mx");
   return {codes, scales};
 }
 
@@ -365,17 +372,48 @@ void check_operand(const char* what, const at::Tensor& codes, const at::Tensor& 
   TORCH_CHECK(scales.numel() == n_scales, what, ": ", scales.numel(), " scales, expected ", n_scales);
 }
 
+// Operand shapes of the FP4 GEMMs: both row-major codes [rows, K / 2] (2-D) or both k-major images [K / 128, image rows, 64] (3-D,
+// include/fpq.h; the weight image has outs rounded up to 64 rows, outs itself comes from the scales [outs, K / 128]).
+struct Fp4Shapes {
+  int64_t tokens, outs, k;
+  bool kmajor;
+};
+static Fp4Shapes fp4_shapes(const char* what, const at::Tensor& a_codes, const at::Tensor& a_scales, const at::Tensor& w_codes,
+                            const at::Tensor& w_scales) {
+  Fp4Shapes sh;
+  TORCH_CHECK((a_codes.dim() == 2 && w_codes.dim() == 2) || (a_codes.dim() == 3 && w_codes.dim() == 3), what,
+              ": both operands must be row-major codes [rows, K / 2] or both k-major images [K / 128, rows, 64]");
+  sh.kmajor = a_codes.dim() == 3;
+  int64_t w_rows;
+  if (sh.kmajor) {
+    TORCH_CHECK(a_codes.size(2) == 64 && w_codes.size(2) == 64 && a_codes.size(0) == w_codes.size(0) && w_codes.size(1) % 64 == 0 &&
+                    w_scales.dim() >= 1, what, ": k-major images must be [K / 128, rows, 64] with the same K and a weight image of a multiple of 64 rows");
+    sh.tokens = a_codes.size(1);
+    sh.outs = w_scales.size(0);
+    sh.k = a_codes.size(0) * 128;
+    w_rows = (sh.outs + 63) / 64 * 64;
+  } else {
+    sh.tokens = a_codes.size(0);
+    sh.outs = w_codes.size(0);
+    sh.k = a_codes.size(1) * 2;
+    w_rows = sh.outs;
+    TORCH_CHECK(w_codes.size(1) * 2 == sh.k, what, ": operand shapes mismatch");
+  }
+  TORCH_CHECK(a_scales.scalar_type() == at::kHalf && sh.k % 128 == 0, what, ": operand shapes / activation scale dtype mismatch");
+  const at::Device dev = a_codes.device();
+  check_operand((std::string(what) + "(activation)").c_str(), a_codes, a_scales, sh.tokens, sh.k / 2, sh.tokens * (sh.k / 128), dev);
+  check_operand((std::string(what) + "(weight)").c_str(), w_codes, w_scales, w_rows, sh.k / 2, sh.outs * (sh.k / 128), dev);
+  return sh;
+}
+
 // fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores, with the AdaLN block's gated residual in
 // the epilogue when given (tr/quant_utils.py:767, tr/basic_var.py:264): gemm.linear_fp4
 at::Tensor linear_fp4(const at::Tensor& a_codes, const at::Tensor& a_scales, const at::Tensor& w_codes, const at::Tensor& w_scales,
                       const c10::optional<at::Tensor>& bias, const c10::optional<at::Tensor>& gate, const c10::optional<at::Tensor>& residual) {
   require_gpu(a_codes, "linear_fp4");
-  TORCH_CHECK(a_codes.dim() == 2 && w_codes.dim() == 2, "linear_fp4: codes must be [rows, K / 2]");
-  const int64_t tokens = a_codes.size(0), outs = w_codes.size(0), k = a_codes.size(1) * 2;
-  TORCH_CHECK(w_codes.size(1) * 2 == k && a_scales.scalar_type() == at::kHalf && k % 128 == 0, "linear_fp4: operand shapes / activation scale dtype mismatch");
+  const Fp4Shapes sh = fp4_shapes("linear_fp4", a_codes, a_scales, w_codes, w_scales);
+  const int64_t tokens = sh.tokens, outs = sh.outs, k = sh.k;
   const at::Device dev = a_codes.device();
-  check_operand("linear_fp4(activation)", a_codes, a_scales, tokens, k / 2, tokens * (k / 128), dev);
-  check_operand("linear_fp4(weight)", w_codes, w_scales, outs, k / 2, outs * (k / 128), dev);
   fpq_gemm_epilogue_t ep{nullptr, nullptr, 1};
   at::Tensor g, r, b;
   at::Tensor out = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
@@ -402,9 +440,11 @@ at::Tensor linear_fp4(const at::Tensor& a_codes, const at::Tensor& a_scales, con
     b = aligned(bias->detach().to(at::kHalf).reshape({-1}).contiguous());
   }
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
-  check(fpq_gemm_fp4_mx_ex((const uint8_t*)a_codes.data_ptr(), a_scales.data_ptr(), (const uint8_t*)w_codes.data_ptr(), w_scales.data_ptr(),
-                           dtype_id(w_scales.scalar_type(), "linear_fp4"), b.defined() ? b.data_ptr() : nullptr, out.data_ptr(), tokens, outs, k,
-                           (gate.has_value() || residual.has_value()) ? &ep : nullptr, current_stream(a_codes)), "fpq_gemm_fp4_mx_ex");
+  check((sh.kmajor ? fpq_gemm_fp4_mx_km : fpq_gemm_fp4_mx_ex)(
+            (const uint8_t*)a_codes.data_ptr(), a_scales.data_ptr(), (const uint8_t*)w_codes.data_ptr(), w_scales.data_ptr(),
+            dtype_id(w_scales.scalar_type(), "linear_fp4"), b.defined() ? b.data_ptr() : nullptr, out.data_ptr(), tokens, outs, k,
+            (gate.has_value() || residual.has_value()) ? &ep : nullptr, current_stream(a_codes)),
+        sh.kmajor ? "fpq_gemm_fp4_mx_km" : "fpq_gemm_fp4_mx_ex");
   return out;
 }
 
@@ -414,13 +454,10 @@ std::tuple<at::Tensor, c10::optional<at::Tensor>> linear_fp4_gelu_dual(const at:
                                                                         const at::Tensor& w_scales, const c10::optional<at::Tensor>& bias,
                                                                         bool return_gelu) {
   require_gpu(a_codes, "linear_fp4_gelu_dual");
-  TORCH_CHECK(a_codes.dim() == 2 && w_codes.dim() == 2, "linear_fp4_gelu_dual: codes must be [rows, K / 2]");
-  const int64_t tokens = a_codes.size(0), outs = w_codes.size(0), k = a_codes.size(1) * 2;
-  TORCH_CHECK(w_codes.size(1) * 2 == k && a_scales.scalar_type() == at::kHalf && k % 128 == 0 && outs % 128 == 0,
-              "linear_fp4_gelu_dual: operand shapes / activation scale dtype mismatch (outs must be a multiple of 128)");
+  const Fp4Shapes sh = fp4_shapes("linear_fp4_gelu_dual", a_codes, a_scales, w_codes, w_scales);
+  const int64_t tokens = sh.tokens, outs = sh.outs, k = sh.k;
+  TORCH_CHECK(outs % 128 == 0, "linear_fp4_gelu_dual: outs must be a multiple of 128");
   const at::Device dev = a_codes.device();
-  check_operand("linear_fp4_gelu_dual(activation)", a_codes, a_scales, tokens, k / 2, tokens * (k / 128), dev);
-  check_operand("linear_fp4_gelu_dual(weight)", w_codes, w_scales, outs, k / 2, outs * (k / 128), dev);
   at::Tensor out = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
   c10::optional<at::Tensor> h;
   if (return_gelu) h = at::empty({tokens, outs}, a_codes.options().dtype(at::kHalf));
@@ -434,11 +471,12 @@ std::tuple<at::Tensor, c10::optional<at::Tensor>> linear_fp4_gelu_dual(const at:
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
   const fpq_stream_t st = current_stream(a_codes);
   at::Tensor scratch = nan_scratch(a_codes, st);
-  const int status = fpq_gemm_fp4_gelu_dual((const uint8_t*)a_codes.data_ptr(), a_scales.data_ptr(), (const uint8_t*)w_codes.data_ptr(), w_scales.data_ptr(),
-                                            dtype_id(w_scales.scalar_type(), "linear_fp4_gelu_dual"), b.defined() ? b.data_ptr() : nullptr, out.data_ptr(),
-                                            h.has_value() ? h->data_ptr() : nullptr, tokens, outs, k, scratch.data_ptr(), st);
+  const int status = (sh.kmajor ? fpq_gemm_fp4_gelu_dual_km : fpq_gemm_fp4_gelu_dual)(
+      (const uint8_t*)a_codes.data_ptr(), a_scales.data_ptr(), (const uint8_t*)w_codes.data_ptr(), w_scales.data_ptr(),
+      dtype_id(w_scales.scalar_type(), "linear_fp4_gelu_dual"), b.defined() ? b.data_ptr() : nullptr, out.data_ptr(),
+      h.has_value() ? h->data_ptr() : nullptr, tokens, outs, k, scratch.data_ptr(), st);
   if (status != 0) (void)hipMemsetAsync(scratch.data_ptr(), 0, 8, (hipStream_t)st);
-  check(status, "fpq_gemm_fp4_gelu_dual");
+  check(status, sh.kmajor ? "fpq_gemm_fp4_gelu_dual_km" : "fpq_gemm_fp4_gelu_dual");
   return {out, h};
 }
 
@@ -488,9 +526,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rotate_quant", &rotate_quant, py::arg("x"), py::arg("table_id"), py::arg("sign_mask"), py::arg("smooth") = py::none());
   m.def("adaln_rotate_quant", &adaln_rotate_quant, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("table_id"),
         py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
-  m.def("rotate_quant_mx", &rotate_quant_mx, py::arg("x"), py::arg("sign_mask"), py::arg("smooth") = py::none());
+  m.def("rotate_quant_mx", &rotate_quant_mx, py::arg("x"), py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("kmajor") = false);
   m.def("adaln_rotate_quant_mx", &adaln_rotate_quant_mx, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("sign_mask"),
-        py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
+        py::arg("smooth") = py::none(), py::arg("eps") = 1e-6, py::arg("kmajor") = false);
   m.def("adaln_rotate_quant_token", &adaln_rotate_quant_token, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("table_id"),
         py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
   m.def("adaln_rotate_quant_token_codes", &adaln_rotate_quant_token_codes, py::arg("x"), py::arg("scale"), py::arg("shift"),

@@ -50,8 +50,40 @@ def _epilogue(name: str, tokens: int, outs: int, gate: Optional[torch.Tensor], r
     return ctypes.byref(ep), keep, torch.empty((tokens, outs), dtype=torch.float16, device=device) if out is None else out
 
 
-def quantize_mx(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """x [..., K] fp16/fp32 (K % 128 == 0) -> (codes uint8 [rows, K/2], scales [rows, K/128] in x.dtype)."""
+# ---- k-major operand images (include/fpq.h): codes as [K / 128, image rows, 64 | 96] instead of [rows, row bytes] --------
+# A 3-D uint8 tensor IS an image, a 2-D one row-major codes: the Linears below pick the entry point from the operand's shape
+# (both operands must agree).  Weights: `to_kmajor(codes, bits, dealt=True)` once at load time; activations: the producers'
+# `kmajor=True` forms write the image directly (to_kmajor(codes, bits) converts any other producer's output).
+def to_kmajor(codes: torch.Tensor, code_bits: int, dealt: bool = False) -> torch.Tensor:
+    """Row-major operand codes [rows, K/2] (code_bits 4) or [rows, K*3/4] (6) -> the k-major image [K/128, image_rows, 64 | 96]
+    (fpq_codes_to_kmajor).  dealt: the weight side's row order, image_rows = rows rounded up to 64."""
+    require_gpu(codes, "to_kmajor")
+    seg = {4: 64, 6: 96}.get(code_bits)
+    if seg is None or codes.dim() != 2 or codes.dtype != torch.uint8 or codes.shape[1] % seg != 0:
+        raise RuntimeError("to_kmajor: codes must be uint8 [rows, K/2] (code_bits 4) or [rows, K*3/4] (6) with K % 128 == 0")
+    c = codes.contiguous()
+    rows, steps = c.shape[0], c.shape[1] // seg
+    image = torch.empty((steps, (rows + 63) // 64 * 64 if dealt else rows, seg), dtype=torch.uint8, device=c.device)
+    with device_guard(c.device):
+        check(lib().fpq_codes_to_kmajor(c.data_ptr(), image.data_ptr(), rows, steps * 128, code_bits, 1 if dealt else 0,
+                                        stream_ptr(c.device)), "fpq_codes_to_kmajor")
+    return image
+
+
+def _kmajor_pair(name: str, a: torch.Tensor, w: torch.Tensor, seg: int) -> bool:
+    """True when both operands are k-major images (3-D), False when both are row-major codes (2-D); anything else is an error."""
+    if a.dim() == 3 and w.dim() == 3:
+        if a.shape[2] != seg or w.shape[2] != seg or a.shape[0] != w.shape[0] or w.shape[1] % 64 != 0:
+            raise RuntimeError(f"{name}: k-major images must be [K/128, rows, {seg}] with the same K and a weight image of a multiple of 64 rows")
+        return True
+    if a.dim() == 2 and w.dim() == 2:
+        return False
+    raise RuntimeError(f"{name}: both operands must be row-major codes (2-D) or both k-major images (3-D)")
+
+
+def quantize_mx(x: torch.Tensor, kmajor: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [..., K] fp16/fp32 (K % 128 == 0) -> (codes uint8 [rows, K/2], scales [rows, K/128] in x.dtype).
+    kmajor: the codes as the activation side's k-major image [K/128, rows, 64] (same scales)."""
     require_gpu(x, "quantize_mx")
     if x.dtype not in (torch.float16, torch.float32):
         raise RuntimeError(f"quantize_mx: x must be float16 or float32, got {x.dtype}")
@@ -60,11 +92,12 @@ def quantize_mx(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         raise RuntimeError("quantize_mx: the last dimension must be a multiple of 128")
     xc = x.contiguous()
     rows = xc.numel() // k
-    codes = torch.empty((rows, k // 2), dtype=torch.uint8, device=x.device)
+    codes = torch.empty((k // 128, rows, 64) if kmajor else (rows, k // 2), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows, k // 128), dtype=x.dtype, device=x.device)
+    fn = lib().fpq_quant_rows_codes_mx_km if kmajor else lib().fpq_quant_rows_codes_mx
     with device_guard(x.device):
-        check(lib().fpq_quant_rows_codes_mx(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
-                                            dtype_id(x.dtype), stream_ptr(x.device)), "fpq_quant_rows_codes_mx")
+        check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k, dtype_id(x.dtype), stream_ptr(x.device)),
+              "fpq_quant_rows_codes_mx_km" if kmajor else "fpq_quant_rows_codes_mx")
     return codes, scales
 
 
@@ -112,22 +145,30 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores; with gate / residual the
     AdaLN block's `residual + y.mul(gate)` (tr/basic_var.py:264) is applied in the epilogue, bit-identical to the two
     torch ops on the plain result."""
-    if _native is not None:   # same checks, same C call (fpq_gemm_fp4_mx_ex)
+    if _native is not None:   # same checks, same C calls (fpq_gemm_fp4_mx_ex / fpq_gemm_fp4_mx_km)
         return _native.linear_fp4(a_codes, a_scales, w_codes, w_scales, bias, gate, residual)
     require_gpu(a_codes, "linear_fp4")
-    if a_codes.dim() != 2 or w_codes.dim() != 2:
-        raise RuntimeError("linear_fp4: codes must be [rows, K / 2]")
-    tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
-    if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16 or k % 128 != 0:
+    km = _kmajor_pair("linear_fp4", a_codes, w_codes, 64)
+    if km:
+        tokens, outs, k = a_codes.shape[1], w_scales.shape[0], a_codes.shape[0] * 128
+        w_rows = (outs + 63) // 64 * 64
+    else:
+        tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
+        w_rows = outs
+        if w_codes.shape[1] * 2 != k:
+            raise RuntimeError("linear_fp4: operand shapes mismatch")
+    if a_scales.dtype != torch.float16 or k % 128 != 0:
         raise RuntimeError("linear_fp4: operand shapes / activation scale dtype mismatch")
     _check_operand("linear_fp4(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), a_codes.device)
-    _check_operand("linear_fp4(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), a_codes.device)
+    _check_operand("linear_fp4(weight)", w_codes, w_scales, w_rows, k // 2, outs * (k // 128), a_codes.device)
     ep, keep, out = _epilogue("linear_fp4", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
+    if km and b is not None and b.data_ptr() % 16:
+        b = b.clone()
+    fn, what = (lib().fpq_gemm_fp4_mx_km, "fpq_gemm_fp4_mx_km") if km else (lib().fpq_gemm_fp4_mx_ex, "fpq_gemm_fp4_mx_ex")
     with device_guard(a_codes.device):
-        check(lib().fpq_gemm_fp4_mx_ex(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
-                                       dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
-                                       tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp4_mx_ex")
+        check(fn(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(), dtype_id(w_scales.dtype),
+                 None if b is None else b.data_ptr(), out.data_ptr(), tokens, outs, k, ep, stream_ptr(a_codes.device)), what)
     del keep
     return out
 
@@ -139,14 +180,18 @@ def linear_fp4_gelu_dual(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes:
     (tr/basic_var.py:120-121, tr/quant_utils.py:415-452,991) as the epilogue of the FP4 GEMM (fpq_gemm_fp4_gelu_dual):
     fp16 [tokens, outs], outs % 128 == 0.  return_gelu: also the GELU values the quantizer saw - the quantization is
     bit-exact on THOSE, they sit within one fp16 ulp of torch's GELU of the Linear output."""
-    if _native is not None:   # same checks, same C call, the binding's own NaN scratch
+    if _native is not None:   # same checks, same C calls, the binding's own NaN scratch
         out, h = _native.linear_fp4_gelu_dual(a_codes, a_scales, w_codes, w_scales, bias, return_gelu)
         return (out, h) if return_gelu else out
     require_gpu(a_codes, "linear_fp4_gelu_dual")
-    if a_codes.dim() != 2 or w_codes.dim() != 2:
-        raise RuntimeError("linear_fp4_gelu_dual: codes must be [rows, K / 2]")
-    tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
-    if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16 or k % 128 != 0 or outs % 128 != 0:
+    km = _kmajor_pair("linear_fp4_gelu_dual", a_codes, w_codes, 64)
+    if km:
+        tokens, outs, k = a_codes.shape[1], w_scales.shape[0], a_codes.shape[0] * 128
+    else:
+        tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
+        if w_codes.shape[1] * 2 != k:
+            raise RuntimeError("linear_fp4_gelu_dual: operand shapes mismatch")
+    if a_scales.dtype != torch.float16 or k % 128 != 0 or outs % 128 != 0:
         raise RuntimeError("linear_fp4_gelu_dual: operand shapes / activation scale dtype mismatch (outs must be a multiple of 128)")
     dev = a_codes.device
     _check_operand("linear_fp4_gelu_dual(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), dev)
@@ -164,10 +209,11 @@ def linear_fp4_gelu_dual(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes:
         from .ops import _nan_scratch
         with device_guard(dev):
             flag = _nan_scratch(dev)
-            check(lib().fpq_gemm_fp4_gelu_dual(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
-                                               dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
-                                               None if h is None else h.data_ptr(), tokens, outs, k, flag.data_ptr(),
-                                               stream_ptr(dev)), "fpq_gemm_fp4_gelu_dual")
+            fn = lib().fpq_gemm_fp4_gelu_dual_km if km else lib().fpq_gemm_fp4_gelu_dual
+            check(fn(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
+                     dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(),
+                     None if h is None else h.data_ptr(), tokens, outs, k, flag.data_ptr(),
+                     stream_ptr(dev)), "fpq_gemm_fp4_gelu_dual_km" if km else "fpq_gemm_fp4_gelu_dual")
     return (out, h) if return_gelu else out
 
 
@@ -186,10 +232,17 @@ class FP4Linear(_ScaledOperandModule):
         self.register_buffer("w_scales", w_scales)
         self.register_buffer("bias", bias)
 
+    @property
+    def kmajor(self) -> bool:
+        """the weight is held as a k-major image (to_kmajor(..., dealt=True)): activations must come as images too"""
+        return self.w_codes.dim() == 3
+
     @classmethod
-    def from_float(cls, module: torch.nn.Linear):
+    def from_float(cls, module: torch.nn.Linear, kmajor: bool = False):
         assert isinstance(module, torch.nn.Linear) and module.in_features % 128 == 0 and module.out_features % 8 == 0
         codes, scales = quantize_mx(module.weight.detach().float())
+        if kmajor:
+            codes = to_kmajor(codes, 4, dealt=True)
         bias = None if module.bias is None else module.bias.detach().to(torch.float16)
         return cls(codes, scales, bias, module.in_features, module.out_features)
 
@@ -197,7 +250,7 @@ class FP4Linear(_ScaledOperandModule):
     def forward(self, x, gate=None, residual=None):
         """gate / residual: the AdaLN block's `residual + y.mul(gate)` fused into the GEMM (see linear_fp4)."""
         lead = x.shape[:-1]
-        a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features))
+        a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features), kmajor=self.kmajor)
         y = linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual)
         return y.view(*lead, self.out_features)
 
@@ -218,7 +271,7 @@ class FP4LinearGeluDual(FP4Linear):
     @torch.no_grad()
     def forward(self, x):
         lead = x.shape[:-1]
-        a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features))
+        a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features), kmajor=self.kmajor)
         return linear_fp4_gelu_dual(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)
 
     @torch.no_grad()
@@ -305,9 +358,10 @@ class FP8Linear(_ScaledOperandModule):
 
 
 # ---- the same with 6-bit packed operands (FP6 E2M3 on both sides: the W6A6 run configuration) ---------------------
-def quantize_fp6(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def quantize_fp6(x: torch.Tensor, kmajor: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """x [..., K] fp16/fp32 (K % 32 == 0) -> (codes uint8 [rows, K * 3 / 4]: dense 6-bit E2M3 codes,
-    scales [rows] in x.dtype); e2m3(code) * scale == fp6_quant_e2m3_per_token_cuda(x)."""
+    scales [rows] in x.dtype); e2m3(code) * scale == fp6_quant_e2m3_per_token_cuda(x).
+    kmajor (K % 128 == 0): the codes as the activation side's k-major image [K/128, rows, 96]."""
     require_gpu(x, "quantize_fp6")
     if x.dtype not in (torch.float16, torch.float32):
         raise RuntimeError(f"quantize_fp6: x must be float16 or float32, got {x.dtype}")
@@ -317,12 +371,14 @@ def quantize_fp6(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         raise RuntimeError("quantize_fp6: the last dimension must be a multiple of 32")
     xc = x.contiguous()
     rows = xc.numel() // k
-    codes = torch.empty((rows, k * 3 // 4), dtype=torch.uint8, device=x.device)
+    if kmajor and k % 128 != 0:
+        raise RuntimeError("quantize_fp6(kmajor=True): the last dimension must be a multiple of 128")
+    codes = torch.empty((k // 128, rows, 96) if kmajor else (rows, k * 3 // 4), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows,), dtype=x.dtype, device=x.device)
+    fn = lib().fpq_quant_rows_codes_fp6_km if kmajor else lib().fpq_quant_rows_codes_fp6
     with device_guard(x.device):
-        check(lib().fpq_quant_rows_codes_fp6(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k,
-                                             TABLE_IDS["e2m3"], dtype_id(x.dtype), stream_ptr(x.device)),
-              "fpq_quant_rows_codes_fp6")
+        check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k, TABLE_IDS["e2m3"], dtype_id(x.dtype),
+                 stream_ptr(x.device)), "fpq_quant_rows_codes_fp6_km" if kmajor else "fpq_quant_rows_codes_fp6")
     return codes, scales
 
 
@@ -343,19 +399,24 @@ def linear_fp6(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP6 matrix cores (row-scaled operands); optional
     fused `residual + y.mul(gate)` as in linear_fp4."""
     require_gpu(a_codes, "linear_fp6")
-    if a_codes.dim() != 2 or w_codes.dim() != 2:
-        raise RuntimeError("linear_fp6: codes must be [rows, K * 3 / 4]")
-    tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 4 // 3
-    if w_codes.shape[1] != a_codes.shape[1] or a_codes.shape[1] % 3 != 0:
-        raise RuntimeError("linear_fp6: operand shapes mismatch")
-    _check_operand("linear_fp6(activation)", a_codes, a_scales, tokens, a_codes.shape[1], tokens, a_codes.device)
-    _check_operand("linear_fp6(weight)", w_codes, w_scales, outs, a_codes.shape[1], outs, a_codes.device)
+    km = _kmajor_pair("linear_fp6", a_codes, w_codes, 96)
+    if km:
+        tokens, outs, k = a_codes.shape[1], w_scales.shape[0], a_codes.shape[0] * 128
+        w_rows, row_bytes = (outs + 63) // 64 * 64, a_codes.shape[0] * 96
+    else:
+        tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 4 // 3
+        w_rows, row_bytes = outs, a_codes.shape[1]
+        if w_codes.shape[1] != a_codes.shape[1] or a_codes.shape[1] % 3 != 0:
+            raise RuntimeError("linear_fp6: operand shapes mismatch")
+    _check_operand("linear_fp6(activation)", a_codes, a_scales, tokens, row_bytes, tokens, a_codes.device)
+    _check_operand("linear_fp6(weight)", w_codes, w_scales, w_rows, row_bytes, outs, a_codes.device)
     ep, keep, out = _epilogue("linear_fp6", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
+    fn, what = (lib().fpq_gemm_fp6_rows_km, "fpq_gemm_fp6_rows_km") if km else (lib().fpq_gemm_fp6_rows_ex, "fpq_gemm_fp6_rows_ex")
     with device_guard(a_codes.device):
-        check(lib().fpq_gemm_fp6_rows_ex(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(),
-                                         w_scales.data_ptr(), dtype_id(w_scales.dtype), None if b is None else b.data_ptr(),
-                                         out.data_ptr(), tokens, outs, k, ep, stream_ptr(a_codes.device)), "fpq_gemm_fp6_rows_ex")
+        check(fn(a_codes.data_ptr(), a_scales.data_ptr(), dtype_id(a_scales.dtype), w_codes.data_ptr(), w_scales.data_ptr(),
+                 dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), out.data_ptr(), tokens, outs, k, ep,
+                 stream_ptr(a_codes.device)), what)
     del keep
     return out
 
@@ -370,15 +431,21 @@ class FP6Linear(_ScaledOperandModule):
         self.register_buffer("w_scales", w_scales)
         self.register_buffer("bias", bias)
 
+    @property
+    def kmajor(self) -> bool:
+        return self.w_codes.dim() == 3
+
     @classmethod
-    def from_float(cls, module: torch.nn.Linear):
+    def from_float(cls, module: torch.nn.Linear, kmajor: bool = False):
         assert isinstance(module, torch.nn.Linear) and module.in_features % 128 == 0 and module.out_features % 8 == 0
         codes, scales = quantize_fp6(module.weight.detach().float())
+        if kmajor:
+            codes = to_kmajor(codes, 6, dealt=True)
         bias = None if module.bias is None else module.bias.detach().to(torch.float16)
         return cls(codes, scales, bias, module.in_features, module.out_features)
 
     @torch.no_grad()
     def forward(self, x, gate=None, residual=None):
         lead = x.shape[:-1]
-        a_codes, a_scales = quantize_fp6(x.to(torch.float16).reshape(-1, self.in_features))
+        a_codes, a_scales = quantize_fp6(x.to(torch.float16).reshape(-1, self.in_features), kmajor=self.kmajor)
         return linear_fp6(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual).view(*lead, self.out_features)

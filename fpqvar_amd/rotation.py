@@ -291,32 +291,35 @@ def _smooth_ptr(smooth, c, device):
     return sm, sm.data_ptr()
 
 
-def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None
-                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None,
+                    kmajor: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """rotate_quant(x, "e2m1") emitting the FP4 GEMM's operands instead of values:
-    (codes uint8 [rows, C/2], scales fp16 [rows, C/128]); level(code) * scale == rotate_quant(x) bit for bit."""
+    (codes uint8 [rows, C/2], scales fp16 [rows, C/128]); level(code) * scale == rotate_quant(x) bit for bit.
+    kmajor: the codes as the activation side's k-major image [C/128, rows, 64] (gemm.to_kmajor; same scales)."""
     require_gpu(x, "rotate_quant_mx")
     if x.dtype not in (torch.float16, torch.float32) or x.shape[-1] % 128 != 0:
         raise RuntimeError("rotate_quant_mx: x must be float16/float32 with a last dimension that is a multiple of 128")
     c = x.shape[-1]
     rows = x.numel() // c
     if _native_ok(x, d, smooth, c):
-        return _native.rotate_quant_mx(x, _default_mask_tuple(), smooth)
+        return _native.rotate_quant_mx(x, _default_mask_tuple(), smooth, kmajor)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
-    codes = torch.empty((rows, c // 2), dtype=torch.uint8, device=x.device)
+    codes = torch.empty((c // 128, rows, 64) if kmajor else (rows, c // 2), dtype=torch.uint8, device=x.device)
     scales = torch.empty((rows, c // 128), dtype=torch.float16, device=x.device)
+    fn = lib().fpq_rotate_quant_rows_codes_mx_km if kmajor else lib().fpq_rotate_quant_rows_codes_mx
     with device_guard(x.device):
-        check(lib().fpq_rotate_quant_rows_codes_mx(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c,
-                                                   dtype_id(x.dtype), sm_ptr, mask, stream_ptr(x.device)),
-              "fpq_rotate_quant_rows_codes_mx")
+        check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c, dtype_id(x.dtype), sm_ptr, mask, stream_ptr(x.device)),
+              "fpq_rotate_quant_rows_codes_mx_km" if kmajor else "fpq_rotate_quant_rows_codes_mx")
     return codes, scales
 
 
 def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, d: Optional[torch.Tensor] = None,
-                          smooth: Optional[torch.Tensor] = None, eps: float = 1e-6) -> Tuple[torch.Tensor, torch.Tensor]:
-    """adaln_rotate_quant(x, scale, shift, "e2m1") emitting (codes uint8 [B*L, C/2], scales fp16 [B*L, C/128])."""
+                          smooth: Optional[torch.Tensor] = None, eps: float = 1e-6, kmajor: bool = False
+                          ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """adaln_rotate_quant(x, scale, shift, "e2m1") emitting (codes uint8 [B*L, C/2], scales fp16 [B*L, C/128]).
+    kmajor (C <= 2560): the codes as the activation side's k-major image [C/128, B*L, 64]."""
     require_gpu(x, "adaln_rotate_quant_mx")
     if x.dim() != 3:
         raise RuntimeError("adaln_rotate_quant_mx: x must be [B, L, C]")
@@ -328,27 +331,28 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
     sc = _mod_rows(scale, bsz, c)
     sh = _mod_rows(shift, bsz, c)
     if sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c):
-        return _native.adaln_rotate_quant_mx(x, sc, sh, _default_mask_tuple(), smooth, float(eps))
+        return _native.adaln_rotate_quant_mx(x, sc, sh, _default_mask_tuple(), smooth, float(eps), kmajor)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
-    codes = torch.empty((bsz * seq, c // 2), dtype=torch.uint8, device=x.device)
+    codes = torch.empty((c // 128, bsz * seq, 64) if kmajor else (bsz * seq, c // 2), dtype=torch.uint8, device=x.device)
     scales = torch.empty((bsz * seq, c // 128), dtype=torch.float16, device=x.device)
+    fn = lib().fpq_adaln_rotate_quant_rows_codes_mx_km if kmajor else lib().fpq_adaln_rotate_quant_rows_codes_mx
     with device_guard(x.device):
-        check(lib().fpq_adaln_rotate_quant_rows_codes_mx(
-            xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), bsz * seq, c, dtype_id(x.dtype), sc.data_ptr(),
-            sh.data_ptr(), dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, stream_ptr(x.device)),
-            "fpq_adaln_rotate_quant_rows_codes_mx")
+        check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), bsz * seq, c, dtype_id(x.dtype), sc.data_ptr(),
+                 sh.data_ptr(), dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, stream_ptr(x.device)),
+              "fpq_adaln_rotate_quant_rows_codes_mx_km" if kmajor else "fpq_adaln_rotate_quant_rows_codes_mx")
     return codes, scales
 
 
 def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, table: str = "e2m3",
                              d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None, eps: float = 1e-6,
-                             emit: str = "values"):
+                             emit: str = "values", kmajor: bool = False):
     """The fused producer for the per-token configurations (W6A6): LayerNorm, modulate, smooth, rotate, then
     fp6_quant_*_per_token_cuda with one scale per token row.  emit="values": fp16 [B, L, C];
     emit="fp8": (codes uint8 [B*L, C], scales fp16 [B*L]) for gemm.linear_fp8; emit="fp6" (table e2m3 only):
-    (dense 6-bit codes uint8 [B*L, C * 3 / 4], scales) for gemm.linear_fp6.  C <= 2560."""
+    (dense 6-bit codes uint8 [B*L, C * 3 / 4], scales) for gemm.linear_fp6.  C <= 2560.
+    kmajor (emit="fp6" only): the codes as the activation side's k-major image [C/128, B*L, 96]."""
     require_gpu(x, "adaln_rotate_quant_token")
     if x.dim() != 3:
         raise RuntimeError("adaln_rotate_quant_token: x must be [B, L, C]")
@@ -363,7 +367,9 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
         raise RuntimeError(f"adaln_rotate_quant_token: unknown emit {emit!r}")
     if emit == "fp6" and table != "e2m3":
         raise RuntimeError("adaln_rotate_quant_token: emit='fp6' is the E2M3 operand format")
-    if sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c):
+    if kmajor and emit != "fp6":
+        raise RuntimeError("adaln_rotate_quant_token: kmajor is a layout of the FP6 operand codes (emit='fp6')")
+    if sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c) and not kmajor:
         if emit == "values":
             return _native.adaln_rotate_quant_token(x, sc, sh, TABLE_IDS[table], _default_mask_tuple(), smooth, float(eps))
         return _native.adaln_rotate_quant_token_codes(x, sc, sh, TABLE_IDS[table], 8 if emit == "fp8" else 6, _default_mask_tuple(),
@@ -376,9 +382,11 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
         if emit in ("fp8", "fp6"):
             if emit == "fp6" and table != "e2m3":
                 raise RuntimeError("adaln_rotate_quant_token: emit='fp6' is the E2M3 operand format")
-            codes = torch.empty((rows, c if emit == "fp8" else c * 3 // 4), dtype=torch.uint8, device=x.device)
+            codes = torch.empty((c // 128, rows, 96) if kmajor else (rows, c if emit == "fp8" else c * 3 // 4), dtype=torch.uint8,
+                                device=x.device)
             scales = torch.empty((rows,), dtype=torch.float16, device=x.device)
             fn = (lib().fpq_adaln_rotate_quant_token_rows_codes_fp8 if emit == "fp8"
+                  else lib().fpq_adaln_rotate_quant_token_rows_codes_fp6_km if kmajor
                   else lib().fpq_adaln_rotate_quant_token_rows_codes_fp6)
             check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c, dtype_id(x.dtype), sc.data_ptr(), sh.data_ptr(),
                      dtype_id(sc.dtype), seq, float(eps), sm_ptr, mask, TABLE_IDS[table], stream_ptr(x.device)),

@@ -24,10 +24,12 @@
 extern "C" {
 #endif
 
-#define FPQ_VERSION 124 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
+#define FPQ_VERSION 125 /* 0.1.2: + fpq_quant_tensor_argmin, fpq_quant_rows_segments, fpq_quant_rows_multi (round 2);
                            0.1.3: + fpq_quant_rows_codes_segments, fpq_dequant_rows_codes_segments (round 3);
                            123: + fpq_build_tag (round 4);
-                           124: + fpq_set_option, fpq_get_option, fpq_option_name, fpq_gemm_fp4_gelu_dual, fpq_gelu_quant_rows_dual (round 5) */
+                           124: + fpq_set_option, fpq_get_option, fpq_option_name, fpq_gemm_fp4_gelu_dual, fpq_gelu_quant_rows_dual (round 5);
+                           125: + k-major operand images: fpq_codes_to_kmajor, fpq_gemm_fp4_mx_km, fpq_gemm_fp4_gelu_dual_km,
+                                fpq_gemm_fp6_rows_km and the *_km producers (round 5) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -427,6 +429,58 @@ int fpq_gemm_fp8_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_sca
                          const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
                          int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
 int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_scale_dtype, const uint8_t* w_codes,
+                         const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
+                         int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
+
+/* ---- K-MAJOR OPERAND IMAGES ------------------------------------------------------------------------------------------
+ * The FP4 and FP6 matrix-core GEMMs above read ROW-MAJOR code tensors [rows, k/2] / [rows, k*3/4]; per K step of 128
+ * elements their LDS-DMA engine then gathers 64 / 96 bytes out of each of 384 rows that lie a whole row apart, and issuing
+ * those gathers is what bounds them (profiles/r05_gemm6_stamps.txt, r05_lds_dma_issue.txt: 100 - 150 cycles per 1 KiB
+ * piece against 65 - 70 for a contiguous one).  The *_km entry points take the same codes as a K-MAJOR IMAGE instead:
+ *
+ *     image[(s * image_rows + j) * seg + p * 16 + b]      s = K step (k / 128 of them), j = image row, seg = 64 (FP4) or
+ *                                                          96 (FP6) bytes, p = 16-byte chunk inside the segment, b = byte
+ *   = codes[row(j), s * seg + c(j, p) * 16 + b]
+ *
+ *   chunk order (the GEMM's bank-conflict-free LDS image, so that a DMA piece is one linear 1 KiB copy):
+ *     FP4: c = p ^ pi(j & 15),  pi(q) = (0, 2, 3, 1)[q >> 2]          FP6: c = (p - ((j >> 3) & 1)) mod 6
+ *   activation side: image_rows = rows, row(j) = j (no padding: the image has exactly the row-major tensor's size);
+ *   weight side ("dealt", the order the kernels hand a wavefront's 64 outputs to its four 16-row tiles):
+ *     image_rows = rows rounded up to 64, row(j) = (j & ~63) + 4 * (j & 15) + ((j >> 4) & 3), zero where row(j) >= rows.
+ *
+ * Same arithmetic, same results bit for bit (tests/test_gpu_kmajor.py); scales, bias, out and the epilogue are unchanged.
+ * fpq_codes_to_kmajor converts row-major codes (weights once at load time; any producer's output as a fallback); the
+ * *_km producers below write the activation image directly.  code_bits: 4 or 6; all pointers 16-byte aligned. */
+int fpq_codes_to_kmajor(const uint8_t* codes, uint8_t* image, int64_t rows, int64_t k, int code_bits, int dealt,
+                        fpq_stream_t stream);
+/* fpq_gemm_fp4_mx_ex / fpq_gemm_fp4_gelu_dual / fpq_gemm_fp6_rows_ex on k-major images (a_image: activation side,
+ * w_image: dealt weight side).  bias must be 8-byte aligned; k limited by the LDS-DMA kernels' scale tiles (FP4: the
+ * row-major entry point falls back to a register-staged kernel for very long k, this one returns FPQ_ERR_SHAPE). */
+int fpq_gemm_fp4_mx_km(const uint8_t* a_image, const void* a_scales, const uint8_t* w_image, const void* w_scales,
+                       int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
+                       const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
+int fpq_gemm_fp4_gelu_dual_km(const uint8_t* a_image, const void* a_scales, const uint8_t* w_image, const void* w_scales,
+                              int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
+                              int64_t k, void* nan_flag, fpq_stream_t stream);
+/* The activation producers writing the k-major image directly (same arguments and scales as the forms without _km;
+ * image: rows * cols / 2 bytes (FP4) or rows * cols * 3 / 4 (FP6), below 2 GiB, 16-byte aligned; cols % 128 == 0).
+ * fpq_quant_rows_codes_mx_km: fp16 rows only.  The fused adaLN / rotation producers: the matrix-core forms only (rows of up
+ * to 2560 channels for adaLN), FPQ_ERR_SHAPE otherwise - use the row-major producer + fpq_codes_to_kmajor there. */
+int fpq_quant_rows_codes_mx_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                               fpq_stream_t stream);
+int fpq_rotate_quant_rows_codes_mx_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols, int in_dtype,
+                                      const float* smooth, const uint32_t* sign_mask_host, fpq_stream_t stream);
+int fpq_adaln_rotate_quant_rows_codes_mx_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols,
+                                            int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                            int64_t rows_per_batch, float eps, const float* smooth,
+                                            const uint32_t* sign_mask_host, fpq_stream_t stream);
+int fpq_quant_rows_codes_fp6_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols, int table_id,
+                                int in_dtype, fpq_stream_t stream);
+int fpq_adaln_rotate_quant_token_rows_codes_fp6_km(const void* x, uint8_t* image, void* row_scales, int64_t rows, int64_t cols,
+                                                   int in_dtype, const void* scale, const void* shift, int mod_dtype,
+                                                   int64_t rows_per_batch, float eps, const float* smooth,
+                                                   const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
+int fpq_gemm_fp6_rows_km(const uint8_t* a_image, const void* a_scales, int a_scale_dtype, const uint8_t* w_image,
                          const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
                          int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
 
