@@ -417,6 +417,10 @@ def other_kernels(dev):
         s = torch.rand(COLS, device=dev, generator=g) + 0.5
         hbm("adaln_rotate_quant_codes_mx_fp16_65500x1920",
             timed(lambda: rot.adaln_rotate_quant_mx(nxt(xa), scale, shift, smooth=s)), na * (2 + wr4))
+        hbm("adaln_rotate_quant_codes_mx_kmajor_fp16_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant_mx(nxt(xa), scale, shift, smooth=s, kmajor=True)), na * (2 + wr4))
+        hbm("adaln_rotate_quant_token_codes_fp6_kmajor_fp16_65500x1920",
+            timed(lambda: rot.adaln_rotate_quant_token(nxt(xa), scale, shift, "e2m3", smooth=s, emit="fp6", kmajor=True)), na * (2 + 0.75) + B * L * 2)
         hbm("adaln_rotate_quant_token_codes_fp8_fp16_65500x1920",
             timed(lambda: rot.adaln_rotate_quant_token(nxt(xa), scale, shift, "e2m3", smooth=s, emit="fp8")), na * (2 + 1) + B * L * 2)
         hbm("adaln_rotate_quant_token_codes_fp6_fp16_65500x1920",
@@ -452,13 +456,20 @@ def other_kernels(dev):
                         "TFLOPs_min_burst": round(2.0 * ROWS * COLS * 3 * COLS / t.min_burst / 1e9, 1)}
 
         flops("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", timed(lambda: gemm.linear_fp4(*a, *w)))
-        del a, w
+        # the same codes as k-major operand images (include/fpq.h): every LDS-DMA piece of the GEMM is 1 KiB contiguous
+        ak, wk = (gemm.to_kmajor(a[0], 4), a[1]), (gemm.to_kmajor(w[0], 4, dealt=True), w[1])
+        flops("gemm_fp4_w4a4_mat_qkv_65536x1920x5760_kmajor", timed(lambda: gemm.linear_fp4(*ak, *wk)))
+        del a, w, ak, wk
         # the W6A6 pair (per token x per channel): the 6-bit packed form and the E4M3-byte form of the same instruction
         wf = torch.randn(3 * COLS, COLS, device=dev, generator=g) * 0.02
         for tag, quant, lin in (("gemm_fp6_w6a6_mat_qkv_65536x1920x5760", gemm.quantize_fp6, gemm.linear_fp6),
                                 ("gemm_fp8_rows_mat_qkv_65536x1920x5760", gemm.quantize_fp8, gemm.linear_fp8)):
             a, w = quant(x), quant(wf)
             flops(tag, timed(lambda: lin(*a, *w)))
+            if "fp6" in tag:
+                ak, wk = (gemm.to_kmajor(a[0], 6), a[1]), (gemm.to_kmajor(w[0], 6, dealt=True), w[1])
+                flops(tag + "_kmajor", timed(lambda: lin(*ak, *wk)))
+                del ak, wk
             del a, w
 
     def configs():

@@ -53,11 +53,12 @@ __global__ __launch_bounds__(kBlock) void rows16_codes6_wave_kernel(const uint16
           if ((bit & 31) + 48 > 64) o[(bit >> 5) + 2] |= (uint32_t)(p48 >> (64 - (bit & 31)));
         }
         if (km_rows) {   // k-major image (include/fpq.h): block b = bytes 24 (b & 3) .. + 23 of K step b >> 2, three 8-byte halves of chunks
+          // (plain stores: a row leaves 96 bytes per plane, the workgroup's four consecutive rows fill three whole 128-byte lines
+          // between them - L2 has to be allowed to merge them; streamed past it the partial lines cost 2 x the kernel's time)
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const uint32_t w = 24u * ((uint32_t)b & 3u) + 8u * j;
-            u32x2* dst = (u32x2*)(codes + km6_off((uint32_t)row, (uint32_t)b >> 2, w >> 4, km_rows) + (w & 15u));
-            __builtin_nontemporal_store(u32x2{o[2 * j], o[2 * j + 1]}, dst);
+            *(u32x2*)(codes + km6_off((uint32_t)row, (uint32_t)b >> 2, w >> 4, km_rows) + (w & 15u)) = u32x2{o[2 * j], o[2 * j + 1]};
           }
         } else {
           u32x2* dst = (u32x2*)(codes + row * (nblk * 24) + b * 24);

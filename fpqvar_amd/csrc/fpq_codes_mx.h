@@ -14,17 +14,29 @@ __global__ __launch_bounds__(kBlock) void rows16_codes_mx_kernel(const u32x4* __
     lut16_stage(lut, tab, a.shift);
     __syncthreads();
   }
+  if (km_rows) {
+    // k-major image (include/fpq.h): a workgroup's 256 vectors are ONE group of 16 consecutive rows (16 lanes per row as before), so
+    // that what it writes - 64 bytes per row into the group's plane - is 1 KiB in a row; a flat run of 16 groups would scatter 64-byte
+    // halves of lines over 15 planes, with the other half written by a workgroup on another XCD.  unit u = row block u / G, group u % G.
+    const uint32_t G = groups_per_row.d, lane16 = threadIdx.x & 15u, row_in = threadIdx.x >> 4;
+    const uint32_t units = ((km_rows + 15u) >> 4) * G;
+    for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {
+      const uint32_t rb = fast_div_q(u, groups_per_row), g = u - rb * G, t = rb * 16u + row_in;
+      if (t >= km_rows) continue;   // whole 16-lane clusters drop out
+      const int64_t v = ((int64_t)t * G + g) * 16 + lane16;
+      const u32x4 w = __builtin_nontemporal_load(x + v);
+      const uint32_t m = row_max_dpp<16>(vec_absmax16(w));
+      const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
+      if (lane16 == 0) scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
+      codes[(km4_off(t, g, lane16 >> 2, km_rows) >> 2) + (lane16 & 3u)] = codes_vec16(w, lut, a.shift, s.inv, s.inv_lo);
+    }
+    return;
+  }
   for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * kBlock) {
     const u32x4 w = __builtin_nontemporal_load(x + v);
     const uint32_t m = row_max_dpp<16>(vec_absmax16(w));
     const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
     if ((threadIdx.x & 15) == 0) scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
-    const uint32_t packed = codes_vec16(w, lut, a.shift, s.inv, s.inv_lo);
-    if (km_rows) {   // k-major image (include/fpq.h): vector v = 4 bytes at byte 4 (v & 15) of group (v >> 4) % G of row (v >> 4) / G
-      const uint32_t gi = (uint32_t)(v >> 4), t = fast_div_q(gi, groups_per_row), g = gi - t * groups_per_row.d;
-      codes[(km4_off(t, g, ((uint32_t)v & 15u) >> 2, km_rows) >> 2) + ((uint32_t)v & 3u)] = packed;
-    } else {
-      codes[v] = packed;
-    }
+    codes[v] = codes_vec16(w, lut, a.shift, s.inv, s.inv_lo);
   }
 }

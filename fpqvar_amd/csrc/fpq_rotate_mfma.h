@@ -246,6 +246,11 @@ __device__ __forceinline__ uint32_t rq_lut_pair(const uint16_t* lut, uint32_t u,
 __device__ __forceinline__ uint32_t rq_km4_off(uint32_t t, uint32_t g, bool live, int lane, uint32_t km_rows) {
   return live ? km4_off(t, g, (uint32_t)lane & 3u, km_rows) : 0xFFFFFFFFu;
 }
+// 16 bytes of operand codes out, non-temporal in both layouts (measured for the k-major image too: with plain stores the adaLN
+// producer is 8 - 13 % slower at 10 000+ rows, profiles/r05_kmajor_ab.txt - unlike the stand-alone FP6 quantizer, fpq_codes_fp6.h).
+__device__ __forceinline__ void rq_store_code_chunk(const u32x4& o, __amdgpu_buffer_rsrc_t dst, uint32_t off) {
+  __builtin_amdgcn_raw_buffer_store_b128(o, dst, off, 0, kRqNt);
+}
 template <typename OffFn>
 __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[8][2], const RowScale16& s,
                                                const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t codes_dst,
@@ -270,7 +275,7 @@ __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[
   lane = rq_opaque(lane);
   const int gg = lane >> 2, j = lane & 3;
   const u32x4 o = buf[gg * 4 + (j ^ ((gg >> 2) & 3))];
-  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, code_off(lane), 0, kRqNt);
+  rq_store_code_chunk(o, codes_dst, code_off(lane));
   if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
   __builtin_amdgcn_wave_barrier();
 }
@@ -300,7 +305,7 @@ __device__ __forceinline__ void rq_store_codes_hw(char* img, const uint32_t (&yw
   }
   __builtin_amdgcn_wave_barrier();
   const u32x4 o = *(const u32x4*)(img + (lane >> 2) * kRqCodeStride + (lane & 3) * 16);   // chunk lane % 4 of group lane / 4
-  __builtin_amdgcn_raw_buffer_store_b128(o, codes_dst, code_off(rq_opaque(lane)), 0, kRqNt);
+  rq_store_code_chunk(o, codes_dst, code_off(rq_opaque(lane)));
   if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
   __builtin_amdgcn_wave_barrier();
 }
@@ -364,8 +369,8 @@ __device__ __forceinline__ void rq_store_codes6(u32x4* buf, const uint32_t (&yw)
   }
   __builtin_amdgcn_wave_barrier();
   lane = rq_opaque(lane);
-  __builtin_amdgcn_raw_buffer_store_b128(buf[lane], dst, off(lane), 0, kRqNt);   // chunk `lane` of the tile's 96: row-major lane * 16
-  if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(buf[64 + lane], dst, off(64 + lane), 0, kRqNt);   // chunk 64 + lane: row-major 1024 + lane * 16
+  rq_store_code_chunk(buf[lane], dst, off(lane));   // chunk `lane` of the tile's 96: row-major lane * 16
+  if (lane < 32) rq_store_code_chunk(buf[64 + lane], dst, off(64 + lane));   // chunk 64 + lane: row-major 1024 + lane * 16
   __builtin_amdgcn_wave_barrier();
 }
 

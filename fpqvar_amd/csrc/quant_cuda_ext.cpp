@@ -329,14 +329,18 @@ at::Tensor adaln_rotate_quant_token(const at::Tensor& x, const at::Tensor& scale
 std::tuple<at::Tensor, at::Tensor> adaln_rotate_quant_token_codes(const at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift,
                                                                   int64_t table_id, int64_t code_bits,
                                                                   const std::array<uint32_t, 4>& sign_mask,
-                                                                  const c10::optional<at::Tensor>& smooth, double eps) {
+                                                                  const c10::optional<at::Tensor>& smooth, double eps, bool kmajor) {
   const ProducerArgs a = producer_checks("adaln_rotate_quant_token_codes", x, &scale, &shift, smooth, 2560);
   TORCH_CHECK(code_bits == 8 || (code_bits == 6 && table_id == FPQ_E2M3), "adaln_rotate_quant_token_codes: E4M3 bytes (8) or dense E2M3 codes (6)");
+  TORCH_CHECK(!kmajor || code_bits == 6, "adaln_rotate_quant_token_codes: kmajor is a layout of the dense 6-bit codes");
   const int64_t rows = a.b * a.l;
-  at::Tensor codes = at::empty({rows, code_bits == 8 ? a.c : a.c * 3 / 4}, x.options().dtype(at::kByte));
+  at::Tensor codes = kmajor ? at::empty({a.c / 128, rows, 96}, x.options().dtype(at::kByte))   // the activation side's k-major image (include/fpq.h)
+                            : at::empty({rows, code_bits == 8 ? a.c : a.c * 3 / 4}, x.options().dtype(at::kByte));
   at::Tensor scales = at::empty({rows}, x.options().dtype(at::kHalf));
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
-  const auto fn = code_bits == 8 ? fpq_adaln_rotate_quant_token_rows_codes_fp8 : fpq_adaln_rotate_quant_token_rows_codes_fp6;
+  const auto fn = code_bits == 8 ? fpq_adaln_rotate_quant_token_rows_codes_fp8
+                  : kmajor       ? fpq_adaln_rotate_quant_token_rows_codes_fp6_km
+                                 : fpq_adaln_rotate_quant_token_rows_codes_fp6;
   check(fn(x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c, dtype_id(x.scalar_type(), "adaln_rotate_quant_token_codes"),
            scale.data_ptr(), shift.data_ptr(), dtype_id(scale.scalar_type(), "adaln_rotate_quant_token_codes"), a.l, (float)eps, a.smooth,
            sign_mask.data(), (int)table_id, current_stream(x)), "fpq_adaln_rotate_quant_token_rows_codes");
@@ -532,7 +536,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("adaln_rotate_quant_token", &adaln_rotate_quant_token, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("table_id"),
         py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
   m.def("adaln_rotate_quant_token_codes", &adaln_rotate_quant_token_codes, py::arg("x"), py::arg("scale"), py::arg("shift"),
-        py::arg("table_id"), py::arg("code_bits"), py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6);
+        py::arg("table_id"), py::arg("code_bits"), py::arg("sign_mask"), py::arg("smooth") = py::none(), py::arg("eps") = 1e-6,
+        py::arg("kmajor") = false);
   m.def("kv_cache_step", &kv_cache_step, py::arg("cache"), py::arg("quant_start"), py::arg("quant_stop"), py::arg("k"), py::arg("v"),
         py::arg("new_start"), py::arg("group"), py::arg("table_id"));
   m.def("linear_fp4", &linear_fp4, py::arg("a_codes"), py::arg("a_scales"), py::arg("w_codes"), py::arg("w_scales"),

@@ -369,11 +369,11 @@ def adaln_rotate_quant_token(x: torch.Tensor, scale: torch.Tensor, shift: torch.
         raise RuntimeError("adaln_rotate_quant_token: emit='fp6' is the E2M3 operand format")
     if kmajor and emit != "fp6":
         raise RuntimeError("adaln_rotate_quant_token: kmajor is a layout of the FP6 operand codes (emit='fp6')")
-    if sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c) and not kmajor:
+    if sc.device == x.device and sh.device == x.device and _native_ok(x, d, smooth, c):
         if emit == "values":
             return _native.adaln_rotate_quant_token(x, sc, sh, TABLE_IDS[table], _default_mask_tuple(), smooth, float(eps))
         return _native.adaln_rotate_quant_token_codes(x, sc, sh, TABLE_IDS[table], 8 if emit == "fp8" else 6, _default_mask_tuple(),
-                                                      smooth, float(eps))
+                                                      smooth, float(eps), kmajor)
     mask = _mask_arg(d)
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)

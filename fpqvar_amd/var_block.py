@@ -108,7 +108,8 @@ class GenerationBatch:
     """Weights, modulation vectors and the step function of one model-shaped batch on `device`."""
 
     def __init__(self, model: str = "d30-256", config: str = "w4a4", depth: Optional[int] = None,
-                 batch_rows: Optional[int] = None, device=None, seed: int = 0, fused_fc1: bool = True, sdpa_in_f: bool = False):
+                 batch_rows: Optional[int] = None, device=None, seed: int = 0, fused_fc1: bool = True, sdpa_in_f: bool = False,
+                 kmajor: bool = True):
         assert model in MODELS and config in ("w4a4", "w6a6")
         self.model, self.config = model, config
         heads, self.patch_nums, rows = MODELS[model]
@@ -121,6 +122,7 @@ class GenerationBatch:
         self.fused_fc1 = fused_fc1 and not self.W6 and hasattr(gemm, "linear_fp4_gelu_dual")
         self.sdpa_in_f = sdpa_in_f                              # path F with torch's SDPA instead of fpq_attention_blhc (rounds 1 - 4 timed it that way)
         self.fused_gelu_quant = fused_fc1                       # path F: GELU + fc2's input quantizer in one pass over the fc1 output
+        self.kmajor = kmajor                                    # path Q: operands as k-major images (include/fpq.h): contiguous LDS-DMA pieces
         C, HID, B = self.C, self.HID, self.B
         g = torch.Generator(device=dev).manual_seed(seed)
         self.gen = g
@@ -140,9 +142,13 @@ class GenerationBatch:
         if self.W6:
             self.wq = {n: qu.fp6_quant_e2m3_per_token_cuda(w, 6) for n, w in w32.items()}
             self.wop = {n: gemm.quantize_fp6(w32[n]) for n in ("qkv", "proj", "fc1")}   # operands of the row-scaled GEMMs
+            if kmajor:
+                self.wop = {n: (gemm.to_kmajor(c, 6, dealt=True), sc) for n, (c, sc) in self.wop.items()}
         else:
             self.wq = {n: qu.fp_quant_e2_per_group_cuda(w, 4, 128).half() for n, w in w32.items()}
             self.wop = {n: gemm.quantize_mx(w32[n]) for n in ("qkv", "proj", "fc1")}
+            if kmajor:
+                self.wop = {n: (gemm.to_kmajor(c, 4, dealt=True), sc) for n, (c, sc) in self.wop.items()}
         del w32
         self.mods = [[(torch.randn(B, 1, C, device=dev, generator=g) * 0.2).half() for _ in range(6)] for _ in range(self.depth)]
         self.e2m1 = qu.fp4_e2m1_grid.to(dev)
@@ -181,17 +187,17 @@ class GenerationBatch:
 
     def q_producer_linear(self, t, sc, sh, sm, name):
         if self.W6:
-            return gemm.linear_fp6(*rot.adaln_rotate_quant_token(t, sc, sh, "e2m3", smooth=sm, emit="fp6"), *self.wop[name])
-        return gemm.linear_fp4(*rot.adaln_rotate_quant_mx(t, sc, sh, smooth=sm), *self.wop[name])
+            return gemm.linear_fp6(*rot.adaln_rotate_quant_token(t, sc, sh, "e2m3", smooth=sm, emit="fp6", kmajor=self.kmajor), *self.wop[name])
+        return gemm.linear_fp4(*rot.adaln_rotate_quant_mx(t, sc, sh, smooth=sm, kmajor=self.kmajor), *self.wop[name])
 
     def q_proj(self, t2d, gate, resid):       # x + proj(a).mul(gamma1), gate and residual applied in the GEMM epilogue
         if self.W6:
-            return gemm.linear_fp6(*gemm.quantize_fp6(t2d), *self.wop["proj"], None, gate, resid)
-        return gemm.linear_fp4(*gemm.quantize_mx(t2d), *self.wop["proj"], None, gate, resid)
+            return gemm.linear_fp6(*gemm.quantize_fp6(t2d, kmajor=self.kmajor), *self.wop["proj"], None, gate, resid)
+        return gemm.linear_fp4(*gemm.quantize_mx(t2d, kmajor=self.kmajor), *self.wop["proj"], None, gate, resid)
 
     def q_fc1_gelu_dual(self, t, sc, sh):
         """fc2's quantized input straight out of the fc1 GEMM: GELU(tanh) and the dual E1M2-/E2M1+ quantizer in its epilogue."""
-        return gemm.linear_fp4_gelu_dual(*rot.adaln_rotate_quant_mx(t, sc, sh, smooth=self.s_fc1), *self.wop["fc1"])
+        return gemm.linear_fp4_gelu_dual(*rot.adaln_rotate_quant_mx(t, sc, sh, smooth=self.s_fc1, kmajor=self.kmajor), *self.wop["fc1"])
 
     def attend(self, q, kc, vc):               # q [B,L,H,c]; kc, vc [B,Ltot,H,c] (flash layout, as the KV runs use)
         o = Fn.scaled_dot_product_attention(q.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2))
@@ -317,6 +323,8 @@ def generation_record(models: Sequence[str] = ("d30-256", "d36-512"), paths: Seq
         gb = GenerationBatch(model, config, depth=depth, device=device, seed=seed)
         for path in paths:
             rec = {"model": model, "path": path, "config": config, "images_per_batch": gb.B // 2, "what": WHAT[model]}
+            if path == "Q":
+                rec["operands"] = "k-major images (include/fpq.h)" if gb.kmajor else "row-major codes"
             try:
                 if tuned_gemms:
                     with tuned_torch_gemms() as tg:

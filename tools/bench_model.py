@@ -27,12 +27,13 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--unfused-fc1", action="store_true", help="Q path: GEMM, GELU and the dual quantizer as three launches")
     ap.add_argument("--sdpa-in-f", action="store_true", help="path F with torch's SDPA instead of fpq_attention_blhc (as rounds 1 - 4 timed it)")
+    ap.add_argument("--row-major-operands", action="store_true", help="Q path: row-major code tensors instead of k-major images (the form of rounds 1 - 4)")
     ap.add_argument("--tuned-gemms", action="store_true", help="torch's own GEMMs with the recorded TunableOp selections (var_block.tuned_torch_gemms)")
     args = ap.parse_args()
     torch.manual_seed(0)
     gb = var_block.GenerationBatch(args.model, args.config, depth=args.depth, batch_rows=args.batch, device="cuda:0",
-                                   fused_fc1=not args.unfused_fc1, sdpa_in_f=args.sdpa_in_f)
-    res = {"workload": gb.describe(), "depth": gb.depth, "batch_rows": gb.B, "fc1_epilogue_fused": gb.fused_fc1,
+                                   fused_fc1=not args.unfused_fc1, sdpa_in_f=args.sdpa_in_f, kmajor=not args.row_major_operands)
+    res = {"workload": gb.describe(), "depth": gb.depth, "batch_rows": gb.B, "fc1_epilogue_fused": gb.fused_fc1, "kmajor_operands": gb.kmajor,
            "library": _lib.build_tag()}
     paths = args.paths.split(",")
     import contextlib
