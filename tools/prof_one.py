@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE kernel a few times (for rocprofv3 --pmc passes).
-usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|token6|group6|sym|calib|channel|gemm|gemm6|gemm8|fc1}   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
+usage: prof_one.py {adaln|adaln32|adaln_codes|rotate|rotate_smooth|rotate_codes|dual|dual6|token6|group6|sym|calib|channel|gemm|gemm6|gemm8|fc1|gemm_km|gemm6_km|fc1_km}   (_km: operands as k-major images, include/fpq.h)   (FPQ_ADALN_V1=1: the round-1 adaLN kernel)"""
 import os
 import sys
 
@@ -45,28 +45,34 @@ elif which == "adaln_codes":    # the producer writing packed E2M1 codes + one f
 elif which == "rotate_codes":
     xs = [torch.randn(65536, C, device=dev).half() for _ in range(3)]
     fn = lambda: rot.rotate_quant_mx(nxt(xs))
-elif which == "gemm":
+elif which in ("gemm", "gemm_km"):
     from fpqvar_amd import gemm
     x = torch.randn(65536, C, device=dev).half()
     w = torch.randn(5760, C, device=dev) * 0.02
-    ac, asc = gemm.quantize_mx(x)
+    ac, asc = gemm.quantize_mx(x, kmajor=which == "gemm_km")
     wc, wsc = gemm.quantize_mx(w)
+    if which == "gemm_km":
+        wc = gemm.to_kmajor(wc, 4, dealt=True)
     fn = lambda: gemm.linear_fp4(ac, asc, wc, wsc)
-elif which == "fc1":   # fc1 with GELU and fc2's dual quantizer in the GEMM's epilogue (fpq_gemm_fp4_gelu_dual), VAR-d30's shape
+elif which in ("fc1", "fc1_km"):   # fc1 with GELU and fc2's dual quantizer in the GEMM's epilogue (fpq_gemm_fp4_gelu_dual), VAR-d30's shape
     from fpqvar_amd import gemm
     x = torch.randn(65536, C, device=dev).half()
     w = torch.randn(7680, C, device=dev) * 0.02
     bias = (torch.randn(7680, device=dev) * 0.1).half()
-    ac, asc = gemm.quantize_mx(x)
+    ac, asc = gemm.quantize_mx(x, kmajor=which == "fc1_km")
     wc, wsc = gemm.quantize_mx(w)
+    if which == "fc1_km":
+        wc = gemm.to_kmajor(wc, 4, dealt=True)
     fn = lambda: gemm.linear_fp4_gelu_dual(ac, asc, wc, wsc, bias)
-elif which in ("gemm6", "gemm8"):   # the row-scaled GEMMs of the W6A6 configuration (6-bit packed / E4M3 bytes)
+elif which in ("gemm6", "gemm8", "gemm6_km"):   # the row-scaled GEMMs of the W6A6 configuration (6-bit packed / E4M3 bytes)
     from fpqvar_amd import gemm
     x = torch.randn(65536, C, device=dev).half()
     w = torch.randn(5760, C, device=dev) * 0.02
-    quant, lin = (gemm.quantize_fp6, gemm.linear_fp6) if which == "gemm6" else (gemm.quantize_fp8, gemm.linear_fp8)
-    ac, asc = quant(x)
+    quant, lin = (gemm.quantize_fp6, gemm.linear_fp6) if which != "gemm8" else (gemm.quantize_fp8, gemm.linear_fp8)
+    ac, asc = quant(x, kmajor=True) if which == "gemm6_km" else quant(x)
     wc, wsc = quant(w)
+    if which == "gemm6_km":
+        wc = gemm.to_kmajor(wc, 6, dealt=True)
     fn = lambda: lin(ac, asc, wc, wsc)
 elif which == "calib":
     from fpqvar_amd import calibrate as cal
