@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
     FPQ_SYNC();   // stage s has landed; the other buffer's readers are done
     FPQ_ST6(1);
     const uint8_t* st = smem + (s & 1) * STAGE;
+#ifndef FPQ_GEMM6_INTERLEAVE   // (-DFPQ_GEMM6_INTERLEAVE: one piece behind every third MFMA instead - re-measured on k-major operands, profiles/r05_kmajor_ab.txt)
     if (s + 1 < steps) { FPQ_GLDS6_ISSUE(s + 1, (s + 1) & 1); }
+#endif
     FPQ_ST6(2);
     v8i_t bf[NT];
 #pragma unroll
@@ -159,9 +161,23 @@ __global__ __launch_bounds__(256, 2) FPQ_NOPK void gemm_fp6_rows_kernel(const ui
         // a scheduling fence after every third MFMA - where the interleaved form issued its pieces: without the fences the
         // compiler's order of the rows' ds_reads and MFMAs is 5 % slower (0.635 against 0.603 ms), measured both ways
         // (a fence after every MFMA, every second or every fourth measures the same; in the FP8 kernel fences cost 2 %)
-        if ((m * NT + n) % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        if ((m * NT + n) % 3 == 2) {
+          __builtin_amdgcn_sched_barrier(0);
+#ifdef FPQ_GEMM6_INTERLEAVE
+          if ((m * NT + n) / 3 < PIECES && s + 1 < steps) {
+            FPQ_GLDS6_ONE(s + 1, (s + 1) & 1, (m * NT + n) / 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
+        }
       }
     }
+#ifdef FPQ_GEMM6_INTERLEAVE
+    if (s + 1 < steps) {
+#pragma unroll
+      for (int i_ = (MT * NT) / 3; i_ < PIECES; ++i_) FPQ_GLDS6_ONE(s + 1, (s + 1) & 1, i_);
+    }
+#endif
     FPQ_ST6(3);
   }
 #undef FPQ_GLDS6_ISSUE

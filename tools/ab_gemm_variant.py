@@ -2,7 +2,7 @@
 """Stock library against a GEMM-unit variant (tools/build_variant.sh --gemm <name> -D...), same process, alternating bursts:
 the FP6 / FP8 row-scaled GEMMs and the FP4 per-group GEMM (plain and with the fused fc1 tail) at the bench shapes; every
 variant result must be bit-equal to the stock one (ragged shapes included).
-usage: ab_gemm_variant.py tools/ab/lib<name>.so"""
+usage: ab_gemm_variant.py tools/ab/lib<name>.so [kmajor]      kmajor: the FP4 / FP6 operands as k-major images (include/fpq.h)"""
 import os
 import sys
 
@@ -14,6 +14,7 @@ from fpqvar_amd import _lib, gemm  # noqa: E402
 
 stock = _lib.lib()
 variant_path = sys.argv[1]
+KM = "kmajor" in sys.argv[2:]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
@@ -27,9 +28,11 @@ def operands(T, K, O):
 
 def cases(T, K, O):
     x, w, b = operands(T, K, O)
-    a6, w6 = gemm.quantize_fp6(x), gemm.quantize_fp6(w)
+    a6, w6 = gemm.quantize_fp6(x, kmajor=KM), gemm.quantize_fp6(w)
     a8, w8 = gemm.quantize_fp8(x), gemm.quantize_fp8(w)
-    a4, w4 = gemm.quantize_mx(x), gemm.quantize_mx(w)
+    a4, w4 = gemm.quantize_mx(x, kmajor=KM), gemm.quantize_mx(w)
+    if KM:
+        w6, w4 = (gemm.to_kmajor(w6[0], 6, dealt=True), w6[1]), (gemm.to_kmajor(w4[0], 4, dealt=True), w4[1])
     out = {
         "fp6": lambda: gemm.linear_fp6(*a6, *w6, bias=b),
         "fp8": lambda: gemm.linear_fp8(*a8, *w8, bias=b),
@@ -56,7 +59,7 @@ def use(l):
 
 variant = _lib.use_variant(variant_path)
 use(stock)
-print(f"# stock {os.path.basename(stock._name)} against {os.path.basename(variant_path)}; ms = best of 5 alternating bursts of 20")
+print(f"# stock {os.path.basename(stock._name)} against {os.path.basename(variant_path)}, {'k-major images' if KM else 'row-major codes'}; ms = best of 5 alternating bursts of 20")
 for T, K, O in ((65536, 1920, 5760), (65536, 1920, 7680), (16900, 1920, 1920), (301, 1920, 392)):
     cs = cases(T, K, O)
     for name, fn in cs.items():
