@@ -90,6 +90,9 @@ def quantize_mx(x: torch.Tensor, kmajor: bool = False) -> Tuple[torch.Tensor, to
     k = x.shape[-1]
     if k % 128 != 0:
         raise RuntimeError("quantize_mx: the last dimension must be a multiple of 128")
+    if kmajor and x.dtype == torch.float32:   # the image-writing quantizer takes fp16 rows (activations); fp32 rows: two steps
+        codes, scales = quantize_mx(x)
+        return to_kmajor(codes, 4), scales
     xc = x.contiguous()
     rows = xc.numel() // k
     codes = torch.empty((k // 128, rows, 64) if kmajor else (rows, k // 2), dtype=torch.uint8, device=x.device)

@@ -245,3 +245,55 @@ def test_kmajor_path_under_graph_replay():
     a, s = rotation.adaln_rotate_quant_mx(x, sc, sc)
     want = gemm.linear_fp4(a, s, *gemm.quantize_mx(lin.weight.detach().float()), lin.bias.detach().half())
     assert torch.equal(y, want)
+
+
+def test_quantize_var_uses_kmajor_operands_and_survives_a_state_dict_round_trip():
+    """quantize_VAR(real_fp4 / real_fp6): k-major weights by default, bit-identical outputs to kmajor_operands=False, and the
+    3-D image buffers travel through state_dict / load_state_dict like any other buffer."""
+    import copy
+    from fpqvar_amd import gemm, quant_linear as ql
+
+    class FFN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.act, self.fc2 = torch.nn.Linear(256, 1024), torch.nn.GELU(approximate="tanh"), torch.nn.Linear(1024, 256)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mat_qkv, self.proj = torch.nn.Linear(256, 768), torch.nn.Linear(256, 256)
+
+        def forward(self, x):
+            return self.proj(self.mat_qkv(x)[..., :256])
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn, self.ffn = Attn(), FFN()
+
+        def forward(self, x):
+            return self.ffn(self.attn(x))
+
+    cfg4 = dict(weight_quant="per_group", act_quant="per_group", w_bit=4, a_bit=4, act_quant_sym=True, activation_fp_quant=True,
+                weight_fp_quant=True, act_fp_type="fp_e2", weight_fp_type="fp_e2", fc2_fp_type="fp_e1m2_neg_e2m1_pos", real_fp4=True)
+    cfg6 = dict(weight_quant="per_channel", act_quant="per_token", w_bit=6, a_bit=6, act_quant_sym=True, activation_fp_quant=True,
+                weight_fp_quant=True, act_fp_type="fp6_e2m3", weight_fp_type="fp6_e2m3", fc2_fp_type="fp6_int_neg_e2m3_pos", real_fp6=True)
+    torch.manual_seed(11)
+    x = torch.randn(3, 40, 256, device=_dev()).half()
+    for cfg in (cfg4, dict(cfg4, fuse_ffn=True), cfg6):
+        base = Toy().to(_dev())
+        km = ql.quantize_VAR(copy.deepcopy(base), **cfg).half()
+        rm = ql.quantize_VAR(copy.deepcopy(base), kmajor_operands=False, **cfg).half()
+        n_images = sum(1 for m in km.modules() if isinstance(m, (gemm.FP4Linear, gemm.FP6Linear)) and m.kmajor)
+        assert n_images == 3 and not any(getattr(m, "kmajor", False) for m in rm.modules())
+        y = km(x)
+        assert torch.equal(y, rm(x))
+        again = ql.quantize_VAR(copy.deepcopy(base), **cfg).half()
+        for m in again.modules():          # wipe the weights, then restore them from the first model's state_dict
+            if isinstance(m, (gemm.FP4Linear, gemm.FP6Linear)):
+                m.w_codes.zero_()
+        again.load_state_dict(km.state_dict())
+        assert torch.equal(again(x), y)
