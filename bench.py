@@ -457,7 +457,8 @@ def other_kernels(dev):
 
         flops("gemm_fp4_w4a4_mat_qkv_65536x1920x5760", timed(lambda: gemm.linear_fp4(*a, *w)))
         # the same codes as k-major operand images (include/fpq.h): every LDS-DMA piece of the GEMM is 1 KiB contiguous
-        ak, wk = (gemm.to_kmajor(a[0], 4), a[1]), (gemm.to_kmajor(w[0], 4, dealt=True), w[1])
+        ak = (gemm.to_kmajor(a[0], 4), gemm.to_kmajor_scales(a[1]))
+        wk = (gemm.to_kmajor(w[0], 4, dealt=True), gemm.to_kmajor_scales(w[1], weight_side=True))
         flops("gemm_fp4_w4a4_mat_qkv_65536x1920x5760_kmajor", timed(lambda: gemm.linear_fp4(*ak, *wk)))
         del a, w, ak, wk
         # the W6A6 pair (per token x per channel): the 6-bit packed form and the E4M3-byte form of the same instruction

@@ -130,6 +130,7 @@ _SIGS = {
                                                                    _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
                                                                    _c.c_float, _c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int,
                                                                    _c.c_void_p]),
+    "fpq_scales_to_kmajor": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p]),
     "fpq_codes_to_kmajor": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
     "fpq_gemm_fp8_rows_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                          _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),

@@ -1126,20 +1126,29 @@ __global__ __launch_bounds__(64 * NW, (EMIT || (X32 && MAXC == 5)) ? 3 : TIGHT ?
         const uint32_t u = (uint32_t)ln >> 2, second = (nrows == 2 && u >= gpr) ? 1u : 0u;
         return rq_km4_off((uint32_t)row + second, u - second * gpr, u < (uint32_t)nrows * gpr, ln, r.km_rows);
       };
+      const uint32_t tpad = (r.km_rows + 3u) & ~3u;   // k-major: the scales as fp32 [G][rows rounded up to 4] (include/fpq.h)
+      const __amdgpu_buffer_rsrc_t sdst = r.km_rows ? rq_rsrc(r.code_scales, (int)(tpad * gpr * 4u)) : rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2);
+      const auto soff = [&](int u_) -> uint32_t {
+        if (!r.km_rows) return (uint32_t)u_ * 2u;
+        const uint32_t u = (uint32_t)u_, second = (nrows == 2 && u >= gpr) ? 1u : 0u;
+        return u < (uint32_t)nrows * gpr ? ((((u - second * gpr) * tpad + (uint32_t)row + second) * 4u) | 0x80000000u) : 0xFFFFFFFFu;
+      };
       if constexpr (HW4)
-        rq_store_codes_hw(img, yw, s, cdst, rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane, coff);
+        rq_store_codes_hw(img, yw, s, cdst, sdst, lane, coff, soff);
       else
-        rq_store_codes((u32x4*)img, yw, s, lut, a.shift, cdst, rq_rsrc(r.code_scales + row * (vpr >> 4), nrows * (vpr >> 4) * 2), lane, coff);
+        rq_store_codes((u32x4*)img, yw, s, lut, a.shift, cdst, sdst, lane, coff, soff);
       if (MAXC == 5 && do_slot) {
         const uint32_t cd = HW4 ? codes_vec16_hw(y1, s1.inv) : codes_vec16(y1, lut, a.shift, s1.inv, s1.inv_lo);
         if (slot_live) {
           if (r.km_rows) {   // vector j = 256 + slot_idx of slot_row: 4 bytes at byte 4 (j & 3) of chunk (j & 15) >> 2 of group j >> 4
             const uint32_t j = 256u + (uint32_t)slot_idx;
             ((uint32_t*)out)[(km4_off((uint32_t)slot_row, j >> 4, (j & 15u) >> 2, r.km_rows) >> 2) + (j & 3u)] = cd;
+            if ((lane & 15) == 0)
+              ((float*)r.code_scales)[(int64_t)(j >> 4) * tpad + slot_row] = (float)__builtin_bit_cast(_Float16, (uint16_t)(s1.s16x2 & 0xFFFFu));
           } else {
             ((uint32_t*)out)[slot_at] = cd;
           }
-          if ((lane & 15) == 0) r.code_scales[slot_at >> 4] = (uint16_t)(s1.s16x2 & 0xFFFFu);
+          if (!r.km_rows && (lane & 15) == 0) r.code_scales[slot_at >> 4] = (uint16_t)(s1.s16x2 & 0xFFFFu);
         }
       }
     } else {

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(kBlock) void rows16_codes_mx_kernel(const u32x4* __
       const u32x4 w = __builtin_nontemporal_load(x + v);
       const uint32_t m = row_max_dpp<16>(vec_absmax16(w));
       const RowScale16 s = row_scale16(m, a.fpos.gmax, a.inv_gpos);
-      if (lane16 == 0) scales[v >> 4] = (uint16_t)(s.s16x2 & 0xFFFFu);
+      if (lane16 == 0)   // the scale as fp32 into the k-major scale image [G][rows rounded up to 4] (include/fpq.h)
+        ((float*)scales)[(int64_t)g * ((km_rows + 3u) & ~3u) + t] = (float)__builtin_bit_cast(_Float16, (uint16_t)(s.s16x2 & 0xFFFFu));
       codes[(km4_off(t, g, lane16 >> 2, km_rows) >> 2) + (lane16 & 3u)] = codes_vec16(w, lut, a.shift, s.inv, s.inv_lo);
     }
     return;

@@ -10,6 +10,18 @@ namespace {
 #include "fpq_gemm_fp8.h"
 #include "fpq_gemm_fp6.h"
 #include "fpq_attention.h"
+
+// Per-group scales [rows, groups] (fp16 or fp32) -> the fp32 k-major scale image [groups][image_rows] of the FP4 GEMM (include/fpq.h):
+// image_rows = rows rounded up to 4 (activation side) or to 64 (weight side; natural row order), padding = 0.
+template <typename Ts>
+__global__ __launch_bounds__(256) void scales_to_kmajor_kernel(const Ts* __restrict__ scales, float* __restrict__ image, int64_t rows,
+                                                               int64_t image_rows, int groups) {
+  const int64_t n = (int64_t)groups * image_rows;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t g = i / image_rows, r = i - g * image_rows;
+    image[i] = r < rows ? (float)scales[r * groups + g] : 0.0f;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -126,7 +138,12 @@ static int gemm_fp4_mx_impl(const uint8_t* a_codes, const void* a_scales, const 
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
   GemmEpi epi;
   if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
-  if (km) epi.km_w_rows = (int)((outs + 63) / 64 * 64);
+  if (km) {   // scales come as fp32 k-major images too (include/fpq.h); their lane offsets are 32-bit: 3 planes of rows * 4 bytes
+    if (w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+    if (tokens >= (1ll << 28) || outs >= (1ll << 28)) return FPQ_ERR_SHAPE;
+    if ((((uintptr_t)a_scales | (uintptr_t)w_scales) & 15) != 0) return FPQ_ERR_ARG;
+    epi.km_w_rows = (int)((outs + 63) / 64 * 64);
+  }
   if (w_scale_dtype != FPQ_F16 && w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
   if (k % 128 != 0 || k > 128 * 64 || outs % 8 != 0 || tokens > 0x7FFFFFFF || outs > 0x7FFFFFFF) return FPQ_ERR_SHAPE;
   if (tokens == 0 || outs == 0) return FPQ_OK;
@@ -243,6 +260,7 @@ static int gemm_fp4_gelu_dual_impl(const uint8_t* a_codes, const void* a_scales,
   const int G = (int)(k / 128);
   hipStream_t st = (hipStream_t)stream;
   GemmEpi epi{nullptr, nullptr, 1, km ? (int)outs : 0};   // (outs % 128 == 0: the weight image has exactly outs rows)
+  if (km && (w_scale_dtype != FPQ_F32 || tokens >= (1ll << 28) || (((uintptr_t)a_scales | (uintptr_t)w_scales) & 15) != 0)) return FPQ_ERR_ARG;
   // tile choice as fpq_gemm_fp4_mx_ex (FPQ_GEMM_CFG 10 / 20 / 30 forces one of the three LDS-DMA tilings)
   const int64_t big_tiles = ((tokens + 255) / 256) * (outs / 128), mid_tiles = ((tokens + 127) / 128) * (outs / 128);
   const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds_fc1(G, xe.a.shift) <= 160 * 1024;
@@ -360,6 +378,22 @@ __global__ __launch_bounds__(256) void codes_to_kmajor_kernel(const u32x4* __res
     if (row < rows) v = codes[(row * steps + s) * cps + c];
     image[i] = v;
   }
+}
+int fpq_scales_to_kmajor(const void* scales, int scale_dtype, float* image, int64_t rows, int64_t groups, int weight_side,
+                         fpq_stream_t stream) {
+  if (rows < 0 || groups < 0 || groups > 0x7FFFFFFF) return FPQ_ERR_ARG;
+  if (scale_dtype != FPQ_F16 && scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
+  if (rows == 0 || groups == 0) return FPQ_OK;
+  if (!scales || !image || ((uintptr_t)image & 15) != 0) return FPQ_ERR_ARG;
+  const int64_t image_rows = weight_side ? (rows + 63) / 64 * 64 : (rows + 3) / 4 * 4;
+  const dim3 grid(grid_for((groups * image_rows + 255) / 256, 1 << 16));
+  if (scale_dtype == FPQ_F16)
+    hipLaunchKernelGGL(scales_to_kmajor_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)scales, image, rows,
+                       image_rows, (int)groups);
+  else
+    hipLaunchKernelGGL(scales_to_kmajor_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)scales, image, rows,
+                       image_rows, (int)groups);
+  return check_launch();
 }
 int fpq_codes_to_kmajor(const uint8_t* codes, uint8_t* image, int64_t rows, int64_t k, int code_bits, int dealt, fpq_stream_t stream) {
   if (rows < 0 || k < 0 || (code_bits != 4 && code_bits != 6)) return FPQ_ERR_ARG;

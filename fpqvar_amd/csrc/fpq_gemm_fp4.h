@@ -309,7 +309,11 @@ FPQ_NOPK __device__ __forceinline__ void load_scale_tiles(const _Float16* __rest
       for (int g0 = 0; g0 < G; g0 += GB) {
         _Float16 v[GB];
 #pragma unroll
+#ifdef FPQ_GEMM_SCALE_FAKE   // timing experiment only (wrong results): what the scale tiles' global loads cost the prologue
+        for (int i = 0; i < GB; ++i) v[i] = (_Float16)(1.0f + (float)(r & 1));
+#else
         for (int i = 0; i < GB; ++i) v[i] = src[g0 + i < G ? g0 + i : G - 1];
+#endif
 #pragma unroll
         for (int i = 0; i < GB; ++i)
           if (g0 + i < G) lsa[(g0 + i) * BM + r] = ok ? (float)v[i] : 0.0f;
@@ -321,7 +325,11 @@ FPQ_NOPK __device__ __forceinline__ void load_scale_tiles(const _Float16* __rest
       for (int g0 = 0; g0 < G; g0 += GB) {
         Tsw v[GB];
 #pragma unroll
+#ifdef FPQ_GEMM_SCALE_FAKE
+        for (int i = 0; i < GB; ++i) v[i] = (Tsw)(0.01f + 0.001f * (float)(c & 3));
+#else
         for (int i = 0; i < GB; ++i) v[i] = src[g0 + i < G ? g0 + i : G - 1];
+#endif
 #pragma unroll
         for (int i = 0; i < GB; ++i)
           if (g0 + i < G) lsw[(g0 + i) * BN + c] = ok ? (float)v[i] : 0.0f;
@@ -409,7 +417,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int G = C >> 7, row_bytes = C >> 1;
   float* lsa = (float*)(smem + 2 * STAGE);   // [G][BM]
-  float* lsw = lsa + G * BM;                 // [G][BN]
+  const int Gp = (G + 3) & ~3;               // the scale tiles' LDS-DMA pieces cover up to four groups each: room for a whole last piece
+  float* lsw = lsa + Gp * BM;                // [G][BN]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int n_col = (O + BN - 1) / BN, n_row = (T + BM - 1) / BM;
@@ -470,17 +479,43 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
 #define FPQ_GLDS_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
   FPQ_GLDS_ISSUE(0, 0);
 
-  load_scale_tiles<Tsw, BM, BN, NTHR>(sa, sw, lsa, lsw, t0, o0, T, O, G, tid);
+  if (km) {
+    // K-MAJOR SCALE IMAGES (include/fpq.h): fp32 planes [G][rows rounded up to 4] (activations) and [G][km_w_rows] (weights, natural
+    // output order) - the tile's scales of a group are 4 BM (4 BN) contiguous bytes, exactly one row of lsa (lsw): they come
+    // in by LDS-DMA like the codes, 256 / BM (two) groups per 1 KiB piece, no register round trip, no conversion, no ds_write.
+    // Row-major fp16 / fp32 scales cost 90 strided load instructions + as many LDS writes per tile: 8 % of the kernel
+    // (profiles/r05_kmajor_ab.txt).  Pieces dealt round-robin over the four wavefronts; the main loop's first wait covers them.
+    constexpr int APG = 256 / BM, LPG_A = BM / 4;          // groups per piece, lanes per group (activation side)
+    const int Tpad = (T + 3) & ~3, n_a = (G + APG - 1) / APG, n_w = (G + 1) >> 1;
+    const float* sa_km = (const float*)sa;
+    const float* sw_km = (const float*)sw;
+    for (int p = wave; p < n_a + n_w; p += 4) {
+      const bool is_a = p < n_a;
+      const int g0 = is_a ? p * APG : (p - n_a) * 2;
+      const int sub = is_a ? lane / LPG_A : lane >> 5, l4 = is_a ? lane % LPG_A : lane & 31;
+      const int grp = g0 + sub < G ? g0 + sub : G - 1;       // (a last piece's surplus groups re-read the last one; their LDS rows are padding)
+      const int rows = is_a ? Tpad : epi.km_w_rows, r0 = is_a ? t0 : o0;
+      int r4 = r0 + 4 * l4;
+      r4 = r4 < rows - 4 ? r4 : rows - 4;
+      const uint32_t vo = (uint32_t)(((grp - g0) * rows + (r4 - r0)) * 4);
+      const float* sbase = (is_a ? sa_km : sw_km) + ((int64_t)g0 * rows + r0);
+      const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(is_a ? lsa + g0 * BM : lsw + g0 * BN);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sbase), "s"(dst) : "m0");
+    }
+  } else {
+    load_scale_tiles<Tsw, BM, BN, NTHR>(sa, sw, lsa, lsw, t0, o0, T, O, G, tid);
+  }
   uint16_t* lut = nullptr;
   if constexpr (FC1) {   // the dual quantizer's bucket table, behind the scale tiles; visible after the first barrier of the main loop
-    lut = (uint16_t*)(lsw + G * BN);
+    lut = (uint16_t*)(lsw + Gp * BN);
     lut16_stage(lut, xe.tab, xe.a.shift);
   }
 
   // A wait the COMPILER sees (the builtin, not assembly): its scoreboard still carries the scale loads above, whose last
   // waits it counted without knowing of the stage-0 pieces in the same queue - left like that, it protects their
   // destination registers with vmcnt waits inside the main loop, and those wait for the stage just requested.
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  // (k-major: no load the compiler knows of is in flight - nothing to wait for here, the prologue runs on)
+  if (!km) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
   // the tile's bias (four consecutive outputs per lane, see the epilogue) is requested here, not between the last MFMA and
   // the stores
@@ -706,8 +741,8 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
 template <int MT, int NT>
 struct GemmGldsCfg {
   static constexpr int BM = 32 * MT, BN = 32 * NT;
-  static size_t lds(int G) {
-    return 2 * (size_t)(BM + BN) * 64 + (size_t)G * (BM + BN) * 4;   // two stages + the scale tiles (the plain epilogue uses no LDS)
+  static size_t lds(int G) {   // two stages + the scale tiles, groups rounded up to four (the plain epilogue uses no LDS)
+    return 2 * (size_t)(BM + BN) * 64 + (size_t)((G + 3) & ~3) * (BM + BN) * 4;
   }
   static size_t lds_fc1(int G, int shift) { return lds(G) + ((size_t)2 << (16 - shift)); }   // + the dual quantizer's bucket table
 };

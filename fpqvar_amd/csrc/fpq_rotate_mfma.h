@@ -251,10 +251,25 @@ __device__ __forceinline__ uint32_t rq_km4_off(uint32_t t, uint32_t g, bool live
 __device__ __forceinline__ void rq_store_code_chunk(const u32x4& o, __amdgpu_buffer_rsrc_t dst, uint32_t off) {
   __builtin_amdgcn_raw_buffer_store_b128(o, dst, off, 0, kRqNt);
 }
+// the tile's 16 group scales (lane u < 16 holds group u's): fp16 at byte 2 u of scales_dst (row-major [rows][G]), or - scale_off(u)
+// with bit 31 set - as fp32 at that byte offset of the k-major scale image [G][rows rounded up to 4] (0xFFFFFFFF: no such group)
 template <typename OffFn>
+__device__ __forceinline__ void rq_store_scale(const RowScale16& s, __amdgpu_buffer_rsrc_t scales_dst, int lane, OffFn scale_off) {
+  if (lane < 16) {
+    const uint32_t off = scale_off(lane);
+    if (off & 0x80000000u) {
+      if (off != 0xFFFFFFFFu)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)__builtin_bit_cast(_Float16, (uint16_t)(s.s16x2 & 0xFFFFu))),
+                                              scales_dst, off & 0x7FFFFFFFu, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, off, 0, 0);
+    }
+  }
+}
+template <typename OffFn, typename ScaleFn>
 __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[8][2], const RowScale16& s,
                                                const uint16_t* lut, int shift, __amdgpu_buffer_rsrc_t codes_dst,
-                                               __amdgpu_buffer_rsrc_t scales_dst, int lane, OffFn code_off) {
+                                               __amdgpu_buffer_rsrc_t scales_dst, int lane, OffFn code_off, ScaleFn scale_off) {
   lane = rq_opaque(lane);
   const int g = lane & 15, quarter = lane >> 4;
   const int swz = ((g >> 2) & 3) << 2;
@@ -276,7 +291,7 @@ __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[
   const int gg = lane >> 2, j = lane & 3;
   const u32x4 o = buf[gg * 4 + (j ^ ((gg >> 2) & 3))];
   rq_store_code_chunk(o, codes_dst, code_off(lane));
-  if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
+  rq_store_scale(s, scales_dst, lane, scale_off);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -286,10 +301,10 @@ __device__ __forceinline__ void rq_store_codes(u32x4* buf, const uint32_t (&yw)[
 // bytes in the image (20 dwords: the 64 lanes of a 2-byte write hit 32 dwords, two lanes each sharing one), every
 // address a lane constant + an immediate.
 constexpr int kRqCodeStride = 80;
-template <typename OffFn>
+template <typename OffFn, typename ScaleFn>
 __device__ __forceinline__ void rq_store_codes_hw(char* img, const uint32_t (&yw)[8][2], const RowScale16& s,
                                                   __amdgpu_buffer_rsrc_t codes_dst, __amdgpu_buffer_rsrc_t scales_dst,
-                                                  int lane, OffFn code_off) {
+                                                  int lane, OffFn code_off, ScaleFn scale_off) {
   const int g = lane & 15, quarter = lane >> 4;
   const int cw = g * kRqCodeStride + 2 * quarter;
 #pragma unroll
@@ -306,7 +321,7 @@ __device__ __forceinline__ void rq_store_codes_hw(char* img, const uint32_t (&yw
   __builtin_amdgcn_wave_barrier();
   const u32x4 o = *(const u32x4*)(img + (lane >> 2) * kRqCodeStride + (lane & 3) * 16);   // chunk lane % 4 of group lane / 4
   rq_store_code_chunk(o, codes_dst, code_off(rq_opaque(lane)));
-  if (lane < 16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(s.s16x2 & 0xFFFFu), scales_dst, lane * 2, 0, 0);
+  rq_store_scale(s, scales_dst, rq_opaque(lane), scale_off);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -537,10 +552,18 @@ __global__ __launch_bounds__(kBlock, SMOOTH ? FPQ_ROT_WAVES - 1 : FPQ_ROT_WAVES)
         const uint32_t gi = (uint32_t)(base_vec >> 4) + ((uint32_t)ln >> 2), t = fast_div_q(gi, r.km_gpr);
         return rq_km4_off(t, gi - t * r.km_gpr.d, (int64_t)gi * 16 < n_vec, ln, r.km_rows);
       };
+      // scales: fp16 [rows][G] behind the tile's first group, or (k-major) fp32 [G][rows rounded up to 4]
+      const uint32_t tpad = (r.km_rows + 3u) & ~3u;
+      const __amdgpu_buffer_rsrc_t sdst = r.km_rows ? rq_rsrc(r.code_scales, (int)(tpad * r.km_gpr.d * 4u)) : rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8);
+      const auto soff = [&](int u) -> uint32_t {
+        if (!r.km_rows) return (uint32_t)u * 2u;
+        const uint32_t gi = (uint32_t)(base_vec >> 4) + (uint32_t)u, t = fast_div_q(gi, r.km_gpr);
+        return (int64_t)gi * 16 < n_vec ? ((((gi - t * r.km_gpr.d) * tpad + t) * 4u) | 0x80000000u) : 0xFFFFFFFFu;
+      };
       if constexpr (HW4)
-        rq_store_codes_hw(img, yw, s, cdst, rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), rq_opaque(lane), coff);
+        rq_store_codes_hw(img, yw, s, cdst, sdst, rq_opaque(lane), coff, soff);
       else
-        rq_store_codes(buf, yw, s, lut, a.shift, cdst, rq_rsrc(r.code_scales + (base_vec >> 4), rem / 8), lane, coff);
+        rq_store_codes(buf, yw, s, lut, a.shift, cdst, sdst, lane, coff, soff);
     } else {
 #pragma unroll
       for (int c = 0; c < 8; ++c)

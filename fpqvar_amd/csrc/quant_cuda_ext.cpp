@@ -282,13 +282,21 @@ ProducerArgs producer_checks(const char* what, const at::Tensor& x, const at::Te
 static at::Tensor mx_codes_tensor(const at::Tensor& x, int64_t rows, int64_t c, bool kmajor) {
   return kmajor ? at::empty({c / 128, rows, 64}, x.options().dtype(at::kByte)) : at::empty({rows, c / 2}, x.options().dtype(at::kByte));
 }
+// ... and their scales: fp16 [rows, C / 128], or (kmajor) the fp32 k-major scale image [C / 128, rows rounded up to 4], padding zeroed
+static at::Tensor mx_scales_tensor(const at::Tensor& x, int64_t rows, int64_t c, bool kmajor) {
+  if (!kmajor) return at::empty({rows, c / 128}, x.options().dtype(at::kHalf));
+  const int64_t pad = (rows + 3) / 4 * 4;
+  at::Tensor t = at::empty({c / 128, pad}, x.options().dtype(at::kFloat));
+  if (pad != rows) t.narrow(1, rows, pad - rows).zero_();
+  return t;
+}
 
 std::tuple<at::Tensor, at::Tensor> rotate_quant_mx(const at::Tensor& x, const std::array<uint32_t, 4>& sign_mask,
                                                    const c10::optional<at::Tensor>& smooth, bool kmajor) {
   const ProducerArgs a = producer_checks("rotate_quant_mx", x, nullptr, nullptr, smooth, 1 << 30);
   const int64_t rows = a.l;
   at::Tensor codes = mx_codes_tensor(x, rows, a.c, kmajor);
-  at::Tensor scales = at::empty({rows, a.c / 128}, x.options().dtype(at::kHalf));
+  at::Tensor scales = mx_scales_tensor(x, rows, a.c, kmajor);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
   check((kmajor ? fpq_rotate_quant_rows_codes_mx_km : fpq_rotate_quant_rows_codes_mx)(
             x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c, dtype_id(x.scalar_type(), "rotate_quant_mx"), a.smooth,
@@ -303,7 +311,7 @@ std::tuple<at::Tensor, at::Tensor> adaln_rotate_quant_mx(const at::Tensor& x, co
   const ProducerArgs a = producer_checks("adaln_rotate_quant_mx", x, &scale, &shift, smooth, 4096);
   const int64_t rows = a.b * a.l;
   at::Tensor codes = mx_codes_tensor(x, rows, a.c, kmajor);
-  at::Tensor scales = at::empty({rows, a.c / 128}, x.options().dtype(at::kHalf));
+  at::Tensor scales = mx_scales_tensor(x, rows, a.c, kmajor);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
   check((kmajor ? fpq_adaln_rotate_quant_rows_codes_mx_km : fpq_adaln_rotate_quant_rows_codes_mx)(
             x.data_ptr(), (uint8_t*)codes.data_ptr(), scales.data_ptr(), rows, a.c, dtype_id(x.scalar_type(), "adaln_rotate_quant_mx"),
@@ -383,39 +391,47 @@ struct Fp4Shapes {
   bool kmajor;
 };
 static Fp4Shapes fp4_shapes(const char* what, const at::Tensor& a_codes, const at::Tensor& a_scales, const at::Tensor& w_codes,
-                            const at::Tensor& w_scales) {
+                            const at::Tensor& w_scales, const c10::optional<at::Tensor>& bias, const c10::optional<int64_t>& outs_arg) {
   Fp4Shapes sh;
   TORCH_CHECK((a_codes.dim() == 2 && w_codes.dim() == 2) || (a_codes.dim() == 3 && w_codes.dim() == 3), what,
               ": both operands must be row-major codes [rows, K / 2] or both k-major images [K / 128, rows, 64]");
   sh.kmajor = a_codes.dim() == 3;
-  int64_t w_rows;
-  if (sh.kmajor) {
-    TORCH_CHECK(a_codes.size(2) == 64 && w_codes.size(2) == 64 && a_codes.size(0) == w_codes.size(0) && w_codes.size(1) % 64 == 0 &&
-                    w_scales.dim() >= 1, what, ": k-major images must be [K / 128, rows, 64] with the same K and a weight image of a multiple of 64 rows");
-    sh.tokens = a_codes.size(1);
-    sh.outs = w_scales.size(0);
-    sh.k = a_codes.size(0) * 128;
-    w_rows = (sh.outs + 63) / 64 * 64;
-  } else {
-    sh.tokens = a_codes.size(0);
-    sh.outs = w_codes.size(0);
-    sh.k = a_codes.size(1) * 2;
-    w_rows = sh.outs;
-    TORCH_CHECK(w_codes.size(1) * 2 == sh.k, what, ": operand shapes mismatch");
-  }
-  TORCH_CHECK(a_scales.scalar_type() == at::kHalf && sh.k % 128 == 0, what, ": operand shapes / activation scale dtype mismatch");
   const at::Device dev = a_codes.device();
+  if (sh.kmajor) {
+    TORCH_CHECK(a_codes.size(2) == 64 && w_codes.size(2) == 64 && a_codes.size(0) == w_codes.size(0) && w_codes.size(1) % 64 == 0, what,
+                ": k-major images must be [K / 128, rows, 64] with the same K and a weight image of a multiple of 64 rows");
+    const int64_t groups = a_codes.size(0), w_rows = w_codes.size(1);
+    sh.tokens = a_codes.size(1);
+    sh.k = groups * 128;
+    // the Linear's width: named by the caller, or the bias' length, or the weight image's row count
+    sh.outs = outs_arg.has_value() ? *outs_arg : bias.has_value() ? bias->numel() : w_rows;
+    TORCH_CHECK(sh.outs > w_rows - 64 && sh.outs <= w_rows, what, ": outs = ", sh.outs, " does not belong to a weight image of ", w_rows, " rows");
+    const auto image_ok = [&](const at::Tensor& t, int64_t rows) {
+      return t.scalar_type() == at::kFloat && t.dim() == 2 && t.size(0) == groups && t.size(1) == rows && t.is_contiguous() && t.device() == dev;
+    };
+    TORCH_CHECK(image_ok(a_scales, (sh.tokens + 3) / 4 * 4) && image_ok(w_scales, w_rows), what,
+                ": the k-major scale images must be contiguous float32 [K / 128, rows rounded up to 4 (activation) | weight image rows]");
+    TORCH_CHECK(a_codes.scalar_type() == at::kByte && w_codes.scalar_type() == at::kByte && a_codes.is_contiguous() && w_codes.is_contiguous() &&
+                    w_codes.device() == dev, what, ": the k-major images must be contiguous uint8 tensors on ", dev);
+    return sh;
+  }
+  sh.tokens = a_codes.size(0);
+  sh.outs = w_codes.size(0);
+  sh.k = a_codes.size(1) * 2;
+  TORCH_CHECK(w_codes.size(1) * 2 == sh.k, what, ": operand shapes mismatch");
+  TORCH_CHECK(a_scales.scalar_type() == at::kHalf && sh.k % 128 == 0, what, ": operand shapes / activation scale dtype mismatch");
   check_operand((std::string(what) + "(activation)").c_str(), a_codes, a_scales, sh.tokens, sh.k / 2, sh.tokens * (sh.k / 128), dev);
-  check_operand((std::string(what) + "(weight)").c_str(), w_codes, w_scales, w_rows, sh.k / 2, sh.outs * (sh.k / 128), dev);
+  check_operand((std::string(what) + "(weight)").c_str(), w_codes, w_scales, sh.outs, sh.k / 2, sh.outs * (sh.k / 128), dev);
   return sh;
 }
 
 // fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores, with the AdaLN block's gated residual in
 // the epilogue when given (tr/quant_utils.py:767, tr/basic_var.py:264): gemm.linear_fp4
 at::Tensor linear_fp4(const at::Tensor& a_codes, const at::Tensor& a_scales, const at::Tensor& w_codes, const at::Tensor& w_scales,
-                      const c10::optional<at::Tensor>& bias, const c10::optional<at::Tensor>& gate, const c10::optional<at::Tensor>& residual) {
+                      const c10::optional<at::Tensor>& bias, const c10::optional<at::Tensor>& gate, const c10::optional<at::Tensor>& residual,
+                      const c10::optional<int64_t>& outs_arg) {
   require_gpu(a_codes, "linear_fp4");
-  const Fp4Shapes sh = fp4_shapes("linear_fp4", a_codes, a_scales, w_codes, w_scales);
+  const Fp4Shapes sh = fp4_shapes("linear_fp4", a_codes, a_scales, w_codes, w_scales, bias, outs_arg);
   const int64_t tokens = sh.tokens, outs = sh.outs, k = sh.k;
   const at::Device dev = a_codes.device();
   fpq_gemm_epilogue_t ep{nullptr, nullptr, 1};
@@ -456,9 +472,9 @@ at::Tensor linear_fp4(const at::Tensor& a_codes, const at::Tensor& a_scales, con
 // tr/quant_utils.py:415-452,991): gemm.linear_fp4_gelu_dual.  Returns (out, gelu values or an undefined tensor).
 std::tuple<at::Tensor, c10::optional<at::Tensor>> linear_fp4_gelu_dual(const at::Tensor& a_codes, const at::Tensor& a_scales, const at::Tensor& w_codes,
                                                                         const at::Tensor& w_scales, const c10::optional<at::Tensor>& bias,
-                                                                        bool return_gelu) {
+                                                                        bool return_gelu, const c10::optional<int64_t>& outs_arg) {
   require_gpu(a_codes, "linear_fp4_gelu_dual");
-  const Fp4Shapes sh = fp4_shapes("linear_fp4_gelu_dual", a_codes, a_scales, w_codes, w_scales);
+  const Fp4Shapes sh = fp4_shapes("linear_fp4_gelu_dual", a_codes, a_scales, w_codes, w_scales, bias, outs_arg);
   const int64_t tokens = sh.tokens, outs = sh.outs, k = sh.k;
   TORCH_CHECK(outs % 128 == 0, "linear_fp4_gelu_dual: outs must be a multiple of 128");
   const at::Device dev = a_codes.device();
@@ -541,9 +557,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("kv_cache_step", &kv_cache_step, py::arg("cache"), py::arg("quant_start"), py::arg("quant_stop"), py::arg("k"), py::arg("v"),
         py::arg("new_start"), py::arg("group"), py::arg("table_id"));
   m.def("linear_fp4", &linear_fp4, py::arg("a_codes"), py::arg("a_scales"), py::arg("w_codes"), py::arg("w_scales"),
-        py::arg("bias") = py::none(), py::arg("gate") = py::none(), py::arg("residual") = py::none());
+        py::arg("bias") = py::none(), py::arg("gate") = py::none(), py::arg("residual") = py::none(), py::arg("outs") = py::none());
   m.def("linear_fp4_gelu_dual", &linear_fp4_gelu_dual, py::arg("a_codes"), py::arg("a_scales"), py::arg("w_codes"), py::arg("w_scales"),
-        py::arg("bias") = py::none(), py::arg("return_gelu") = false);
+        py::arg("bias") = py::none(), py::arg("return_gelu") = false, py::arg("outs") = py::none());
   m.def("gelu_quant_rows_dual", &gelu_quant_rows_dual, py::arg("y"), py::arg("neg_table_id"), py::arg("pos_table_id"), py::arg("cols") = 128,
         py::arg("nan_rule") = true, py::arg("return_gelu") = false);
   m.def("fp6_quant_per_token_contig", &fp6_quant_per_token_contig, py::arg("x"), py::arg("n_bits"), py::arg("table_id"));

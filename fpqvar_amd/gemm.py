@@ -53,7 +53,9 @@ def _epilogue(name: str, tokens: int, outs: int, gate: Optional[torch.Tensor], r
 # ---- k-major operand images (include/fpq.h): codes as [K / 128, image rows, 64 | 96] instead of [rows, row bytes] --------
 # A 3-D uint8 tensor IS an image, a 2-D one row-major codes: the Linears below pick the entry point from the operand's shape
 # (both operands must agree).  Weights: `to_kmajor(codes, bits, dealt=True)` once at load time; activations: the producers'
-# `kmajor=True` forms write the image directly (to_kmajor(codes, bits) converts any other producer's output).
+# `kmajor=True` forms write the image directly (to_kmajor(codes, bits) converts any other producer's output).  The per-group
+# scales of an FP4 operand travel with it as an fp32 image [K/128, rows rounded up to 4 | 64] (`to_kmajor_scales`); the FP6
+# operands keep their one scale per row.
 def to_kmajor(codes: torch.Tensor, code_bits: int, dealt: bool = False) -> torch.Tensor:
     """Row-major operand codes [rows, K/2] (code_bits 4) or [rows, K*3/4] (6) -> the k-major image [K/128, image_rows, 64 | 96]
     (fpq_codes_to_kmajor).  dealt: the weight side's row order, image_rows = rows rounded up to 64."""
@@ -70,6 +72,31 @@ def to_kmajor(codes: torch.Tensor, code_bits: int, dealt: bool = False) -> torch
     return image
 
 
+def to_kmajor_scales(scales: torch.Tensor, weight_side: bool = False) -> torch.Tensor:
+    """Per-group scales [rows, K/128] (fp16 / fp32) of an FP4 operand -> the fp32 k-major scale image [K/128, image_rows]
+    (fpq_scales_to_kmajor): image_rows = rows rounded up to 4, or to 64 on the weight side; the padding is zero."""
+    require_gpu(scales, "to_kmajor_scales")
+    if scales.dim() != 2 or scales.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("to_kmajor_scales: scales must be float16 / float32 [rows, K/128]")
+    sc = scales.contiguous()
+    rows, groups = sc.shape
+    image = torch.empty((groups, (rows + 63) // 64 * 64 if weight_side else (rows + 3) // 4 * 4), dtype=torch.float32, device=sc.device)
+    with device_guard(sc.device):
+        check(lib().fpq_scales_to_kmajor(sc.data_ptr(), dtype_id(sc.dtype), image.data_ptr(), rows, groups, 1 if weight_side else 0,
+                                         stream_ptr(sc.device)), "fpq_scales_to_kmajor")
+    return image
+
+
+def kmajor_mx_scales(rows: int, k: int, device) -> torch.Tensor:
+    """an empty k-major scale image for `rows` activation rows ([K/128, rows rounded up to 4] fp32) with its padding zeroed -
+    what the *_km producers of FP4 operands write their scales into"""
+    pad = (rows + 3) // 4 * 4
+    image = torch.empty((k // 128, pad), dtype=torch.float32, device=device)
+    if pad != rows:
+        image[:, rows:].zero_()
+    return image
+
+
 def _kmajor_pair(name: str, a: torch.Tensor, w: torch.Tensor, seg: int) -> bool:
     """True when both operands are k-major images (3-D), False when both are row-major codes (2-D); anything else is an error."""
     if a.dim() == 3 and w.dim() == 3:
@@ -83,7 +110,7 @@ def _kmajor_pair(name: str, a: torch.Tensor, w: torch.Tensor, seg: int) -> bool:
 
 def quantize_mx(x: torch.Tensor, kmajor: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """x [..., K] fp16/fp32 (K % 128 == 0) -> (codes uint8 [rows, K/2], scales [rows, K/128] in x.dtype).
-    kmajor: the codes as the activation side's k-major image [K/128, rows, 64] (same scales)."""
+    kmajor: the activation side's k-major images - codes [K/128, rows, 64] and scales fp32 [K/128, rows rounded up to 4]."""
     require_gpu(x, "quantize_mx")
     if x.dtype not in (torch.float16, torch.float32):
         raise RuntimeError(f"quantize_mx: x must be float16 or float32, got {x.dtype}")
@@ -92,11 +119,11 @@ def quantize_mx(x: torch.Tensor, kmajor: bool = False) -> Tuple[torch.Tensor, to
         raise RuntimeError("quantize_mx: the last dimension must be a multiple of 128")
     if kmajor and x.dtype == torch.float32:   # the image-writing quantizer takes fp16 rows (activations); fp32 rows: two steps
         codes, scales = quantize_mx(x)
-        return to_kmajor(codes, 4), scales
+        return to_kmajor(codes, 4), to_kmajor_scales(scales)
     xc = x.contiguous()
     rows = xc.numel() // k
     codes = torch.empty((k // 128, rows, 64) if kmajor else (rows, k // 2), dtype=torch.uint8, device=x.device)
-    scales = torch.empty((rows, k // 128), dtype=x.dtype, device=x.device)
+    scales = kmajor_mx_scales(rows, k, x.device) if kmajor else torch.empty((rows, k // 128), dtype=x.dtype, device=x.device)
     fn = lib().fpq_quant_rows_codes_mx_km if kmajor else lib().fpq_quant_rows_codes_mx
     with device_guard(x.device):
         check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, k, dtype_id(x.dtype), stream_ptr(x.device)),
@@ -142,28 +169,44 @@ def _check_operand(what: str, codes: torch.Tensor, scales: torch.Tensor, rows: i
 
 
 
+def _check_kmajor_fp4(name: str, a_codes, a_scales, w_codes, w_scales, bias, outs):
+    """shapes of a k-major FP4 operand pair -> (tokens, outs, k); `outs` (or the bias) names the Linear's width when it is not
+    the weight image's row count (a multiple of 64)"""
+    groups, tokens, w_rows = a_codes.shape[0], a_codes.shape[1], w_codes.shape[1]
+    if outs is None:
+        outs = bias.numel() if bias is not None else w_rows
+    if not (w_rows - 64 < outs <= w_rows):
+        raise RuntimeError(f"{name}: outs = {outs} does not belong to a weight image of {w_rows} rows")
+    dev = a_codes.device
+    for what, t, rows in (("activation", a_scales, (tokens + 3) // 4 * 4), ("weight", w_scales, w_rows)):
+        if t.dtype != torch.float32 or tuple(t.shape) != (groups, rows) or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError(f"{name}({what}): the k-major scale image must be a contiguous float32 [{groups}, {rows}] tensor on {dev}")
+    for what, t in (("activation", a_codes), ("weight", w_codes)):
+        if t.dtype != torch.uint8 or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError(f"{name}({what}): the k-major image must be a contiguous uint8 tensor on {dev}")
+    return tokens, outs, groups * 128
+
+
 def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
                bias: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
-               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, outs: Optional[int] = None) -> torch.Tensor:
     """fp16 [tokens, outs] = dequant(a) @ dequant(w).T + bias on the FP4 matrix cores; with gate / residual the
     AdaLN block's `residual + y.mul(gate)` (tr/basic_var.py:264) is applied in the epilogue, bit-identical to the two
     torch ops on the plain result."""
     if _native is not None:   # same checks, same C calls (fpq_gemm_fp4_mx_ex / fpq_gemm_fp4_mx_km)
-        return _native.linear_fp4(a_codes, a_scales, w_codes, w_scales, bias, gate, residual)
+        return _native.linear_fp4(a_codes, a_scales, w_codes, w_scales, bias, gate, residual, outs)
     require_gpu(a_codes, "linear_fp4")
     km = _kmajor_pair("linear_fp4", a_codes, w_codes, 64)
     if km:
-        tokens, outs, k = a_codes.shape[1], w_scales.shape[0], a_codes.shape[0] * 128
-        w_rows = (outs + 63) // 64 * 64
+        tokens, outs, k = _check_kmajor_fp4("linear_fp4", a_codes, a_scales, w_codes, w_scales, bias, outs)
     else:
         tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
-        w_rows = outs
         if w_codes.shape[1] * 2 != k:
             raise RuntimeError("linear_fp4: operand shapes mismatch")
-    if a_scales.dtype != torch.float16 or k % 128 != 0:
-        raise RuntimeError("linear_fp4: operand shapes / activation scale dtype mismatch")
-    _check_operand("linear_fp4(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), a_codes.device)
-    _check_operand("linear_fp4(weight)", w_codes, w_scales, w_rows, k // 2, outs * (k // 128), a_codes.device)
+        if a_scales.dtype != torch.float16 or k % 128 != 0:
+            raise RuntimeError("linear_fp4: operand shapes / activation scale dtype mismatch")
+        _check_operand("linear_fp4(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), a_codes.device)
+        _check_operand("linear_fp4(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), a_codes.device)
     ep, keep, out = _epilogue("linear_fp4", tokens, outs, gate, residual, None, a_codes.device)
     b = None if bias is None else bias.detach().to(torch.float16).reshape(-1).contiguous()
     if km and b is not None and b.data_ptr() % 16:
@@ -177,28 +220,28 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
 
 
 def linear_fp4_gelu_dual(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
-                         bias: Optional[torch.Tensor] = None, return_gelu: bool = False):
+                         bias: Optional[torch.Tensor] = None, return_gelu: bool = False, outs: Optional[int] = None):
     """fc1 of the AdaLN block's FFN up to fc2's GEMM in ONE launch (+ the dual quantizer's tiny NaN fix-up launch):
     `fp_quant_e1m2_neg_e2m1_pos_per_group_cuda(F.gelu(linear_fp4(a, w, bias), approximate="tanh"), 4, 128)`
     (tr/basic_var.py:120-121, tr/quant_utils.py:415-452,991) as the epilogue of the FP4 GEMM (fpq_gemm_fp4_gelu_dual):
     fp16 [tokens, outs], outs % 128 == 0.  return_gelu: also the GELU values the quantizer saw - the quantization is
     bit-exact on THOSE, they sit within one fp16 ulp of torch's GELU of the Linear output."""
     if _native is not None:   # same checks, same C calls, the binding's own NaN scratch
-        out, h = _native.linear_fp4_gelu_dual(a_codes, a_scales, w_codes, w_scales, bias, return_gelu)
+        out, h = _native.linear_fp4_gelu_dual(a_codes, a_scales, w_codes, w_scales, bias, return_gelu, outs)
         return (out, h) if return_gelu else out
     require_gpu(a_codes, "linear_fp4_gelu_dual")
     km = _kmajor_pair("linear_fp4_gelu_dual", a_codes, w_codes, 64)
+    dev = a_codes.device
     if km:
-        tokens, outs, k = a_codes.shape[1], w_scales.shape[0], a_codes.shape[0] * 128
+        tokens, outs, k = _check_kmajor_fp4("linear_fp4_gelu_dual", a_codes, a_scales, w_codes, w_scales, bias, outs)
     else:
         tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
-        if w_codes.shape[1] * 2 != k:
-            raise RuntimeError("linear_fp4_gelu_dual: operand shapes mismatch")
-    if a_scales.dtype != torch.float16 or k % 128 != 0 or outs % 128 != 0:
-        raise RuntimeError("linear_fp4_gelu_dual: operand shapes / activation scale dtype mismatch (outs must be a multiple of 128)")
-    dev = a_codes.device
-    _check_operand("linear_fp4_gelu_dual(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), dev)
-    _check_operand("linear_fp4_gelu_dual(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), dev)
+        if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16 or k % 128 != 0:
+            raise RuntimeError("linear_fp4_gelu_dual: operand shapes / activation scale dtype mismatch")
+        _check_operand("linear_fp4_gelu_dual(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), dev)
+        _check_operand("linear_fp4_gelu_dual(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), dev)
+    if outs % 128 != 0:
+        raise RuntimeError("linear_fp4_gelu_dual: outs must be a multiple of 128")
     out = torch.empty((tokens, outs), dtype=torch.float16, device=dev)
     h = torch.empty((tokens, outs), dtype=torch.float16, device=dev) if return_gelu else None
     b = None
@@ -245,7 +288,7 @@ class FP4Linear(_ScaledOperandModule):
         assert isinstance(module, torch.nn.Linear) and module.in_features % 128 == 0 and module.out_features % 8 == 0
         codes, scales = quantize_mx(module.weight.detach().float())
         if kmajor:
-            codes = to_kmajor(codes, 4, dealt=True)
+            codes, scales = to_kmajor(codes, 4, dealt=True), to_kmajor_scales(scales, weight_side=True)
         bias = None if module.bias is None else module.bias.detach().to(torch.float16)
         return cls(codes, scales, bias, module.in_features, module.out_features)
 
@@ -254,14 +297,14 @@ class FP4Linear(_ScaledOperandModule):
         """gate / residual: the AdaLN block's `residual + y.mul(gate)` fused into the GEMM (see linear_fp4)."""
         lead = x.shape[:-1]
         a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features), kmajor=self.kmajor)
-        y = linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual)
+        y = linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual, outs=self.out_features)
         return y.view(*lead, self.out_features)
 
     @torch.no_grad()
     def forward_operands(self, a_codes: torch.Tensor, a_scales: torch.Tensor, gate=None, residual=None) -> torch.Tensor:
         """The same product for an activation that already is in operand form - what the fused producers
         `rotation.rotate_quant_mx` / `rotation.adaln_rotate_quant_mx` emit: fp16 [tokens, out_features]."""
-        return linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual)
+        return linear_fp4(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, gate, residual, outs=self.out_features)
 
 
 class FP4LinearGeluDual(FP4Linear):
@@ -275,11 +318,11 @@ class FP4LinearGeluDual(FP4Linear):
     def forward(self, x):
         lead = x.shape[:-1]
         a_codes, a_scales = quantize_mx(x.to(torch.float16).reshape(-1, self.in_features), kmajor=self.kmajor)
-        return linear_fp4_gelu_dual(a_codes, a_scales, self.w_codes, self.w_scales, self.bias).view(*lead, self.out_features)
+        return linear_fp4_gelu_dual(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, outs=self.out_features).view(*lead, self.out_features)
 
     @torch.no_grad()
     def forward_operands(self, a_codes: torch.Tensor, a_scales: torch.Tensor) -> torch.Tensor:
-        return linear_fp4_gelu_dual(a_codes, a_scales, self.w_codes, self.w_scales, self.bias)
+        return linear_fp4_gelu_dual(a_codes, a_scales, self.w_codes, self.w_scales, self.bias, outs=self.out_features)
 
 
 # ---- per-token activations x per-channel weights (W6A6): one scale per row, FP8-coded levels ---------------------

@@ -291,11 +291,16 @@ def _smooth_ptr(smooth, c, device):
     return sm, sm.data_ptr()
 
 
+def _kmajor_mx_scales(rows: int, c: int, device) -> torch.Tensor:
+    from .gemm import kmajor_mx_scales
+    return kmajor_mx_scales(rows, c, device)
+
+
 def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: Optional[torch.Tensor] = None,
                     kmajor: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """rotate_quant(x, "e2m1") emitting the FP4 GEMM's operands instead of values:
     (codes uint8 [rows, C/2], scales fp16 [rows, C/128]); level(code) * scale == rotate_quant(x) bit for bit.
-    kmajor: the codes as the activation side's k-major image [C/128, rows, 64] (gemm.to_kmajor; same scales)."""
+    kmajor: the activation side's k-major images (include/fpq.h) - codes [C/128, rows, 64], scales fp32 [C/128, rows rounded up to 4]."""
     require_gpu(x, "rotate_quant_mx")
     if x.dtype not in (torch.float16, torch.float32) or x.shape[-1] % 128 != 0:
         raise RuntimeError("rotate_quant_mx: x must be float16/float32 with a last dimension that is a multiple of 128")
@@ -307,7 +312,7 @@ def rotate_quant_mx(x: torch.Tensor, d: Optional[torch.Tensor] = None, smooth: O
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     codes = torch.empty((c // 128, rows, 64) if kmajor else (rows, c // 2), dtype=torch.uint8, device=x.device)
-    scales = torch.empty((rows, c // 128), dtype=torch.float16, device=x.device)
+    scales = _kmajor_mx_scales(rows, c, x.device) if kmajor else torch.empty((rows, c // 128), dtype=torch.float16, device=x.device)
     fn = lib().fpq_rotate_quant_rows_codes_mx_km if kmajor else lib().fpq_rotate_quant_rows_codes_mx
     with device_guard(x.device):
         check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), rows, c, dtype_id(x.dtype), sm_ptr, mask, stream_ptr(x.device)),
@@ -319,7 +324,7 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
                           smooth: Optional[torch.Tensor] = None, eps: float = 1e-6, kmajor: bool = False
                           ) -> Tuple[torch.Tensor, torch.Tensor]:
     """adaln_rotate_quant(x, scale, shift, "e2m1") emitting (codes uint8 [B*L, C/2], scales fp16 [B*L, C/128]).
-    kmajor (C <= 2560): the codes as the activation side's k-major image [C/128, B*L, 64]."""
+    kmajor (C <= 2560): the activation side's k-major images - codes [C/128, B*L, 64], scales fp32 [C/128, B*L rounded up to 4]."""
     require_gpu(x, "adaln_rotate_quant_mx")
     if x.dim() != 3:
         raise RuntimeError("adaln_rotate_quant_mx: x must be [B, L, C]")
@@ -336,7 +341,8 @@ def adaln_rotate_quant_mx(x: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
     xc = x if x.is_contiguous() else x.contiguous()
     sm, sm_ptr = _smooth_ptr(smooth, c, x.device)
     codes = torch.empty((c // 128, bsz * seq, 64) if kmajor else (bsz * seq, c // 2), dtype=torch.uint8, device=x.device)
-    scales = torch.empty((bsz * seq, c // 128), dtype=torch.float16, device=x.device)
+    scales = (_kmajor_mx_scales(bsz * seq, c, x.device) if kmajor
+              else torch.empty((bsz * seq, c // 128), dtype=torch.float16, device=x.device))
     fn = lib().fpq_adaln_rotate_quant_rows_codes_mx_km if kmajor else lib().fpq_adaln_rotate_quant_rows_codes_mx
     with device_guard(x.device):
         check(fn(xc.data_ptr(), codes.data_ptr(), scales.data_ptr(), bsz * seq, c, dtype_id(x.dtype), sc.data_ptr(),

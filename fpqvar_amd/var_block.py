@@ -148,7 +148,7 @@ class GenerationBatch:
             self.wq = {n: qu.fp_quant_e2_per_group_cuda(w, 4, 128).half() for n, w in w32.items()}
             self.wop = {n: gemm.quantize_mx(w32[n]) for n in ("qkv", "proj", "fc1")}
             if kmajor:
-                self.wop = {n: (gemm.to_kmajor(c, 4, dealt=True), sc) for n, (c, sc) in self.wop.items()}
+                self.wop = {n: (gemm.to_kmajor(c, 4, dealt=True), gemm.to_kmajor_scales(sc, weight_side=True)) for n, (c, sc) in self.wop.items()}
         del w32
         self.mods = [[(torch.randn(B, 1, C, device=dev, generator=g) * 0.2).half() for _ in range(6)] for _ in range(self.depth)]
         self.e2m1 = qu.fp4_e2m1_grid.to(dev)

@@ -28,7 +28,7 @@ extern "C" {
                            0.1.3: + fpq_quant_rows_codes_segments, fpq_dequant_rows_codes_segments (round 3);
                            123: + fpq_build_tag (round 4);
                            124: + fpq_set_option, fpq_get_option, fpq_option_name, fpq_gemm_fp4_gelu_dual, fpq_gelu_quant_rows_dual (round 5);
-                           125: + k-major operand images: fpq_codes_to_kmajor, fpq_gemm_fp4_mx_km, fpq_gemm_fp4_gelu_dual_km,
+                           125: + k-major operand images: fpq_codes_to_kmajor, fpq_scales_to_kmajor, fpq_gemm_fp4_mx_km, fpq_gemm_fp4_gelu_dual_km,
                                 fpq_gemm_fp6_rows_km and the *_km producers (round 5) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
@@ -448,22 +448,35 @@ int fpq_gemm_fp6_rows_ex(const uint8_t* a_codes, const void* a_scales, int a_sca
  *   weight side ("dealt", the order the kernels hand a wavefront's 64 outputs to its four 16-row tiles):
  *     image_rows = rows rounded up to 64, row(j) = (j & ~63) + 4 * (j & 15) + ((j >> 4) & 3), zero where row(j) >= rows.
  *
- * Same arithmetic, same results bit for bit (tests/test_gpu_kmajor.py); scales, bias, out and the epilogue are unchanged.
- * fpq_codes_to_kmajor converts row-major codes (weights once at load time; any producer's output as a fallback); the
- * *_km producers below write the activation image directly.  code_bits: 4 or 6; all pointers 16-byte aligned. */
+ * The per-group scales of the FP4 GEMM travel the same way - row-major [rows, k/128] costs every tile 90 strided loads and as
+ * many LDS writes, 8 % of the kernel - as a K-MAJOR SCALE IMAGE, always fp32:
+ *     scale_image[g * image_rows + r] = (float)scales[r, g]        image_rows = rows rounded up to 4 (activation side) or to 64
+ *                                                                   (weight side; natural row order, NOT dealt), padding = 0
+ * (fp16 -> fp32 is exact: the GEMM multiplies the same numbers).  The FP6 GEMM's one scale per row stays a plain vector.
+ *
+ * Same arithmetic, same results bit for bit (tests/test_gpu_kmajor.py); bias, out and the epilogue are unchanged.
+ * fpq_codes_to_kmajor / fpq_scales_to_kmajor convert row-major codes / scales (weights once at load time; any producer's
+ * output as a fallback); the *_km producers below write the activation images directly.  code_bits: 4 or 6;
+ * scale_dtype: FPQ_F16 or FPQ_F32; all image pointers 16-byte aligned. */
 int fpq_codes_to_kmajor(const uint8_t* codes, uint8_t* image, int64_t rows, int64_t k, int code_bits, int dealt,
                         fpq_stream_t stream);
+int fpq_scales_to_kmajor(const void* scales, int scale_dtype, float* image, int64_t rows, int64_t groups, int weight_side,
+                         fpq_stream_t stream);
 /* fpq_gemm_fp4_mx_ex / fpq_gemm_fp4_gelu_dual / fpq_gemm_fp6_rows_ex on k-major images (a_image: activation side,
- * w_image: dealt weight side).  bias must be 8-byte aligned; k limited by the LDS-DMA kernels' scale tiles (FP4: the
- * row-major entry point falls back to a register-staged kernel for very long k, this one returns FPQ_ERR_SHAPE). */
+ * w_image: dealt weight side).  FP4: a_scales / w_scales are k-major SCALE images (fp32: w_scale_dtype must be FPQ_F32;
+ * tokens, outs < 2^28); FP6: the row scale vectors as before.  bias must be 8-byte aligned; k limited by the LDS-DMA
+ * kernels' scale tiles (FP4: the row-major entry point falls back to a register-staged kernel for very long k, this one
+ * returns FPQ_ERR_SHAPE). */
 int fpq_gemm_fp4_mx_km(const uint8_t* a_image, const void* a_scales, const uint8_t* w_image, const void* w_scales,
                        int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
                        const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);
 int fpq_gemm_fp4_gelu_dual_km(const uint8_t* a_image, const void* a_scales, const uint8_t* w_image, const void* w_scales,
                               int w_scale_dtype, const void* bias, void* out, void* gelu_out, int64_t tokens, int64_t outs,
                               int64_t k, void* nan_flag, fpq_stream_t stream);
-/* The activation producers writing the k-major image directly (same arguments and scales as the forms without _km;
- * image: rows * cols / 2 bytes (FP4) or rows * cols * 3 / 4 (FP6), below 2 GiB, 16-byte aligned; cols % 128 == 0).
+/* The activation producers writing the k-major images directly (same arguments as the forms without _km; image:
+ * rows * cols / 2 bytes (FP4) or rows * cols * 3 / 4 (FP6), below 2 GiB, 16-byte aligned; cols % 128 == 0).  The FP4
+ * producers' `scales` is the fp32 k-major scale image [cols / 128][rows rounded up to 4] (padding rows are not written);
+ * the FP6 producers' `scales` / `row_scales` stay one value per row.
  * fpq_quant_rows_codes_mx_km: fp16 rows only.  The fused adaLN / rotation producers: the matrix-core forms only (rows of up
  * to 2560 channels for adaLN), FPQ_ERR_SHAPE otherwise - use the row-major producer + fpq_codes_to_kmajor there. */
 int fpq_quant_rows_codes_mx_km(const void* x, uint8_t* image, void* scales, int64_t rows, int64_t cols, int in_dtype,

@@ -43,6 +43,21 @@ def test_converter_matches_the_definition(rows, bits, seg, dealt):
     assert got.shape == want.shape and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("rows", [1, 7, 64, 301, 392])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("weight_side", [False, True])
+def test_scale_converter_matches_the_definition(rows, dtype, weight_side):
+    """include/fpq.h: scale_image[g, r] = (float) scales[r, g], rows rounded up to 4 (64 on the weight side), zero padding"""
+    from fpqvar_amd import gemm
+    torch.manual_seed(rows)
+    sc = (torch.rand(rows, 15, device=_dev()) + 0.01).to(dtype)
+    got = gemm.to_kmajor_scales(sc, weight_side=weight_side)
+    pad = (rows + 63) // 64 * 64 if weight_side else (rows + 3) // 4 * 4
+    want = torch.zeros(15, pad, dtype=torch.float32, device=_dev())
+    want[:, :rows] = sc.float().t()
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+
+
 def test_converter_rejects_bad_arguments():
     from fpqvar_amd import gemm
     with pytest.raises(RuntimeError):
@@ -61,7 +76,7 @@ def test_quantize_mx_km(rows, k):
     codes, scales = gemm.quantize_mx(x)
     image, scales_km = gemm.quantize_mx(x, kmajor=True)
     assert image.shape == (k // 128, rows, 64)
-    assert torch.equal(scales, scales_km)
+    assert torch.equal(gemm.to_kmajor_scales(scales), scales_km)
     assert torch.equal(image, gemm.to_kmajor(codes, 4))
 
 
@@ -87,7 +102,7 @@ def test_rotate_quant_mx_km(rows, c, dtype, smooth):
     sm = (torch.rand(c, device=_dev()) + 0.5) if smooth else None
     codes, scales = rotation.rotate_quant_mx(x, smooth=sm)
     image, scales_km = rotation.rotate_quant_mx(x, smooth=sm, kmajor=True)
-    assert torch.equal(scales, scales_km)
+    assert torch.equal(gemm.to_kmajor_scales(scales), scales_km)
     assert torch.equal(image, gemm.to_kmajor(codes, 4))
 
 
@@ -103,7 +118,7 @@ def test_adaln_rotate_quant_mx_km(b, l, c, dtype):
     codes, scales = rotation.adaln_rotate_quant_mx(x, scale, shift, smooth=sm)
     image, scales_km = rotation.adaln_rotate_quant_mx(x, scale, shift, smooth=sm, kmajor=True)
     assert image.shape == (c // 128, b * l, 64)
-    assert torch.equal(scales, scales_km)
+    assert torch.equal(gemm.to_kmajor_scales(scales), scales_km)
     assert torch.equal(image, gemm.to_kmajor(codes, 4))
 
 
@@ -149,12 +164,14 @@ def test_linear_fp4_km_equals_row_major(tokens, k, outs, cfg, lib_options):
     bias = (torch.randn(outs, device=_dev()) * 0.1).half()
     (ac, asc), (wc, wsc) = gemm.quantize_mx(x), gemm.quantize_mx(w)
     ai, wi = gemm.to_kmajor(ac, 4), gemm.to_kmajor(wc, 4, dealt=True)
-    assert torch.equal(gemm.linear_fp4(ac, asc, wc, wsc, bias), gemm.linear_fp4(ai, asc, wi, wsc, bias))
+    asi, wsi = gemm.to_kmajor_scales(asc), gemm.to_kmajor_scales(wsc, weight_side=True)
+    assert torch.equal(gemm.linear_fp4(ac, asc, wc, wsc, bias), gemm.linear_fp4(ai, asi, wi, wsi, bias))
+    assert torch.equal(gemm.linear_fp4(ac, asc, wc, wsc), gemm.linear_fp4(ai, asi, wi, wsi, outs=outs))
     if tokens % 3 == 0 or tokens == 33:
         bsz = 3 if tokens % 3 == 0 else 1
         gate = torch.randn(bsz, 1, outs, device=_dev()).half()
         res = torch.randn(tokens, outs, device=_dev()).half()
-        assert torch.equal(gemm.linear_fp4(ac, asc, wc, wsc, bias, gate, res), gemm.linear_fp4(ai, asc, wi, wsc, bias, gate, res))
+        assert torch.equal(gemm.linear_fp4(ac, asc, wc, wsc, bias, gate, res), gemm.linear_fp4(ai, asi, wi, wsi, bias, gate, res))
 
 
 @pytest.mark.parametrize("tokens,k,outs", [(1, 128, 128), (33, 256, 128), (301, 1920, 384), (4356, 1920, 7680), (700, 1920, 1920)])
@@ -169,8 +186,9 @@ def test_linear_fp4_gelu_dual_km_equals_row_major(tokens, k, outs, cfg, lib_opti
     bias = (torch.randn(outs, device=_dev()) * 0.1).half()
     (ac, asc), (wc, wsc) = gemm.quantize_mx(x), gemm.quantize_mx(w)
     ai, wi = gemm.to_kmajor(ac, 4), gemm.to_kmajor(wc, 4, dealt=True)
+    asi, wsi = gemm.to_kmajor_scales(asc), gemm.to_kmajor_scales(wsc, weight_side=True)
     q0, h0 = gemm.linear_fp4_gelu_dual(ac, asc, wc, wsc, bias, return_gelu=True)
-    q1, h1 = gemm.linear_fp4_gelu_dual(ai, asc, wi, wsc, bias, return_gelu=True)
+    q1, h1 = gemm.linear_fp4_gelu_dual(ai, asi, wi, wsi, bias, return_gelu=True)
     assert torch.equal(q0, q1) and torch.equal(h0, h1)
 
 
@@ -198,12 +216,17 @@ def test_mixed_layouts_are_an_error():
     x = torch.randn(64, 256, device=_dev()).half()
     w = torch.randn(128, 256, device=_dev())
     (ac, asc), (wc, wsc) = gemm.quantize_mx(x), gemm.quantize_mx(w)
+    asi, wsi = gemm.to_kmajor_scales(asc), gemm.to_kmajor_scales(wsc, weight_side=True)
     with pytest.raises(RuntimeError):
-        gemm.linear_fp4(gemm.to_kmajor(ac, 4), asc, wc, wsc)
+        gemm.linear_fp4(gemm.to_kmajor(ac, 4), asi, wc, wsc)
     with pytest.raises(RuntimeError):
-        gemm.linear_fp4(ac, asc, gemm.to_kmajor(wc, 4, dealt=True), wsc)
+        gemm.linear_fp4(ac, asc, gemm.to_kmajor(wc, 4, dealt=True), wsi)
     with pytest.raises(RuntimeError):   # an activation-side (undealt, unpadded) image is not a weight image
-        gemm.linear_fp4(gemm.to_kmajor(ac, 4), asc, gemm.to_kmajor(wc[:100], 4), wsc[:100])
+        gemm.linear_fp4(gemm.to_kmajor(ac, 4), asi, gemm.to_kmajor(wc[:100], 4), gemm.to_kmajor_scales(wsc[:100]))
+    with pytest.raises(RuntimeError):   # images need scale IMAGES (fp32 [K/128, rows]), not the row-major fp16 scales
+        gemm.linear_fp4(gemm.to_kmajor(ac, 4), asc, gemm.to_kmajor(wc, 4, dealt=True), wsi)
+    with pytest.raises(RuntimeError):   # a width the weight image cannot have
+        gemm.linear_fp4(gemm.to_kmajor(ac, 4), asi, gemm.to_kmajor(wc, 4, dealt=True), wsi, outs=32)
 
 
 @pytest.mark.parametrize("cls_name", ["FP4Linear", "FP4LinearGeluDual", "FP6Linear"])
@@ -244,6 +267,7 @@ def test_kmajor_path_under_graph_replay():
     torch.cuda.synchronize()
     a, s = rotation.adaln_rotate_quant_mx(x, sc, sc)
     want = gemm.linear_fp4(a, s, *gemm.quantize_mx(lin.weight.detach().float()), lin.bias.detach().half())
+    assert mod.w_scales.shape == (15, 5760) and mod.w_scales.dtype == torch.float32
     assert torch.equal(y, want)
 
 

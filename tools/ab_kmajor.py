@@ -41,7 +41,7 @@ bits = 6 if W6 else 4
 quant = gemm.quantize_fp6 if W6 else gemm.quantize_mx
 lin = gemm.linear_fp6 if W6 else gemm.linear_fp4
 w = {n: quant(torch.randn(o, C, device=dev) * 0.02) for n, o in (("qkv", 3 * C), ("proj", C), ("fc1", 4 * C))}
-wk = {n: (gemm.to_kmajor(c, bits, dealt=True), s) for n, (c, s) in w.items()}
+wk = {n: (gemm.to_kmajor(c, bits, dealt=True), s if W6 else gemm.to_kmajor_scales(s, weight_side=True)) for n, (c, s) in w.items()}
 sm = torch.rand(C, device=dev) + 0.5
 print(f"# {cfg}: us per launch, row-major / k-major (ratio); d30 batch of {B} rows per token")
 print("# tokens   adaLN producer          quantizer (proj input)   GEMM qkv                GEMM proj               GEMM fc1" + ("" if W6 else " (+GELU+dual)"))

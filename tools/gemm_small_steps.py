@@ -22,6 +22,8 @@ for O in (5760, 1920, 7680):
     wc, wsc = quant(w)
     if KM:
         wc = gemm.to_kmajor(wc, 4 if kind == "fp4" else 6, dealt=True)
+        if kind == "fp4":
+            wsc = gemm.to_kmajor_scales(wsc, weight_side=True)
     for pn in (1, 2, 3, 4, 5, 6, 8, 10, 13, 16):
         T = 100 * pn * pn
         x = torch.randn(T, K, device=dev).half()

@@ -52,7 +52,7 @@ elif which in ("gemm", "gemm_km"):
     ac, asc = gemm.quantize_mx(x, kmajor=which == "gemm_km")
     wc, wsc = gemm.quantize_mx(w)
     if which == "gemm_km":
-        wc = gemm.to_kmajor(wc, 4, dealt=True)
+        wc, wsc = gemm.to_kmajor(wc, 4, dealt=True), gemm.to_kmajor_scales(wsc, weight_side=True)
     fn = lambda: gemm.linear_fp4(ac, asc, wc, wsc)
 elif which in ("fc1", "fc1_km"):   # fc1 with GELU and fc2's dual quantizer in the GEMM's epilogue (fpq_gemm_fp4_gelu_dual), VAR-d30's shape
     from fpqvar_amd import gemm
@@ -62,7 +62,7 @@ elif which in ("fc1", "fc1_km"):   # fc1 with GELU and fc2's dual quantizer in t
     ac, asc = gemm.quantize_mx(x, kmajor=which == "fc1_km")
     wc, wsc = gemm.quantize_mx(w)
     if which == "fc1_km":
-        wc = gemm.to_kmajor(wc, 4, dealt=True)
+        wc, wsc = gemm.to_kmajor(wc, 4, dealt=True), gemm.to_kmajor_scales(wsc, weight_side=True)
     fn = lambda: gemm.linear_fp4_gelu_dual(ac, asc, wc, wsc, bias)
 elif which in ("gemm6", "gemm8", "gemm6_km"):   # the row-scaled GEMMs of the W6A6 configuration (6-bit packed / E4M3 bytes)
     from fpqvar_amd import gemm
