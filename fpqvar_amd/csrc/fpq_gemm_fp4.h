@@ -504,6 +504,12 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
     }
   } else {
     load_scale_tiles<Tsw, BM, BN, NTHR>(sa, sw, lsa, lsw, t0, o0, T, O, G, tid);
+    // A wait the COMPILER sees (the builtin, not assembly): its scoreboard still carries the scale loads above, whose last
+    // waits it counted without knowing of the stage-0 pieces in the same queue - left like that, it protects their
+    // destination registers with vmcnt waits inside the main loop, and those wait for the stage just requested.
+    // (It has to stand in THIS branch: behind the join, under a second `if (!km)`, the compiler's scoreboard keeps the loads
+    // pending on the path it cannot rule out, and the loop got its vmcnt(0) back - 8 % - profiles/r05_kmajor_ab.txt.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   }
   uint16_t* lut = nullptr;
   if constexpr (FC1) {   // the dual quantizer's bucket table, behind the scale tiles; visible after the first barrier of the main loop
@@ -511,11 +517,6 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
     lut16_stage(lut, xe.tab, xe.a.shift);
   }
 
-  // A wait the COMPILER sees (the builtin, not assembly): its scoreboard still carries the scale loads above, whose last
-  // waits it counted without knowing of the stage-0 pieces in the same queue - left like that, it protects their
-  // destination registers with vmcnt waits inside the main loop, and those wait for the stage just requested.
-  // (k-major: no load the compiler knows of is in flight - nothing to wait for here, the prologue runs on)
-  if (!km) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
   // the tile's bias (four consecutive outputs per lane, see the epilogue) is requested here, not between the last MFMA and
   // the stores

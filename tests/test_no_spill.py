@@ -101,3 +101,63 @@ def test_fc1_tail_register_budgets(tmp_path):
     for n, r in fc1:
         limit = 256 if "Li8ELi4E" in n else 168
         assert int(r["vgpr_count"]) + int(r.get("agpr_count", 0)) <= limit and int(r.get("private_segment_fixed_size", 0)) == 0, (n, r["vgpr_count"])
+
+
+def _code_objects(tmp_path):
+    """the gfx950 code objects inside the library's fat binary (paths)"""
+    objcopy, bundler = _tool("llvm-objcopy"), _tool("clang-offload-bundler")
+    if not all((objcopy, bundler, _tool("llvm-objdump"))):
+        pytest.skip("LLVM binutils of the ROCm toolchain not found")
+    fat = str(tmp_path / "fatbin_isa")
+    subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", LIB, fat], check=True)
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), data)]
+    out = []
+    for k, a in enumerate(starts):
+        b = starts[k + 1] if k + 1 < len(starts) else len(data)
+        bundle, elf = str(tmp_path / f"isa_bundle{k}"), str(tmp_path / f"isa_co{k}.elf")
+        open(bundle, "wb").write(data[a:b])
+        subprocess.run([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={bundle}", f"--output={elf}"], check=True)
+        out.append(elf)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libfpq_hip.so not built")
+def test_gemm_main_loops_carry_no_compiler_vmem_waits(tmp_path):
+    """The LDS-DMA GEMMs wait for a stage with ONE explicit `s_waitcnt vmcnt(0)` in front of the loop's barrier; the loads are
+    assembly the compiler does not see.  If its scoreboard believes that other loads are still in flight (the prologue's scale
+    loads behind a branch it cannot rule out: round 5), it inserts vmcnt waits INSIDE the loop - each one waits for the stage just
+    requested and the pipeline is gone (8 % on the FP4 GEMM, silently).  Between the loop's barrier and its back edge there must
+    be none."""
+    checked = 0
+    for elf in _code_objects(tmp_path):
+        txt = subprocess.run([_tool("llvm-objdump"), "-d", elf], capture_output=True, text=True, check=True).stdout.splitlines()
+        heads = [i for i, l in enumerate(txt) if re.search(r"<.*(gemm_fp4_glds_kernel|gemm_fp6_rows_kernel|gemm_fp8_rows_kernel).*>:$", l)]
+        for h in heads:
+            ops = []                                     # (address, text)
+            for l in txt[h + 1:]:
+                m = re.match(r"\t(.*?)\s*// ([0-9A-Fa-f]+):", l)
+                if m:
+                    ops.append((int(m.group(2), 16), " ".join(m.group(1).split())))
+                    if ops[-1][1].startswith("s_endpgm"):
+                        break
+            mf = [i for i, (_, o) in enumerate(ops) if o.startswith("v_mfma")]
+            assert mf, txt[h]
+            # the main loop: closed by the first branch behind the last MFMA that jumps back in front of the first one
+            loop = None
+            for i in range(mf[-1], len(ops)):
+                addr, o = ops[i]
+                if o.startswith("s_cbranch"):
+                    off = int(o.split()[1])
+                    target = addr + 4 + 4 * (off - 65536 if off >= 32768 else off)
+                    if target <= ops[mf[0]][0]:
+                        loop = [o2 for a2, o2 in ops if target <= a2 <= addr]
+                        break
+            between = [o for _, o in ops[mf[0]:mf[-1] + 1] if o.startswith("s_waitcnt") and "vmcnt" in o]
+            assert not between, (txt[h][:160], between)                      # never among the MFMAs
+            if "gemm_fp4_glds_kernel" in txt[h]:                             # (the row-scaled kernels' loops are not contiguous in the image)
+                assert loop, txt[h]
+                waits = [o for o in loop if o.startswith("s_waitcnt") and "vmcnt" in o]
+                assert waits == ["s_waitcnt vmcnt(0)"], (txt[h][:160], waits)    # the explicit one in front of the barrier, nothing else
+            checked += 1
+    assert checked >= 20, checked
