@@ -149,7 +149,8 @@ def test_producers_refuse_what_they_cannot_write():
 
 
 # ---- GEMMs -----------------------------------------------------------------------------------------------------------
-SHAPES = [(1, 128, 8), (33, 256, 128), (301, 1920, 392), (700, 1920, 1920), (4356, 1920, 5760), (2500, 1024, 3072), (513, 2304, 2304)]
+SHAPES = [(1, 128, 8), (33, 256, 128), (301, 1920, 392), (700, 1920, 1920), (4356, 1920, 5760), (2500, 1024, 3072), (513, 2304, 2304),
+          (100, 8192, 256), (4100, 3840, 640)]   # (long K: 64 / 30 groups of scale planes, the bigger tiles' LDS images no longer fit twice)
 
 
 @pytest.mark.parametrize("tokens,k,outs", SHAPES)
