@@ -72,7 +72,9 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     gen = res["generation"]
     assert len(gen) == 6 and all("error" not in g and g["replicas_ok"] == 2 and g["images_per_s"] > 0 for g in gen), gen
     by = {(g["model"], g["path"]): g["ms_per_batch"] for g in gen}
-    assert by[("d30-256", "Q")] < by[("d30-256", "F")] < by[("d30-256", "R")]        # the fused paths beat the reference's op sequence
+    # the fused paths beat the reference's op sequence (a factor of 5 - 7; Q against F is 1.3 and, with two ranks taking turns on
+    # one GPU, not an order this rehearsal can assert)
+    assert max(by[("d30-256", "Q")], by[("d30-256", "F")]) < by[("d30-256", "R")]
     assert res["omitted_at_n_gt_1"] == ["cpu_baseline", "other_kernels", "unfused_gpu"]
 
 
