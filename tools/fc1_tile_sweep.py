@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The fused fc1 GEMM (gemm.linear_fp4_gelu_dual) at the token counts of the ten scale steps per LDS-DMA tiling (library switch
 FPQ_GEMM_CFG: 30 = 64 x 128, 20 = 128 x 128, 10 = 256 x 128 tiles) - what the default selection in fpq_gemm_fp4_gelu_dual rests on.
-usage: fc1_tile_sweep.py [d30|d36]"""
+usage: fc1_tile_sweep.py [d30|d36] [kmajor]      kmajor: operands as k-major images (include/fpq.h)"""
 import os
 import statistics
 import sys
@@ -11,11 +11,14 @@ import torch  # noqa: E402
 
 from fpqvar_amd import _lib, gemm  # noqa: E402
 
-model = sys.argv[1] if len(sys.argv) > 1 else "d30"
+KM = "kmajor" in sys.argv[1:]
+model = ([a for a in sys.argv[1:] if a != "kmajor"] or ["d30"])[0]
 C, B, pns = (1920, 100, (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)) if model == "d30" else (2304, 20, (1, 2, 3, 4, 6, 9, 13, 18, 24, 32))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 w = gemm.quantize_mx(torch.randn(4 * C, C, device=dev) * 0.02)
+if KM:
+    w = (gemm.to_kmajor(w[0], 4, dealt=True), gemm.to_kmajor_scales(w[1], weight_side=True))
 bias = (torch.randn(4 * C, device=dev) * 0.1).half()
 
 
@@ -45,7 +48,7 @@ print(f"# {model}: fused fc1 [{C} -> {4 * C}], us per call by tiling (hipGraph, 
 print(f"{'tokens':>7} {'default':>9} {'64x128':>9} {'128x128':>9} {'256x128':>9}")
 tot = {k: 0.0 for k in ("default", 30, 20, 10)}
 for T in [B * p * p for p in pns]:
-    a = gemm.quantize_mx(torch.randn(T, C, device=dev).half())
+    a = gemm.quantize_mx(torch.randn(T, C, device=dev).half(), kmajor=KM)
     row = []
     for cfg in (None, 30, 20, 10):
         _lib.set_option("FPQ_GEMM_CFG", cfg)
