@@ -322,3 +322,30 @@ def test_quantize_var_uses_kmajor_operands_and_survives_a_state_dict_round_trip(
                 m.w_codes.zero_()
         again.load_state_dict(km.state_dict())
         assert torch.equal(again(x), y)
+
+
+def test_random_shapes_agree_with_the_row_major_path():
+    """forty seeded random (tokens, K, outs) triples: producer images == converted row-major outputs, k-major GEMMs == row-major
+    GEMMs (FP4 with bias and an odd width, FP6), every tiling the dispatcher may pick"""
+    import random
+    from fpqvar_amd import gemm
+    rnd = random.Random(2026)
+    for case in range(40):
+        tokens = rnd.choice([1, 2, 3, 5, 17, 63, 64, 65, 127, 129, 255, 257, 300, 511, 777, 1025, 2049])
+        k = 128 * rnd.randint(1, 20)
+        outs = 8 * rnd.randint(1, 120)
+        torch.manual_seed(case)
+        x = (torch.randn(tokens, k, device=_dev()) * rnd.choice([0.01, 1.0, 30.0])).half()
+        w = torch.randn(outs, k, device=_dev()) * 0.05
+        bias = (torch.randn(outs, device=_dev()) * 0.1).half() if rnd.random() < 0.7 else None
+        # FP4
+        (ac, asc), (wc, wsc) = gemm.quantize_mx(x), gemm.quantize_mx(w)
+        ai, asi = gemm.quantize_mx(x, kmajor=True)
+        assert torch.equal(ai, gemm.to_kmajor(ac, 4)) and torch.equal(asi, gemm.to_kmajor_scales(asc)), (case, tokens, k)
+        wi, wsi = gemm.to_kmajor(wc, 4, dealt=True), gemm.to_kmajor_scales(wsc, weight_side=True)
+        assert torch.equal(gemm.linear_fp4(ac, asc, wc, wsc, bias), gemm.linear_fp4(ai, asi, wi, wsi, bias, outs=outs)), (case, tokens, k, outs)
+        # FP6
+        (ac6, as6), (wc6, ws6) = gemm.quantize_fp6(x), gemm.quantize_fp6(w)
+        ai6, as6k = gemm.quantize_fp6(x, kmajor=True)
+        assert torch.equal(ai6, gemm.to_kmajor(ac6, 6)) and torch.equal(as6, as6k), (case, tokens, k)
+        assert torch.equal(gemm.linear_fp6(ac6, as6, wc6, ws6, bias), gemm.linear_fp6(ai6, as6k, gemm.to_kmajor(wc6, 6, dealt=True), ws6, bias)), (case, tokens, k, outs)
