@@ -34,6 +34,12 @@ class GemmEpilogue(_c.Structure):
     _fields_ = [("gate", _c.c_void_p), ("residual", _c.c_void_p), ("rows_per_gate", _c.c_int64)]
 
 
+class GemmSplit(_c.Structure):
+    """fpq_gemm_split_t (include/fpq.h)."""
+    _fields_ = [("part_cols", _c.c_int64), ("n_parts", _c.c_int32), ("out", _c.c_void_p * 3), ("row_stride", _c.c_int64 * 3),
+                ("rows_per_batch", _c.c_int64), ("batch_stride", _c.c_int64 * 3), ("row0", _c.c_int64 * 3)]
+
+
 _SIGS = {
     "fpq_version": (_c.c_int, []),
     "fpq_strerror": (_c.c_char_p, [_c.c_int]),
@@ -112,6 +118,8 @@ _SIGS = {
                                        _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_gemm_fp4_gelu_dual": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                            _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "fpq_gemm_fp4_mx_split": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                          _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "fpq_gemm_fp4_mx_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                        _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "fpq_gemm_fp4_gelu_dual_km": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,

@@ -121,6 +121,12 @@ static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi*
   epi->resid = nullptr;
   epi->rows_per_gate = 1;
   epi->km_w_rows = 0;
+  epi->sp_cols = 0;
+  epi->sp_rpb = 1;
+  for (int p = 0; p < 3; ++p) {
+    epi->sp_out[p] = nullptr;
+    epi->sp_stride[p] = epi->sp_bstride[p] = epi->sp_row0[p] = 0;
+  }
   if (!ep) return FPQ_OK;
   if (ep->gate && (ep->rows_per_gate < 1 || ep->rows_per_gate > 0x7FFFFFFF)) return FPQ_ERR_ARG;
   if ((((uintptr_t)ep->gate | (uintptr_t)ep->residual) & 15) != 0) return FPQ_ERR_ARG;
@@ -134,10 +140,27 @@ static int gemm_epilogue(const fpq_gemm_epilogue_t* ep, int64_t tokens, GemmEpi*
 // km: both operands are k-major images (include/fpq.h); only the LDS-DMA kernels read them
 static int gemm_fp4_mx_impl(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales,
                             int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
-                            const fpq_gemm_epilogue_t* epilogue, bool km, fpq_stream_t stream) {
+                            const fpq_gemm_epilogue_t* epilogue, bool km, fpq_stream_t stream, const fpq_gemm_split_t* split = nullptr) {
   if (tokens < 0 || outs < 0 || k < 0) return FPQ_ERR_ARG;
   GemmEpi epi;
   if (int rc = gemm_epilogue(epilogue, tokens, &epi)) return rc;
+  if (split) {   // the outputs leave in column parts, each to its own rows (include/fpq.h): the LDS-DMA kernels' plain epilogue only
+    if (epilogue || split->n_parts < 1 || split->n_parts > 3 || split->part_cols <= 0 || split->part_cols % 128 != 0 ||
+        outs != split->n_parts * split->part_cols || split->rows_per_batch < 1 || split->rows_per_batch > 0x7FFFFFFF)
+      return FPQ_ERR_ARG;
+    epi.sp_cols = (int)split->part_cols;
+    epi.sp_rpb = (int)split->rows_per_batch;
+    for (int p = 0; p < split->n_parts; ++p) {
+      if (!split->out[p] || ((uintptr_t)split->out[p] & 7) != 0 || split->row_stride[p] < split->part_cols || split->row_stride[p] % 4 != 0 ||
+          split->batch_stride[p] < 0 || split->row0[p] < 0)
+        return FPQ_ERR_ARG;
+      epi.sp_out[p] = (_Float16*)split->out[p];
+      epi.sp_stride[p] = split->row_stride[p];
+      epi.sp_bstride[p] = split->batch_stride[p];
+      epi.sp_row0[p] = split->row0[p];
+    }
+    if (!out) out = split->out[0];   // (never written: every tile belongs to a part)
+  }
   if (km) {   // scales come as fp32 k-major images too (include/fpq.h); their lane offsets are 32-bit: 3 planes of rows * 4 bytes
     if (w_scale_dtype != FPQ_F32) return FPQ_ERR_DTYPE;
     if (tokens >= (1ll << 28) || outs >= (1ll << 28)) return FPQ_ERR_SHAPE;
@@ -163,7 +186,7 @@ static int gemm_fp4_mx_impl(const uint8_t* a_codes, const void* a_scales, const 
   const bool big_fits_twice = 2 * GemmGldsCfg<8, 4>::lds(G) <= 160 * 1024;
   // (the LDS-DMA kernel reads the bias four outputs at a time: a bias that is not 8-byte aligned goes to the other kernel)
   int cfg = ((uintptr_t)bias & 7) != 0 ? 0 : fpq_opt_set(OPT_FPQ_GEMM_CFG) ? fpq_opt(OPT_FPQ_GEMM_CFG, 0) : mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
-  if (km) {
+  if (km || split) {
     if (((uintptr_t)bias & 7) != 0 || outs + 63 > 0x7FFFFFFF) return FPQ_ERR_ARG;
     if (cfg != 10 && cfg != 20 && cfg != 30) cfg = mid_tiles <= 384 ? 30 : (big_tiles >= 4000 && big_fits_twice) ? 10 : 20;
   }
@@ -205,7 +228,7 @@ static int gemm_fp4_mx_impl(const uint8_t* a_codes, const void* a_scales, const 
   if (cfg == 10) FPQ_GEMM_GLDS(8, 4);
   if (cfg == 10 || cfg == 20 || cfg == 30) FPQ_GEMM_GLDS(4, 4);   // (the larger tile's LDS image may not fit where the smaller one's does)
 #undef FPQ_GEMM_GLDS
-  if (km) return FPQ_ERR_SHAPE;   // K too long for the LDS-DMA kernel's scale tiles: the register-staged kernels read row-major codes only
+  if (km || split) return FPQ_ERR_SHAPE;   // K too long for the LDS-DMA kernel's scale tiles: the register-staged kernels read row-major codes, write one tensor
   if (cfg == 1) FPQ_GEMM_LAUNCH(2, 4, 4, 2);
   else if (cfg == 2) FPQ_GEMM_LAUNCH(4, 4, 2, 4);
   else FPQ_GEMM_LAUNCH(4, 4, 2, 2);
@@ -217,6 +240,12 @@ int fpq_gemm_fp4_mx_ex(const uint8_t* a_codes, const void* a_scales, const uint8
                        int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,
                        const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream) {
   return gemm_fp4_mx_impl(a_codes, a_scales, w_codes, w_scales, w_scale_dtype, bias, out, tokens, outs, k, epilogue, false, stream);
+}
+int fpq_gemm_fp4_mx_split(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales, int w_scale_dtype,
+                          const void* bias, int64_t tokens, int64_t outs, int64_t k, const fpq_gemm_split_t* split, int kmajor,
+                          fpq_stream_t stream) {
+  if (!split) return FPQ_ERR_ARG;
+  return gemm_fp4_mx_impl(a_codes, a_scales, w_codes, w_scales, w_scale_dtype, bias, nullptr, tokens, outs, k, nullptr, kmajor != 0, stream, split);
 }
 int fpq_gemm_fp4_mx_km(const uint8_t* a_image, const void* a_scales, const uint8_t* w_image, const void* w_scales,
                        int w_scale_dtype, const void* bias, void* out, int64_t tokens, int64_t outs, int64_t k,

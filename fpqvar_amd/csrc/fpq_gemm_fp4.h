@@ -46,6 +46,12 @@ struct GemmEpi {
   // K-MAJOR OPERAND IMAGES (include/fpq.h, "k-major operand images"; the FP4 and FP6 LDS-DMA kernels): 0 = row-major codes,
   // else the image rows of the weight side (outs rounded up to 64; the activation side has exactly T).
   int km_w_rows;
+  // SPLIT OUTPUT (include/fpq.h, fpq_gemm_split_t; the FP4 LDS-DMA kernel's plain epilogue): sp_cols != 0: the outputs are sp_cols-wide
+  // column parts with a destination each - token t = b * sp_rpb + l of part p goes to row b * sp_bstride[p] + sp_row0[p] + l of
+  // sp_out[p] (sp_stride[p] elements per row).  mat_qkv writes q to its own tensor and k, v straight into the KV cache's slots.
+  int sp_cols, sp_rpb;
+  _Float16* sp_out[3];
+  int64_t sp_stride[3], sp_bstride[3], sp_row0[3];
 };
 typedef _Float16 fpq_h2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 fpq_h4_t __attribute__((ext_vector_type(4)));
@@ -697,6 +703,19 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
     gr0 = first - gq0 * epi.rows_per_gate;
     gq_last = (T - 1) / epi.rows_per_gate;
   }
+  // split output: the tile lies inside ONE part (sp_cols % 128 == 0); its destination, and the batch entry / row of the wavefront's first row
+  const int part = epi.sp_cols ? o0 / epi.sp_cols : 0;
+  _Float16* const sp_base = part == 0 ? epi.sp_out[0] : part == 1 ? epi.sp_out[1] : epi.sp_out[2];
+  const int64_t sp_stride = part == 0 ? epi.sp_stride[0] : part == 1 ? epi.sp_stride[1] : epi.sp_stride[2];
+  const int64_t sp_bstride = part == 0 ? epi.sp_bstride[0] : part == 1 ? epi.sp_bstride[1] : epi.sp_bstride[2];
+  const int64_t sp_row0 = part == 0 ? epi.sp_row0[0] : part == 1 ? epi.sp_row0[1] : epi.sp_row0[2];
+  const bool sp_far = epi.sp_cols && epi.sp_rpb >= WROWS;
+  int sb0 = 0, sr0 = 0;
+  if (epi.sp_cols) {
+    const int first = t0 + wm * WROWS + 4 * (lane >> 4);
+    sb0 = first / epi.sp_rpb;
+    sr0 = first - sb0 * epi.sp_rpb;
+  }
   // (requesting the gate / residual rows one tile row ahead of their use - the compiler may not move a load above a store
   // that could alias it, and the residual may BE the output - was measured: 13 % slower with the fused tail, round 4)
 #pragma unroll
@@ -730,6 +749,25 @@ __global__ __launch_bounds__(256, (MT * NT > 16 ? 2 : 3)) FPQ_NOPK void gemm_fp4
       for (int i = 0; i < 4; ++i) rs[i] = *(const fpq_h4_t*)(epi.resid + (int64_t)tc[i] * O + oc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = rs[i] + y[i];
+    }
+    if (epi.sp_cols) {   // uniform: four 8-byte stores to the part's rows (one division per tile while a batch entry spans the wavefront's rows)
+      const int oc_l = oc - part * epi.sp_cols;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int off = sr0 + m * 16 + i;
+        int bb, ll;
+        if (sp_far) {
+          const int wrap = off >= epi.sp_rpb ? 1 : 0;
+          bb = sb0 + wrap;
+          ll = off - wrap * epi.sp_rpb;
+        } else {
+          bb = tc[i] / epi.sp_rpb;
+          ll = tc[i] - bb * epi.sp_rpb;
+        }
+        if (t_first + i < T && o < O)
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x2, y[i]), (u32x2*)(sp_base + ((int64_t)bb * sp_bstride + sp_row0 + ll) * sp_stride + oc_l));
+      }
+      continue;
     }
     // (non-temporal: a round of tiles writes as much as an XCD's L2 holds - the operands should stay there; +1-2 %)
     FPQ_GEMM_ROWS_STORE(y, t_first, tc, o, oc);

@@ -219,6 +219,51 @@ def linear_fp4(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Ten
     return out
 
 
+def linear_fp4_qkv_to_cache(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
+                            bias: Optional[torch.Tensor], cache_kv: torch.Tensor, pos: int, seq: int) -> torch.Tensor:
+    """mat_qkv of an attention block with a split output (fpq_gemm_fp4_mx_split): `qkv = linear_fp4(a, w, bias)` for tokens
+    [B * seq] and outs = 3 * C, but only q comes back - fp16 [B, seq, C] - while k and v are written straight into the KV cache
+    `cache_kv` [2, B, max_len, H, c] (C = H * c) at token positions pos .. pos + seq: what `qkv.view(B, L, 3, H, c).unbind(2)`
+    followed by the cache's copy-in (tr/basic_var.py:173-209; kv_cache.IncrementalKVCache.append) leaves there, without the copy.
+    Operands row-major (2-D) or k-major images (3-D) as in linear_fp4."""
+    from ._lib import GemmSplit
+    require_gpu(a_codes, "linear_fp4_qkv_to_cache")
+    km = _kmajor_pair("linear_fp4_qkv_to_cache", a_codes, w_codes, 64)
+    dev = a_codes.device
+    if cache_kv.dim() != 5 or cache_kv.shape[0] != 2 or cache_kv.dtype != torch.float16 or not cache_kv.is_contiguous() or cache_kv.device != dev:
+        raise RuntimeError("linear_fp4_qkv_to_cache: cache_kv must be a contiguous float16 [2, B, max_len, H, c] tensor on the operands' device")
+    _, bsz, max_len, heads, hd = cache_kv.shape
+    c = heads * hd
+    if km:
+        tokens, outs, k = _check_kmajor_fp4("linear_fp4_qkv_to_cache", a_codes, a_scales, w_codes, w_scales, bias, 3 * c)
+    else:
+        tokens, outs, k = a_codes.shape[0], w_codes.shape[0], a_codes.shape[1] * 2
+        if w_codes.shape[1] * 2 != k or a_scales.dtype != torch.float16 or k % 128 != 0:
+            raise RuntimeError("linear_fp4_qkv_to_cache: operand shapes / activation scale dtype mismatch")
+        _check_operand("linear_fp4_qkv_to_cache(activation)", a_codes, a_scales, tokens, k // 2, tokens * (k // 128), dev)
+        _check_operand("linear_fp4_qkv_to_cache(weight)", w_codes, w_scales, outs, k // 2, outs * (k // 128), dev)
+    if outs != 3 * c or c % 128 != 0 or seq < 1 or tokens != bsz * seq or pos < 0 or pos + seq > max_len:
+        raise RuntimeError(f"linear_fp4_qkv_to_cache: {tokens} tokens x {outs} outputs do not fit a cache of [{bsz}, {max_len}, {heads}, {hd}] at {pos} .. {pos + seq}")
+    q = torch.empty((bsz, seq, c), dtype=torch.float16, device=dev)
+    b = None
+    if bias is not None:
+        if bias.numel() != outs or bias.device != dev:
+            raise RuntimeError("linear_fp4_qkv_to_cache: bias must hold one value per output on the operands' device")
+        b = bias.detach().to(torch.float16).reshape(-1).contiguous()
+        if b.data_ptr() % 16:
+            b = b.clone()
+    sp = GemmSplit()
+    sp.part_cols, sp.n_parts, sp.rows_per_batch = c, 3, seq
+    for p, (t, bstride, row0) in enumerate(((q, seq, 0), (cache_kv[0], max_len, pos), (cache_kv[1], max_len, pos))):
+        sp.out[p], sp.row_stride[p], sp.batch_stride[p], sp.row0[p] = t.data_ptr(), c, bstride, row0
+    if tokens:
+        with device_guard(dev):
+            check(lib().fpq_gemm_fp4_mx_split(a_codes.data_ptr(), a_scales.data_ptr(), w_codes.data_ptr(), w_scales.data_ptr(),
+                                              dtype_id(w_scales.dtype), None if b is None else b.data_ptr(), tokens, outs, k,
+                                              ctypes.byref(sp), 1 if km else 0, stream_ptr(dev)), "fpq_gemm_fp4_mx_split")
+    return q
+
+
 def linear_fp4_gelu_dual(a_codes: torch.Tensor, a_scales: torch.Tensor, w_codes: torch.Tensor, w_scales: torch.Tensor,
                          bias: Optional[torch.Tensor] = None, return_gelu: bool = False, outs: Optional[int] = None):
     """fc1 of the AdaLN block's FFN up to fc2's GEMM in ONE launch (+ the dual quantizer's tiny NaN fix-up launch):

@@ -88,6 +88,24 @@ class IncrementalKVCache:
         self._group = group if (dtype == torch.float16 and group in (8, 16, 32, 64, 128, 256, 512)) else None
 
     @torch.no_grad()
+    def commit_written(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """`append` for k / v that the producer has ALREADY written into the cache's slots [len, len + n) (the qkv GEMM with a
+        split output, gemm.linear_fp4_qkv_to_cache(..., cache.kv, cache.len, n)): quantizes the previous step's entries - one launch,
+        nothing copied - and returns the same views."""
+        assert self.len + n <= self.k.shape[1], "IncrementalKVCache: max_len exceeded"
+        if self.len > self._prev:
+            a, b = self._prev, self.len
+            if self._group is not None:
+                empty = self.kv[0, :, :0]
+                ops.kv_cache_step(self.kv, a, b, empty, empty, self.len, self._group, "e2m3" if self.kv_bit == 6 else "e2m1")
+            else:
+                self.k[:, a:b].copy_(quantize_kv(self.k[:, a:b].contiguous(), self.kv_bit))
+                self.v[:, a:b].copy_(quantize_kv(self.v[:, a:b].contiguous(), self.kv_bit))
+        self._prev = self.len
+        self.len += n
+        return self.k[:, :self.len], self.v[:, :self.len]
+
+    @torch.no_grad()
     def append(self, k: torch.Tensor, v: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """k, v: [B, n, H, c] (views of a fused qkv output are fine).  Returns the K / V attention runs on at this
         step: everything older than the previous step's entries as quantized before, the previous step's entries

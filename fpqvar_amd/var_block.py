@@ -109,7 +109,7 @@ class GenerationBatch:
 
     def __init__(self, model: str = "d30-256", config: str = "w4a4", depth: Optional[int] = None,
                  batch_rows: Optional[int] = None, device=None, seed: int = 0, fused_fc1: bool = True, sdpa_in_f: bool = False,
-                 kmajor: bool = True):
+                 kmajor: bool = True, qkv_to_cache: bool = True):
         assert model in MODELS and config in ("w4a4", "w6a6")
         self.model, self.config = model, config
         heads, self.patch_nums, rows = MODELS[model]
@@ -123,6 +123,8 @@ class GenerationBatch:
         self.sdpa_in_f = sdpa_in_f                              # path F with torch's SDPA instead of fpq_attention_blhc (rounds 1 - 4 timed it that way)
         self.fused_gelu_quant = fused_fc1                       # path F: GELU + fc2's input quantizer in one pass over the fc1 output
         self.kmajor = kmajor                                    # path Q: operands as k-major images (include/fpq.h): contiguous LDS-DMA pieces
+        # path Q (W4A4): mat_qkv writes k and v straight into the KV cache's slots (fpq_gemm_fp4_mx_split): no copy-in pass
+        self.qkv_to_cache = qkv_to_cache and not self.W6 and hasattr(gemm, "linear_fp4_qkv_to_cache")
         C, HID, B = self.C, self.HID, self.B
         g = torch.Generator(device=dev).manual_seed(seed)
         self.gen = g
@@ -236,12 +238,17 @@ class GenerationBatch:
                     h = Fn.gelu(Fn.linear(self.r_act(x2), self.wq["fc1"]), approximate="tanh")
                     x = x + Fn.linear(self.r_fc2(h), self.wq["fc2"]).mul(g2)
                 continue
-            if path == "F":
-                qkv = Fn.linear(self.f_producer(x, sc1, sh1, self.s_qkv), self.wq["qkv"])
+            if path == "Q" and self.qkv_to_cache:
+                q = gemm.linear_fp4_qkv_to_cache(*rot.adaln_rotate_quant_mx(x, sc1, sh1, smooth=self.s_qkv, kmajor=self.kmajor), *self.wop["qkv"],
+                                                 None, caches[b].kv, caches[b].len, L).view(B, L, H, hd)
+                kc, vc = caches[b].commit_written(L)
             else:
-                qkv = self.q_producer_linear(x, sc1, sh1, self.s_qkv, "qkv")
-            q, k, v = qkv.view(B, L, 3, H, hd).unbind(2)
-            kc, vc = caches[b].append(k, v)
+                if path == "F":
+                    qkv = Fn.linear(self.f_producer(x, sc1, sh1, self.s_qkv), self.wq["qkv"])
+                else:
+                    qkv = self.q_producer_linear(x, sc1, sh1, self.s_qkv, "qkv")
+                q, k, v = qkv.view(B, L, 3, H, hd).unbind(2)
+                kc, vc = caches[b].append(k, v)
             a = self.attend(q, kc, vc) if (path == "F" and self.sdpa_in_f) else ops.attention_blhc(q, kc, vc, hd ** -0.5).view(B, L, C)
             if path == "F":
                 x = ops.gate_residual(Fn.linear(self.f_act(a), self.wq["proj"]), g1, x)

@@ -29,7 +29,7 @@ extern "C" {
                            123: + fpq_build_tag (round 4);
                            124: + fpq_set_option, fpq_get_option, fpq_option_name, fpq_gemm_fp4_gelu_dual, fpq_gelu_quant_rows_dual (round 5);
                            125: + k-major operand images: fpq_codes_to_kmajor, fpq_scales_to_kmajor, fpq_gemm_fp4_mx_km, fpq_gemm_fp4_gelu_dual_km,
-                                fpq_gemm_fp6_rows_km and the *_km producers (round 5) */
+                                fpq_gemm_fp6_rows_km, the *_km producers, fpq_gemm_fp4_mx_split (round 5) */
 
 typedef void* fpq_stream_t; /* hipStream_t */
 
@@ -493,6 +493,25 @@ int fpq_adaln_rotate_quant_token_rows_codes_fp6_km(const void* x, uint8_t* image
                                                    int in_dtype, const void* scale, const void* shift, int mod_dtype,
                                                    int64_t rows_per_batch, float eps, const float* smooth,
                                                    const uint32_t* sign_mask_host, int table_id, fpq_stream_t stream);
+/* The FP4 GEMM with a SPLIT OUTPUT: the outs columns are n_parts (<= 3) parts of part_cols (% 128 == 0) each, and every part has
+ * its own destination: token t = b * rows_per_batch + l of part p is written to row  b * batch_stride[p] + row0[p] + l  of out[p]
+ * (fp16, row_stride[p] elements per row, >= part_cols, % 4 == 0, 8-byte aligned).  What it is for: mat_qkv of an attention block
+ * (tr/basic_var.py:173-209) - q to its own [B, L, H * c] tensor, k and v straight into the KV cache's slots [B, max_len, H * c] at
+ * token position `len` (batch_stride = max_len, row0 = len), so that the cache's copy-in pass (60 % of the bytes
+ * fpq_kv_cache_step moves) never runs: fpq_kv_cache_step then only quantizes the previous step's entries (n = 0).
+ * Same arithmetic as fpq_gemm_fp4_mx_ex / _km (kmajor: 0 row-major operands, 1 k-major images); no gate / residual tail. */
+typedef struct fpq_gemm_split {
+  int64_t part_cols;
+  int32_t n_parts;
+  void* out[3];
+  int64_t row_stride[3];
+  int64_t rows_per_batch;
+  int64_t batch_stride[3];
+  int64_t row0[3];
+} fpq_gemm_split_t;
+int fpq_gemm_fp4_mx_split(const uint8_t* a_codes, const void* a_scales, const uint8_t* w_codes, const void* w_scales, int w_scale_dtype,
+                          const void* bias, int64_t tokens, int64_t outs, int64_t k, const fpq_gemm_split_t* split, int kmajor,
+                          fpq_stream_t stream);
 int fpq_gemm_fp6_rows_km(const uint8_t* a_image, const void* a_scales, int a_scale_dtype, const uint8_t* w_image,
                          const void* w_scales, int w_scale_dtype, const void* bias, void* out, int64_t tokens,
                          int64_t outs, int64_t k, const fpq_gemm_epilogue_t* epilogue, fpq_stream_t stream);

@@ -28,12 +28,14 @@ def main():
     ap.add_argument("--unfused-fc1", action="store_true", help="Q path: GEMM, GELU and the dual quantizer as three launches")
     ap.add_argument("--sdpa-in-f", action="store_true", help="path F with torch's SDPA instead of fpq_attention_blhc (as rounds 1 - 4 timed it)")
     ap.add_argument("--row-major-operands", action="store_true", help="Q path: row-major code tensors instead of k-major images (the form of rounds 1 - 4)")
+    ap.add_argument("--qkv-copy-in", action="store_true", help="Q path: mat_qkv writes one [tokens, 3 C] tensor and the cache copies k / v in (the form before fpq_gemm_fp4_mx_split)")
     ap.add_argument("--tuned-gemms", action="store_true", help="torch's own GEMMs with the recorded TunableOp selections (var_block.tuned_torch_gemms)")
     args = ap.parse_args()
     torch.manual_seed(0)
     gb = var_block.GenerationBatch(args.model, args.config, depth=args.depth, batch_rows=args.batch, device="cuda:0",
-                                   fused_fc1=not args.unfused_fc1, sdpa_in_f=args.sdpa_in_f, kmajor=not args.row_major_operands)
-    res = {"workload": gb.describe(), "depth": gb.depth, "batch_rows": gb.B, "fc1_epilogue_fused": gb.fused_fc1, "kmajor_operands": gb.kmajor,
+                                   fused_fc1=not args.unfused_fc1, sdpa_in_f=args.sdpa_in_f, kmajor=not args.row_major_operands,
+                                   qkv_to_cache=not args.qkv_copy_in)
+    res = {"workload": gb.describe(), "depth": gb.depth, "batch_rows": gb.B, "fc1_epilogue_fused": gb.fused_fc1, "kmajor_operands": gb.kmajor, "qkv_to_cache": gb.qkv_to_cache,
            "library": _lib.build_tag()}
     paths = args.paths.split(",")
     import contextlib
