@@ -3,6 +3,7 @@ argument validation that needs no GPU; the host mirror refuses CPU tensors."""
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 import torch
@@ -157,3 +158,22 @@ def test_options_roundtrip_and_env_is_read_once(lib, monkeypatch):
     env = dict(os.environ, FPQ_NO_HW4="yes", FPQ_NO_HW6="0", FPQ_GEMM_CFG="20", FPQ_NO_FAST32="", FPQ_ADALN_ROWS="12")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
     assert out == ["1", "0", "20", "None", "12"], out
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fpq.h is the boundary a cgo / JNI / ctypes binding compiles against: it must be valid C99 on its own (no torch, no
+    HIP headers), and the structs the Python layer mirrors must have the sizes ctypes gives them."""
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    from fpqvar_amd import _lib
+    src = tmp_path / "hdr.c"
+    src.write_text('#include <stdio.h>\n#include "fpq.h"\nint main(void) { printf("%zu %zu %zu %d\\n", sizeof(fpq_gemm_epilogue_t), '
+                   'sizeof(fpq_gemm_split_t), sizeof(fpq_segment_t), FPQ_VERSION); return 0; }\n')
+    exe = tmp_path / "hdr"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    import ctypes
+    assert int(out[0]) == ctypes.sizeof(_lib.GemmEpilogue) and int(out[1]) == ctypes.sizeof(_lib.GemmSplit) and int(out[2]) == ctypes.sizeof(_lib.Segment)
+    assert int(out[3]) == FPQ_VERSION
