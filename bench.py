@@ -897,7 +897,7 @@ def generation(plat, dist, world, rank, stage):
             t = plat.torch.tensor([float(ranks_ok)], dtype=plat.torch.float64, device=plat.dev if plat.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             ranks_ok = int(t.item())
-        line = {k: rec[k] for k in ("model", "path", "config", "what", "images_per_batch", "clock", "warmup_eager_ms", "torch_gemms", "operands") if k in rec}
+        line = {k: rec[k] for k in ("model", "path", "config", "what", "images_per_batch", "clock", "warmup_eager_ms", "torch_gemms", "operands", "kv_cache") if k in rec}
         line.update({"model": model, "path": path, "replicas": world, "replicas_ok": ranks_ok})
         if ranks_ok == world and rate > 0:
             line["ms_per_batch"] = round(total / rate * 1e3, 2)               # the slowest replica's batch (total / rate = its seconds)

@@ -332,6 +332,8 @@ def generation_record(models: Sequence[str] = ("d30-256", "d36-512"), paths: Seq
             rec = {"model": model, "path": path, "config": config, "images_per_batch": gb.B // 2, "what": WHAT[model]}
             if path == "Q":
                 rec["operands"] = "k-major images (include/fpq.h)" if gb.kmajor else "row-major codes"
+                rec["kv_cache"] = ("k, v written into the cache's slots by mat_qkv's GEMM (fpq_gemm_fp4_mx_split), one quantization pass per step"
+                                   if gb.qkv_to_cache else "one launch per step: quantization pass + copy-in of k, v")
             try:
                 if tuned_gemms:
                     with tuned_torch_gemms() as tg:
